@@ -1,0 +1,147 @@
+/* nmrgnn_hip.h — C ABI of libnmrgnn_hip.so: the MI355X (gfx950) engine for nmrgnn's
+ * message-passing hot path.
+ *
+ * The reference (ur-whitelab/nmrgnn v0.7) is pure Python/TensorFlow and has NO plugin /
+ * FFI / custom-op interface; this ABI is therefore defined here, one entry point per stage
+ * of GNNModel.call (nmrgnn/model.py:245-274), and each declaration cites the reference
+ * lines it replaces.  INTEGRATION.md shows the reference-side (ctypes) binding.
+ *
+ * Conventions
+ *   - every pointer named *_dev (and every float* / int32_t* tensor argument) is a DEVICE pointer owned
+ *     by the caller (torch allocations in the Python host); the library allocates only the
+ *     opaque ng_ctx (scratch workspace, profiling events).
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream
+ *     and never synchronises the device.
+ *   - return 0 = NG_OK, negative = error; message via ng_last_error(ctx).  Nothing throws.
+ *   - all tensors are fp32 row-major; index tensors are int32.
+ *   - a ctx is not thread-safe: one per host thread / GPU.
+ */
+#ifndef NMRGNN_HIP_H
+#define NMRGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NG_ABI_VERSION 1
+
+enum {
+  NG_OK = 0,
+  NG_ERR_INVALID = -1, /* bad shape / argument */
+  NG_ERR_HIP = -2,     /* HIP runtime error */
+  NG_ERR_NOMEM = -3,
+  NG_ERR_UNSUPPORTED = -4
+};
+
+/* keras activation names of hypers mp_activation / fc_activation (nmrgnn/model.py:33-36) */
+enum { NG_ACT_NONE = 0, NG_ACT_SOFTPLUS = 1, NG_ACT_RELU = 2, NG_ACT_TANH = 3 };
+
+typedef struct ng_ctx ng_ctx;
+
+int ng_abi_version(void);
+int ng_ctx_create(int device, ng_ctx** out);
+void ng_ctx_destroy(ng_ctx* ctx);
+const char* ng_last_error(ng_ctx* ctx);
+/* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
+int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
+
+/* per-kernel hipEvent bracketing for bench.py's roofline leg */
+int ng_prof_enable(ng_ctx* ctx, int on);
+int ng_prof_reset(ng_ctx* ctx);
+/* synchronises the recorded events; returns number of distinct kernel names (<= cap).
+ * names[i] points to a static string; total_ms[i] / count[i] aggregate launches. */
+int ng_prof_read(ng_ctx* ctx, int cap, const char** names, double* total_ms, int64_t* count);
+
+/* ---- RNG (explicit draws so that tests can feed the same numbers to the oracle) ------------ */
+/* xi ~ N(0,1): the draw inside keras GaussianNoise, nmrgnn/model.py:213,253 */
+int ng_randn(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, float* out, int64_t n);
+/* keras Dropout keep-mask, nmrgnn/model.py:216-219,266-267: out = 1/keep with prob keep, else 0 */
+int ng_dropout_mask(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, float keep, float* out,
+                    int64_t n);
+
+/* out = x + alpha*y : applies the GaussianNoise draw, d_eff = d + sigma*xi (nmrgnn/model.py:253) */
+int ng_add_scaled(ng_ctx*, void* stream, int64_t n, const float* x, const float* y, float alpha,
+                  float* out);
+
+/* ---- edge path: mask + RBFExpansion + EdgeFCBlock ------------------------------------------
+ * replaces nmrgnn/model.py:251-261, nmrgnn/layers.py:137-140, nmrgnn/model.py:132-138.
+ *   d_src  [n_edges]  raw distances (mask = d_src > 0)
+ *   d_eff  [n_edges]  distances fed to the RBF (= d_src, or d_src + sigma*xi when training)
+ *   centers[H], gap   RBF grid (layers.py:126-129)
+ *   W[t] [in,out], b[t] [out]  host arrays (length Le) of device pointers, Keras Dense layout
+ *   e_out  [n_edges,E]
+ *   z_save [Le-1, n_edges, H] softplus outputs of the hidden layers (NULL for inference)
+ */
+int ng_edge_mlp_fwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
+                    const float* d_src, const float* d_eff, const float* centers, float gap,
+                    const float* const* W, const float* const* b, float* e_out, float* z_save);
+/* de [n_edges,E] upstream gradient; writes dW[t], db[t] (overwrites) */
+int ng_edge_mlp_bwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
+                    const float* d_src, const float* d_eff, const float* centers, float gap,
+                    const float* const* W, const float* z_save, const float* de,
+                    float* const* dW, float* const* db);
+
+/* ---- node path ----------------------------------------------------------------------------- */
+/* embed_layer, nmrgnn/model.py:241,262: h0 = atoms[N,C] @ Wemb[C,F] */
+int ng_embed_fwd(ng_ctx*, void* stream, int64_t N, int C, int F, const float* atoms,
+                 const float* Wemb, float* h0);
+int ng_embed_bwd(ng_ctx*, void* stream, int64_t N, int C, int F, const float* atoms,
+                 const float* dh0, float* dWemb);
+
+/* MPLayer aggregation, nmrgnn/layers.py:33 + the (i,j)-contraction of layers.py:39-40:
+ *   A[i,n,l] = sum_j e[i,j,n] * h[nlist[i,j], l]        A is [N,E,F] */
+int ng_mp_aggregate(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const float* h,
+                    const int32_t* nlist, const float* e, float* A);
+
+/* MPLayer + residual, nmrgnn/layers.py:26-46 and nmrgnn/model.py:165-167:
+ *   P = inv_degree * einsum('ijn,ijl,lmn->im', e, h[nlist], w);  h_out = act(P) + h
+ *   w is the reference layout [F,F,E].  A_save [N,E,F] and s_save [N,F] (= act(P)) are written
+ *   when non-NULL (training). */
+int ng_mp_layer_fwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act,
+                    const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
+                    const float* w, float* h_out, float* A_save, float* s_save);
+/* backward of the above.  csc_ptr[N+1], csc_edge[nnz]: incoming-edge lists (edge id = i*K+j
+ * grouped by target nlist[i,j]); dh_out [N,F] upstream; writes dh_in (overwrite),
+ * de (accumulate if de_accum else overwrite), dw [F,F,E] (overwrite). */
+int ng_mp_layer_bwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act,
+                    const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
+                    const float* w, const float* A_save, const float* s_save,
+                    const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out,
+                    float* dh_in, float* de, int de_accum, float* dw);
+
+/* keras Dense (+ residual), nmrgnn/model.py:191-196:  Y = act(X@W + b) (+ X if residual)
+ *   s_save [M,Nout] = act(X@W+b) written when non-NULL */
+int ng_dense_fwd(ng_ctx*, void* stream, int64_t M, int Kin, int Nout, int act, int residual,
+                 const float* X, const float* W, const float* b, float* Y, float* s_save);
+/* dX = (residual ? dY : 0) + dP @ W^T,  dW = X^T dP,  db = colsum dP,
+ * dP = dY * act'(.) recovered from s_save (softplus: 1-exp(-s)).  dX may be NULL. */
+int ng_dense_bwd(ng_ctx*, void* stream, int64_t M, int Kin, int Nout, int act, int residual,
+                 const float* X, const float* W, const float* s_save, const float* dY, float* dX,
+                 float* dW, float* db);
+
+/* dropout + out_layer + de-standardisation, nmrgnn/model.py:266-273:
+ *   peaks[i] = sum_c atoms[i,c]*((g*mask)[i,:]@Wout[:,c] + bout[c])*std[c] + atoms[i,c]*avg[c] */
+int ng_head_fwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
+                const float* drop_mask, const float* Wout, const float* bout, const float* atoms,
+                const float* peak_std, const float* peak_avg, float* peaks);
+int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
+                const float* drop_mask, const float* Wout, const float* atoms,
+                const float* peak_std, const float* dpeaks, float* dg, float* dWout, float* dbout);
+
+/* ---- training: NameLoss (s = 1), nmrgnn/losses.py:30-39, batched over graphs -----------------
+ *   loss = mean_g  sum_{i in g} w_i (y_i - pred_i)^2 / sum_{i in g} w_i   (divide_no_nan)
+ *   dpred written for backward; loss_out is one device float. */
+int ng_loss_l2(ng_ctx*, void* stream, int64_t N, int G, const int32_t* graph_ptr, const float* y,
+               const float* w, const float* pred, float* loss_out, float* dpred);
+
+/* Keras Adam (nmrgnn/model.py:44-45): one fused pass over the flat parameter buffer.
+ *   g is first multiplied by grad_scale (1/world_size after a summing all-reduce). */
+int ng_adam_step(ng_ctx*, void* stream, int64_t n, float* p, const float* g, float* m, float* v,
+                 float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMRGNN_HIP_H */

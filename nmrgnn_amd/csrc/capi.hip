@@ -1,0 +1,134 @@
+// Context, error reporting, scratch workspace and per-kernel hipEvent profiling.
+#include <cstring>
+#include <map>
+
+#include "ng_common.h"
+
+namespace ng {
+
+void* workspace(ng_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return ctx->ws;
+  // grow (1.5x headroom); synchronises the device because older launches may still use the block
+  size_t want = bytes + bytes / 2;
+  if (ctx->ws) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    ctx->err = std::string("workspace hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+    return nullptr;
+  }
+  ctx->ws = p;
+  ctx->ws_bytes = want;
+  return p;
+}
+
+ProfScope::ProfScope(ng_ctx* c, hipStream_t s, const char* name) : ctx(c), stream(s) {
+  if (!ctx || !ctx->prof) return;
+  hipEvent_t a = nullptr, b = nullptr;
+  if (ctx->pool.size() >= 2) {
+    a = ctx->pool.back(); ctx->pool.pop_back();
+    b = ctx->pool.back(); ctx->pool.pop_back();
+  } else {
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  }
+  (void)hipEventRecord(a, stream);
+  ctx->recs.push_back({name, a, b});
+  stop = b;
+}
+
+ProfScope::~ProfScope() {
+  if (stop) (void)hipEventRecord(stop, stream);
+}
+
+}  // namespace ng
+
+extern "C" int ng_abi_version(void) { return NG_ABI_VERSION; }
+
+extern "C" int ng_ctx_create(int device, ng_ctx** out) {
+  if (!out) return NG_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return NG_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return NG_ERR_HIP;
+  ng_ctx* ctx = new (std::nothrow) ng_ctx();
+  if (!ctx) return NG_ERR_NOMEM;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return NG_OK;
+}
+
+extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  for (auto& r : ctx->recs) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  for (auto e : ctx->pool) (void)hipEventDestroy(e);
+  delete ctx;
+}
+
+extern "C" const char* ng_last_error(ng_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return NG_ERR_INVALID;
+  return ng::workspace(ctx, (size_t)bytes) ? NG_OK : NG_ERR_NOMEM;
+}
+
+extern "C" int ng_prof_enable(ng_ctx* ctx, int on) {
+  if (!ctx) return NG_ERR_INVALID;
+  ctx->prof = on != 0;
+  return NG_OK;
+}
+
+extern "C" int ng_prof_reset(ng_ctx* ctx) {
+  if (!ctx) return NG_ERR_INVALID;
+  for (auto& r : ctx->recs) {
+    ctx->pool.push_back(r.start);
+    ctx->pool.push_back(r.stop);
+  }
+  ctx->recs.clear();
+  return NG_OK;
+}
+
+extern "C" int ng_prof_read(ng_ctx* ctx, int cap, const char** names, double* total_ms,
+                            int64_t* count) {
+  if (!ctx) return NG_ERR_INVALID;
+  std::vector<const char*> order;
+  std::map<std::string, int> index;
+  std::vector<double> tot;
+  std::vector<int64_t> cnt;
+  for (auto& r : ctx->recs) {
+    if (hipEventSynchronize(r.stop) != hipSuccess) return ng::fail(ctx, NG_ERR_HIP, "prof sync");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+    auto it = index.find(r.name);
+    int k;
+    if (it == index.end()) {
+      k = (int)order.size();
+      index[r.name] = k;
+      order.push_back(r.name);
+      tot.push_back(0.0);
+      cnt.push_back(0);
+    } else {
+      k = it->second;
+    }
+    tot[k] += ms;
+    cnt[k] += 1;
+  }
+  int n = (int)order.size();
+  if (n > cap) n = cap;
+  for (int i = 0; i < n; ++i) {
+    names[i] = order[i];
+    total_ms[i] = tot[i];
+    count[i] = cnt[i];
+  }
+  return n;
+}

@@ -1,0 +1,257 @@
+// Dense (fully-connected) forward / backward on the fp32 MFMA tile GEMM.
+// Replaces keras Dense as used by nmrgnn/model.py:111-138 (EdgeFCBlock), 179-196 (FCBlock) and the
+// [N,F*E]x[F*E,F] contraction of nmrgnn/layers.py:39-40 (MPLayer, aggregate-then-GEMM order).
+#include <algorithm>
+
+#include "mfma_gemm.cuh"
+#include "ng_internal.h"
+
+namespace ng {
+
+// ---------------------------------------------------------------- epilogues
+struct EpiDense {
+  float* Y;
+  float* S;
+  const float* bias;
+  const float* rowscale;
+  const float* R;
+  int N;
+  int act;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float4 v, int) const {
+    if (rowscale) {
+      const float s = rowscale[m];
+      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    }
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (act != NG_ACT_NONE) {
+      v.x = act_apply(act, v.x); v.y = act_apply(act, v.y);
+      v.z = act_apply(act, v.z); v.w = act_apply(act, v.w);
+    }
+    const int64_t o = m * N + n;
+    if (S) *reinterpret_cast<float4*>(S + o) = v;
+    if (R) {
+      const float4 r = *reinterpret_cast<const float4*>(R + o);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(Y + o) = v;
+  }
+};
+
+struct EpiAdd {
+  float* out;
+  const float* add;
+  int N;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float4 v, int) const {
+    const int64_t o = m * N + n;
+    if (add) {
+      const float4 r = *reinterpret_cast<const float4*>(add + o);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + o) = v;
+  }
+};
+
+struct EpiPartial {
+  float* partial;  // [nz][Mo][No]
+  int64_t Mo;
+  int No;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float4 v, int z) const {
+    *reinterpret_cast<float4*>(partial + ((int64_t)z * Mo + m) * No + n) = v;
+  }
+};
+
+// ---------------------------------------------------------------- partial reductions
+// out[map(idx)] = sum_z partial[z][idx]
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nz, int64_t n_elem,
+                                       float* __restrict__ out, int w_map, int F, int E,
+                                       int Nout) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_elem;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n_elem + idx];
+    int64_t o = idx;
+    if (w_map == 1) {  // idx = k*Nout + m, k = ne*F + l  ->  (l*F + m)*E + ne
+      const int k = (int)(idx / Nout), m = (int)(idx % Nout);
+      const int ne = k / F, l = k % F;
+      o = ((int64_t)l * F + m) * E + ne;
+    }
+    out[o] = s;
+  }
+}
+
+// column sums of dP (bias gradient), stage 1: partial[blk][n]
+template <class LoadP>
+__global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int N, int64_t rows_per_block,
+                                                     LoadP lp, float* __restrict__ partial) {
+  __shared__ float4 red[256];
+  const int c4n = N / 4;
+  const int rl_n = 256 / c4n;  // row lanes
+  const int tid = threadIdx.x;
+  const int c4 = tid % c4n, rl = tid / c4n;
+  float4 s = f4zero();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  if (rl < rl_n) {
+    for (int64_t r = r0 + rl; r < r1; r += rl_n) {
+      const float4 v = lp(r, c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (tid < c4n) {
+    float4 t = red[tid];
+    for (int j = 1; j < rl_n; ++j) {
+      const float4 v = red[tid + j * c4n];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * N + tid * 4) = t;
+  }
+}
+
+// ---------------------------------------------------------------- launch helpers
+template <int BM, int BN, int WM, int WN, bool QKC, bool PKC, class LQ, class LP, class EP>
+static void launch_gemm(hipStream_t st, int64_t M, int N, int64_t K, int64_t k_chunk, int nz,
+                        LQ lq, LP lp, EP ep) {
+  dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN), (unsigned)nz);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, 32, WM, WN, QKC, PKC, LQ, LP, EP>), grid, dim3(256), 0,
+                     st, M, N, K, k_chunk, lq, lp, ep);
+}
+
+int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
+              const float* W, const float* b, const float* rowscale, const float* R, float* Y,
+              float* S) {
+  NG_REQUIRE(ctx, Kin % 8 == 0 && Nout % 4 == 0, "dense_fwd: Kin%8, Nout%4");
+  if (M == 0) return NG_OK;
+  ProfScope ps(ctx, st, "dense_fwd");
+  LoadPlain lq{X, M, Kin, Kin};
+  LoadPlain lp{W, Kin, Nout, Nout};
+  EpiDense ep{Y, S, b, rowscale, R, Nout, act};
+  if (Nout > 64)
+    launch_gemm<128, 128, 2, 2, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep);
+  else
+    launch_gemm<128, 64, 4, 1, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY,
+             const float* S, const float* rowscale, const float* W, const float* add, float* dX) {
+  NG_REQUIRE(ctx, Nout % 8 == 0 && Kin % 4 == 0, "dense_dx: Nout%8, Kin%4");
+  if (M == 0) return NG_OK;
+  ProfScope ps(ctx, st, "dense_dx");
+  LoadGradAct lq{dY, act == NG_ACT_NONE ? nullptr : S, rowscale, M, Nout, act};
+  LoadPlain lp{W, Kin, Nout, Nout};  // [k_out][n]: K-contiguous along the contraction n
+  EpiAdd ep{dX, add, Kin};
+  if (Kin > 64)
+    launch_gemm<128, 128, 2, 2, true, true>(st, M, Kin, Nout, Nout, 1, lq, lp, ep);
+  else
+    launch_gemm<128, 64, 4, 1, true, true>(st, M, Kin, Nout, Nout, 1, lq, lp, ep);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+struct DwPlan {
+  int64_t nz, k_chunk, cs_blocks, cs_rows;
+  bool big_n;
+};
+
+static DwPlan dw_plan(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
+  DwPlan p;
+  p.big_n = Nout > 64;
+  const int BMo = 128, BNo = p.big_n ? 128 : 64;
+  const int64_t tiles = cdiv(Kin, BMo) * cdiv(Nout, BNo);
+  // split the contraction (rows) so that ~2 workgroups per CU are in flight
+  int64_t nz = cdiv((int64_t)2 * ctx->num_cu, tiles);
+  const int64_t max_z = std::max<int64_t>(cdiv(M, 32), 1);
+  nz = std::max<int64_t>(std::min(nz, max_z), 1);
+  p.k_chunk = std::max<int64_t>(cdiv(cdiv(M, nz), 32) * 32, 32);
+  p.nz = std::max<int64_t>(cdiv(M, p.k_chunk), 1);
+  p.cs_blocks = has_db ? std::min<int64_t>(std::max<int64_t>(cdiv(M, 4096), 1), 1024) : 0;
+  p.cs_rows = has_db ? cdiv(M, p.cs_blocks) : 0;
+  return p;
+}
+
+size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
+  const DwPlan p = dw_plan(ctx, M, Kin, Nout, has_db);
+  return (size_t)(p.nz * (int64_t)Kin * Nout + p.cs_blocks * Nout);
+}
+
+int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
+             const float* dY, const float* S, const float* rowscale, float* dW, float* db,
+             int w_map, int F, int E, float* scratch) {
+  if (act == NG_ACT_NONE) S = nullptr;
+  NG_REQUIRE(ctx, Kin % 4 == 0 && Nout % 4 == 0, "dense_dw: Kin%4, Nout%4");
+  const int64_t n_elem = (int64_t)Kin * Nout;
+  if (M == 0) {
+    NG_HIP(ctx, hipMemsetAsync(dW, 0, n_elem * sizeof(float), st));
+    if (db) NG_HIP(ctx, hipMemsetAsync(db, 0, Nout * sizeof(float), st));
+    return NG_OK;
+  }
+  const DwPlan p = dw_plan(ctx, M, Kin, Nout, db != nullptr);
+  float* partial = scratch;
+  float* cs_partial = scratch + p.nz * n_elem;
+  {
+    ProfScope ps(ctx, st, "dense_dw");
+    LoadPlain lq{X, M, Kin, Kin};
+    LoadGradAct lp{dY, S, rowscale, M, Nout, act};
+    EpiPartial ep{partial, Kin, Nout};
+    if (p.big_n)
+      launch_gemm<128, 128, 2, 2, false, false>(st, Kin, Nout, M, p.k_chunk, (int)p.nz, lq, lp, ep);
+    else
+      launch_gemm<128, 64, 4, 1, false, false>(st, Kin, Nout, M, p.k_chunk, (int)p.nz, lq, lp, ep);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  {
+    ProfScope ps(ctx, st, "reduce_partials");
+    const int blocks = (int)std::min<int64_t>(cdiv(n_elem, 256), 1024);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, partial, (int)p.nz,
+                       n_elem, dW, w_map, F, E, Nout);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  if (db) {
+    NG_REQUIRE(ctx, Nout / 4 <= 256, "dense_dw: Nout <= 1024 for the bias gradient");
+    ProfScope ps(ctx, st, "bias_grad");
+    LoadGradAct lp{dY, S, rowscale, M, Nout, act};
+    hipLaunchKernelGGL((colsum_kernel<LoadGradAct>), dim3((unsigned)p.cs_blocks), dim3(256), 0, st,
+                       M, Nout, p.cs_rows, lp, cs_partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, cs_partial,
+                       (int)p.cs_blocks, (int64_t)Nout, db, 0, 0, 0, Nout);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  return NG_OK;
+}
+
+}  // namespace ng
+
+// ------------------------------------------------------------------- C ABI
+extern "C" int ng_dense_fwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int Nout, int act,
+                            int residual, const float* X, const float* W, const float* b, float* Y,
+                            float* s_save) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, !residual || Kin == Nout, "ng_dense_fwd: residual needs Kin == Nout");
+  return ng::dense_fwd(ctx, (hipStream_t)stream, M, Kin, Nout, act, X, W, b, nullptr,
+                       residual ? X : nullptr, Y, s_save);
+}
+
+extern "C" int ng_dense_bwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int Nout, int act,
+                            int residual, const float* X, const float* W, const float* s_save,
+                            const float* dY, float* dX, float* dW, float* db) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, !residual || Kin == Nout, "ng_dense_bwd: residual needs Kin == Nout");
+  NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "ng_dense_bwd: activation backward needs s_save");
+  const float* S = s_save;
+  hipStream_t st = (hipStream_t)stream;
+  if (dX) {
+    int rc = ng::dense_dx(ctx, st, M, Kin, Nout, act, dY, S, nullptr, W, residual ? dY : nullptr, dX);
+    if (rc) return rc;
+  }
+  float* scratch = (float*)ng::workspace(
+      ctx, ng::dense_dw_scratch_floats(ctx, M, Kin, Nout, db != nullptr) * sizeof(float));
+  if (!scratch) return NG_ERR_NOMEM;
+  return ng::dense_dw(ctx, st, M, Kin, Nout, act, X, dY, S, nullptr, dW, db, 0, 0, 0, scratch);
+}

@@ -1,0 +1,658 @@
+// Node-side kernels: embedding, neighbour aggregation (gather + edge-weighted segment sum),
+// MPLayer forward/backward, output head, loss, Adam, RNG.
+// Reference: nmrgnn/layers.py:26-46 (MPLayer), nmrgnn/model.py:158-169 (MPBlock), 236-274 (GNNModel),
+// nmrgnn/losses.py:30-39 (NameLoss s=1).
+#include <algorithm>
+
+#include "mfma_gemm.cuh"
+#include "ng_internal.h"
+
+namespace ng {
+
+constexpr int MAX_E = 8;   // edge_feature_size choices {1,2,3,8} (64 is not supported yet)
+constexpr int MAX_C = 32;  // one-hot width
+
+// ------------------------------------------------------------------------------------ embedding
+// h0[i][f] = sum_c atoms[i][c] * Wemb[c][f]      (model.py:262; Dense without bias)
+__global__ void embed_fwd_kernel(int64_t N, int C, int F, const float* __restrict__ atoms,
+                                 const float* __restrict__ Wemb, float* __restrict__ h0) {
+  const int c4n = F / 4;
+  const int64_t total = N * c4n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / c4n;
+    const int c4 = (int)(t % c4n);
+    float4 acc = f4zero();
+    for (int c = 0; c < C; ++c) {
+      const float a = atoms[i * C + c];
+      if (a != 0.f) {
+        const float4 w = *reinterpret_cast<const float4*>(Wemb + (int64_t)c * F + c4 * 4);
+        acc.x += a * w.x; acc.y += a * w.y; acc.z += a * w.z; acc.w += a * w.w;
+      }
+    }
+    *reinterpret_cast<float4*>(h0 + i * F + c4 * 4) = acc;
+  }
+}
+
+// dWemb[c][f] = sum_i atoms[i][c] dh0[i][f]  — stage 1: partial[blk][c][f] over a row chunk
+__global__ __launch_bounds__(256) void embed_bwd_kernel(int64_t N, int C, int F,
+                                                        int64_t rows_per_block,
+                                                        const float* __restrict__ atoms,
+                                                        const float* __restrict__ dh0,
+                                                        float* __restrict__ partial) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
+  const int items = C * F;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int c = it / F, f = it % F;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += atoms[r * C + c] * dh0[r * F + f];
+    partial[(int64_t)blockIdx.x * items + it] = s;
+  }
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nz, int64_t n_elem,
+                                    float* __restrict__ out) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_elem;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n_elem + idx];
+    out[idx] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ aggregation
+// A[i][n][l] = sum_j e[i][j][n] * h[nlist[i][j]][l]        (layers.py:33 + ij-contraction of 39-40)
+// F/4 lanes per atom (float4 of features each); the block's nlist / e rows are staged in LDS with
+// coalesced loads and then broadcast.
+template <int E>
+__global__ __launch_bounds__(256) void aggregate_kernel(int64_t N, int K, int F,
+                                                        const float* __restrict__ h,
+                                                        const int32_t* __restrict__ nlist,
+                                                        const float* __restrict__ e,
+                                                        float* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int c4n = F / 4;
+  const int apb = 256 / c4n;  // atoms per block
+  int32_t* s_nl = reinterpret_cast<int32_t*>(smem_raw);          // [apb*K]
+  float* s_e = reinterpret_cast<float*>(smem_raw) + apb * K;     // [apb*K*E]
+  const int64_t i0 = (int64_t)blockIdx.x * apb;
+  const int64_t n_at = std::min<int64_t>(apb, N - i0);
+  for (int t = threadIdx.x; t < n_at * K; t += 256) s_nl[t] = nlist[i0 * K + t];
+  for (int t = threadIdx.x; t < n_at * K * E; t += 256) s_e[t] = e[i0 * K * E + t];
+  __syncthreads();
+  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
+  if (a >= n_at) return;
+  float4 acc[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) acc[n] = f4zero();
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  for (int j = 0; j < K; ++j) {
+    const int idx = s_nl[a * K + j];
+    const float4 hv = h4[(int64_t)idx * c4n + c4];
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+      const float ev = s_e[(a * K + j) * E + n];
+      acc[n].x += ev * hv.x; acc[n].y += ev * hv.y; acc[n].z += ev * hv.z; acc[n].w += ev * hv.w;
+    }
+  }
+  float4* A4 = reinterpret_cast<float4*>(A);
+#pragma unroll
+  for (int n = 0; n < E; ++n) A4[((i0 + a) * E + n) * c4n + c4] = acc[n];
+}
+
+static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h,
+                     const int32_t* nlist, const float* e, float* A) {
+  NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 1024 && (256 % (F / 4)) == 0,
+             "aggregate: F in {16,32,64,128,256,512,1024}");
+  NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "aggregate: edge_feature_size <= 8");
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, st, "mp_aggregate");
+  const int apb = 256 / (F / 4);
+  const size_t lds = (size_t)apb * K * (1 + E) * 4;
+  const dim3 grid((unsigned)cdiv(N, apb));
+#define NG_AGG(EE)                                                                              \
+  case EE:                                                                                      \
+    hipLaunchKernelGGL((aggregate_kernel<EE>), grid, dim3(256), lds, st, N, K, F, h, nlist, e, A); \
+    break;
+  switch (E) {
+    NG_AGG(1) NG_AGG(2) NG_AGG(3) NG_AGG(4) NG_AGG(5) NG_AGG(6) NG_AGG(7) NG_AGG(8)
+  }
+#undef NG_AGG
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+// w[l][m][n] (reference layout, n fastest) -> Wp[k = n*F + l][m]
+__global__ void repack_w_kernel(int F, int E, const float* __restrict__ w, float* __restrict__ Wp) {
+  const int total = F * F * E;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int k = idx / F, m = idx % F;
+    const int n = k / F, l = k % F;
+    Wp[idx] = w[((int64_t)l * F + m) * E + n];
+  }
+}
+
+int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp) {
+  const int total = F * F * E;
+  hipLaunchKernelGGL(repack_w_kernel, dim3(std::min(cdiv(total, 256), (int64_t)1024)), dim3(256), 0,
+                     st, F, E, w, Wp);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+// de[i][j][n] (+)= sum_l dA[i][n][l] * h[nlist[i][j]][l]
+template <int E>
+__global__ __launch_bounds__(256) void edge_grad_kernel(int64_t N, int K, int F,
+                                                        const float* __restrict__ h,
+                                                        const int32_t* __restrict__ nlist,
+                                                        const float* __restrict__ dA,
+                                                        float* __restrict__ de, int accumulate) {
+  const int c4n = F / 4;  // power of two, <= 64: an atom's lanes sit inside one wave
+  const int apb = 256 / c4n;
+  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
+  const int64_t i = (int64_t)blockIdx.x * apb + a;
+  const bool live = i < N;
+  const int64_t ii = live ? i : 0;
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  float4 g[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) g[n] = dA4[(ii * E + n) * c4n + c4];
+  for (int j = 0; j < K; ++j) {
+    const int idx = nlist[ii * K + j];
+    const float4 hv = h4[(int64_t)idx * c4n + c4];
+    float part[E];
+#pragma unroll
+    for (int n = 0; n < E; ++n)
+      part[n] = g[n].x * hv.x + g[n].y * hv.y + g[n].z * hv.z + g[n].w * hv.w;
+    for (int off = c4n >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int n = 0; n < E; ++n) part[n] += __shfl_xor(part[n], off, 64);
+    }
+    if (live && c4 == 0) {
+#pragma unroll
+      for (int n = 0; n < E; ++n) {
+        const int64_t o = (i * K + j) * E + n;
+        de[o] = accumulate ? de[o] + part[n] : part[n];
+      }
+    }
+  }
+}
+
+// dh_in[t][l] = dh_out[t][l] + sum_{p in csc[t]} sum_n e[p][n] * dA[p / K][n][l]
+// (deterministic "pull" form of the scatter-add  dh[nlist[i][j]] += sum_n e_ijn dA_iln)
+template <int E>
+__global__ __launch_bounds__(256) void scatter_pull_kernel(int64_t N, int K, int F,
+                                                           const int32_t* __restrict__ csc_ptr,
+                                                           const int32_t* __restrict__ csc_edge,
+                                                           const float* __restrict__ e,
+                                                           const float* __restrict__ dA,
+                                                           const float* __restrict__ dh_out,
+                                                           float* __restrict__ dh_in) {
+  const int c4n = F / 4;
+  const int apb = 256 / c4n;
+  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
+  const int64_t t = (int64_t)blockIdx.x * apb + a;
+  if (t >= N) return;
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  float4 acc = reinterpret_cast<const float4*>(dh_out)[t * c4n + c4];
+  const int p0 = csc_ptr[t], p1 = csc_ptr[t + 1];
+  for (int p = p0; p < p1; ++p) {
+    const int eid = csc_edge[p];
+    const int64_t src = eid / K;
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+      const float ev = e[(int64_t)eid * E + n];
+      const float4 v = dA4[(src * E + n) * c4n + c4];
+      acc.x += ev * v.x; acc.y += ev * v.y; acc.z += ev * v.z; acc.w += ev * v.w;
+    }
+  }
+  reinterpret_cast<float4*>(dh_in)[t * c4n + c4] = acc;
+}
+
+// ------------------------------------------------------------------------------------ head
+// peaks[i] = sum_c atoms[i,c] * ((g*mask)[i,:] @ Wout[:,c] + bout[c]) * std[c] + atoms[i,c]*avg[c]
+__global__ __launch_bounds__(256) void head_fwd_kernel(int64_t N, int Fh, int C,
+                                                       const float* __restrict__ g,
+                                                       const float* __restrict__ mask,
+                                                       const float* __restrict__ Wout,
+                                                       const float* __restrict__ bout,
+                                                       const float* __restrict__ atoms,
+                                                       const float* __restrict__ pstd,
+                                                       const float* __restrict__ pavg,
+                                                       float* __restrict__ peaks) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sW = reinterpret_cast<float*>(smem_raw);  // [Fh*C]
+  for (int t = threadIdx.x; t < Fh * C; t += 256) sW[t] = Wout[t];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float full[MAX_C];
+#pragma unroll
+  for (int c = 0; c < MAX_C; ++c) full[c] = (c < C) ? bout[c] : 0.f;
+  for (int f = 0; f < Fh; ++f) {
+    float x = g[i * Fh + f];
+    if (mask) x *= mask[i * Fh + f];
+#pragma unroll
+    for (int c = 0; c < MAX_C; ++c)
+      if (c < C) full[c] += x * sW[f * C + c];
+  }
+  float p = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAX_C; ++c)
+    if (c < C) {
+      const float a = atoms[i * C + c];
+      p += full[c] * a * pstd[c] + a * pavg[c];
+    }
+  peaks[i] = p;
+}
+
+// dg[i][f] = mask[i][f] * sum_c dfull[i][c] Wout[f][c],  dfull[i][c] = dpeaks[i]*atoms[i][c]*std[c]
+__global__ __launch_bounds__(256) void head_bwd_dg_kernel(int64_t N, int Fh, int C,
+                                                          const float* __restrict__ mask,
+                                                          const float* __restrict__ Wout,
+                                                          const float* __restrict__ atoms,
+                                                          const float* __restrict__ pstd,
+                                                          const float* __restrict__ dpeaks,
+                                                          float* __restrict__ dg) {
+  const int64_t total = N * Fh;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / Fh;
+    const int f = (int)(t % Fh);
+    const float dp = dpeaks[i];
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dp * atoms[i * C + c] * pstd[c] * Wout[f * C + c];
+    if (mask) s *= mask[t];
+    dg[t] = s;
+  }
+}
+
+// partial[blk][f*C + c] = sum_{rows} gd[r][f] dfull[r][c] ; partial[blk][Fh*C + c] = sum dfull[r][c]
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(int64_t N, int Fh, int C,
+                                                          int64_t rows_per_block,
+                                                          const float* __restrict__ g,
+                                                          const float* __restrict__ mask,
+                                                          const float* __restrict__ atoms,
+                                                          const float* __restrict__ pstd,
+                                                          const float* __restrict__ dpeaks,
+                                                          float* __restrict__ partial) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
+  const int items = Fh * C + C;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    float s = 0.f;
+    if (it < Fh * C) {
+      const int f = it / C, c = it % C;
+      const float sc = pstd[c];
+      for (int64_t r = r0; r < r1; ++r) {
+        float x = g[r * Fh + f];
+        if (mask) x *= mask[r * Fh + f];
+        s += x * dpeaks[r] * atoms[r * C + c] * sc;
+      }
+    } else {
+      const int c = it - Fh * C;
+      const float sc = pstd[c];
+      for (int64_t r = r0; r < r1; ++r) s += dpeaks[r] * atoms[r * C + c] * sc;
+    }
+    partial[(int64_t)blockIdx.x * items + it] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ loss
+// one wave per graph: lg = sum w (y-p)^2 / sum w ; dpred = -2 w (y-p) / (sum w * G)
+__global__ __launch_bounds__(256) void loss_graph_kernel(int G, const int32_t* __restrict__ gptr,
+                                                         const float* __restrict__ y,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ pred,
+                                                         float* __restrict__ per_graph,
+                                                         float* __restrict__ dpred) {
+  const int lane = threadIdx.x & 63;
+  const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gidx >= G) return;
+  const int a = gptr[gidx], b = gptr[gidx + 1];
+  float sw = 0.f, sl = 0.f;
+  for (int i = a + lane; i < b; i += 64) {
+    const float d = y[i] - pred[i];
+    sw += w[i];
+    sl += w[i] * d * d;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sw += __shfl_xor(sw, off, 64);
+    sl += __shfl_xor(sl, off, 64);
+  }
+  const float inv = (sw != 0.f) ? 1.0f / sw : 0.f;
+  if (lane == 0) per_graph[gidx] = sl * inv;
+  const float sc = -2.0f * inv / (float)G;
+  for (int i = a + lane; i < b; i += 64) dpred[i] = sc * w[i] * (y[i] - pred[i]);
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(int G, const float* __restrict__ per_graph,
+                                                         float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) s += per_graph[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0] / (float)G;
+}
+
+// ------------------------------------------------------------------------------------ Adam
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, float lr_t, float b1,
+                            float b2, float eps, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ------------------------------------------------------------------------------------ RNG
+// Philox4x32-10 counter RNG (Salmon et al. 2011); counter = element index / 4 + offset.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+__device__ __forceinline__ float u01(uint32_t x) {  // (0,1]
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__global__ void randn_kernel(uint64_t seed, uint64_t offset, float* __restrict__ out, int64_t n) {
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32(seed, offset + (uint64_t)q, r);
+    float z[4];
+    const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), t0 = 6.28318530717958648f * u01(r[1]);
+    const float r1 = sqrtf(-2.0f * logf(u01(r[2]))), t1 = 6.28318530717958648f * u01(r[3]);
+    z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1); z[3] = r1 * sinf(t1);
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) out[q * 4 + k] = z[k];
+  }
+}
+
+__global__ void dropout_mask_kernel(uint64_t seed, uint64_t offset, float keep,
+                                    float* __restrict__ out, int64_t n) {
+  const int64_t n4 = (n + 3) / 4;
+  const float inv = 1.0f / keep;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32(seed, offset + (uint64_t)q, r);
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) out[q * 4 + k] = (u01(r[k]) <= keep) ? inv : 0.f;
+  }
+}
+
+// out = x + alpha * y   (GaussianNoise: d_eff = d + sigma * xi, model.py:253)
+__global__ void add_scaled_kernel(int64_t n, const float* __restrict__ x,
+                                  const float* __restrict__ y, float alpha,
+                                  float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = x[i] + alpha * y[i];
+}
+
+static inline dim3 ew_grid(int64_t work_items) {
+  return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(work_items, 256), 256 * 8)));
+}
+
+}  // namespace ng
+
+using namespace ng;
+
+// ===================================================================================== C ABI
+extern "C" int ng_randn(ng_ctx* ctx, void* stream, uint64_t seed, uint64_t offset, float* out,
+                        int64_t n) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (n == 0) return NG_OK;
+  hipLaunchKernelGGL(randn_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed,
+                     offset, out, n);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_dropout_mask(ng_ctx* ctx, void* stream, uint64_t seed, uint64_t offset, float keep,
+                               float* out, int64_t n) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, keep > 0.f && keep <= 1.f, "dropout keep probability in (0,1]");
+  if (n == 0) return NG_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     seed, offset, keep, out, n);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_add_scaled(ng_ctx* ctx, void* stream, int64_t n, const float* x, const float* y,
+                             float alpha, float* out) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (n == 0) return NG_OK;
+  hipLaunchKernelGGL(add_scaled_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, n, x, y,
+                     alpha, out);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_embed_fwd(ng_ctx* ctx, void* stream, int64_t N, int C, int F, const float* atoms,
+                            const float* Wemb, float* h0) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, F % 4 == 0, "embed: F % 4");
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, (hipStream_t)stream, "embed_fwd");
+  hipLaunchKernelGGL(embed_fwd_kernel, ew_grid(N * (F / 4)), dim3(256), 0, (hipStream_t)stream, N,
+                     C, F, atoms, Wemb, h0);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_embed_bwd(ng_ctx* ctx, void* stream, int64_t N, int C, int F, const float* atoms,
+                            const float* dh0, float* dWemb) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t items = (int64_t)C * F;
+  if (N == 0) {
+    NG_HIP(ctx, hipMemsetAsync(dWemb, 0, items * 4, st));
+    return NG_OK;
+  }
+  const int64_t rows = 256;
+  const int64_t nb = cdiv(N, rows);
+  float* partial = (float*)workspace(ctx, nb * items * 4);
+  if (!partial) return NG_ERR_NOMEM;
+  ProfScope ps(ctx, st, "embed_bwd");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, N, C, F, rows, atoms,
+                     dh0, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, ew_grid(items), dim3(256), 0, st, partial, (int)nb, items,
+                     dWemb);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_mp_aggregate(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E,
+                               const float* h, const int32_t* nlist, const float* e, float* A) {
+  if (!ctx) return NG_ERR_INVALID;
+  return aggregate(ctx, (hipStream_t)stream, N, K, F, E, h, nlist, e, A);
+}
+
+extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
+                               const float* h, const int32_t* nlist, const float* e,
+                               const float* inv_degree, const float* w, float* h_out, float* A_save,
+                               float* s_save) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, (E * F) % 8 == 0, "mp_layer: (E*F) % 8");
+  const int64_t KF = (int64_t)E * F;
+  // scratch: Wp [KF*F] (+ A [N*KF] when the caller does not keep it)
+  const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;
+  float* ws = (float*)workspace(ctx, need);
+  if (!ws) return NG_ERR_NOMEM;
+  float* Wp = ws;
+  float* A = A_save ? A_save : ws + KF * F;
+  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  if (rc) return rc;
+  rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, A);
+  if (rc) return rc;
+  // P = inv * (A @ Wp);  h_out = act(P) + h
+  return dense_fwd(ctx, st, N, (int)KF, F, act, A, Wp, nullptr, inv_degree, h, h_out, s_save);
+}
+
+extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
+                               const float* h, const int32_t* nlist, const float* e,
+                               const float* inv_degree, const float* w, const float* A_save,
+                               const float* s_save, const int32_t* csc_ptr, const int32_t* csc_edge,
+                               const float* dh_out, float* dh_in, float* de, int de_accum,
+                               float* dw) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, A_save, "mp_layer_bwd: A_save required");
+  NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
+  NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
+             "mp_layer_bwd: F in {16,32,64,128,256}");
+  NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "mp_layer_bwd: edge_feature_size <= 8");
+  const int64_t KF = (int64_t)E * F;
+  const float* S = s_save;
+  const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
+  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* Wp = ws;
+  float* dA = ws + KF * F;
+  float* scr = dA + N * KF;
+  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  if (rc) return rc;
+  // dw[l][m][n] = sum_i A[i][(n,l)] dP[i][m],   dP = dh_out * act'(P) * inv
+  rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, S, inv_degree, dw, nullptr, 1, F, E, scr);
+  if (rc) return rc;
+  // dA[i][(n,l)] = sum_m dP[i][m] Wp[(n,l)][m]
+  rc = dense_dx(ctx, st, N, (int)KF, F, act, dh_out, S, inv_degree, Wp, nullptr, dA);
+  if (rc) return rc;
+  if (N == 0) return NG_OK;
+  const int apb = 256 / (F / 4);
+  const dim3 grid((unsigned)cdiv(N, apb));
+  {
+    ProfScope ps(ctx, st, "mp_edge_grad");
+#define NG_EG(EE)                                                                                \
+  case EE:                                                                                       \
+    hipLaunchKernelGGL((edge_grad_kernel<EE>), grid, dim3(256), 0, st, N, K, F, h, nlist, dA, de, \
+                       de_accum);                                                                \
+    break;
+    switch (E) { NG_EG(1) NG_EG(2) NG_EG(3) NG_EG(4) NG_EG(5) NG_EG(6) NG_EG(7) NG_EG(8) }
+#undef NG_EG
+    NG_HIP(ctx, hipGetLastError());
+  }
+  {
+    ProfScope ps(ctx, st, "mp_scatter_pull");
+#define NG_SP(EE)                                                                                 \
+  case EE:                                                                                        \
+    hipLaunchKernelGGL((scatter_pull_kernel<EE>), grid, dim3(256), 0, st, N, K, F, csc_ptr,       \
+                       csc_edge, e, dA, dh_out, dh_in);                                           \
+    break;
+    switch (E) { NG_SP(1) NG_SP(2) NG_SP(3) NG_SP(4) NG_SP(5) NG_SP(6) NG_SP(7) NG_SP(8) }
+#undef NG_SP
+    NG_HIP(ctx, hipGetLastError());
+  }
+  return NG_OK;
+}
+
+extern "C" int ng_head_fwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, const float* g,
+                           const float* drop_mask, const float* Wout, const float* bout,
+                           const float* atoms, const float* peak_std, const float* peak_avg,
+                           float* peaks) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, C >= 1 && C <= MAX_C, "head: number of elements <= 32");
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, (hipStream_t)stream, "head_fwd");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), (size_t)Fh * C * 4,
+                     (hipStream_t)stream, N, Fh, C, g, drop_mask, Wout, bout, atoms, peak_std,
+                     peak_avg, peaks);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, const float* g,
+                           const float* drop_mask, const float* Wout, const float* atoms,
+                           const float* peak_std, const float* dpeaks, float* dg, float* dWout,
+                           float* dbout) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, C >= 1 && C <= MAX_C, "head: number of elements <= 32");
+  const int64_t items = (int64_t)Fh * C + C;
+  if (N == 0) {
+    NG_HIP(ctx, hipMemsetAsync(dWout, 0, (size_t)Fh * C * 4, st));
+    NG_HIP(ctx, hipMemsetAsync(dbout, 0, (size_t)C * 4, st));
+    return NG_OK;
+  }
+  const int64_t rows = 256;
+  const int64_t nb = cdiv(N, rows);
+  float* ws = (float*)workspace(ctx, (size_t)(nb * items + items) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* partial = ws;
+  float* summed = ws + nb * items;
+  ProfScope ps(ctx, st, "head_bwd");
+  hipLaunchKernelGGL(head_bwd_dg_kernel, ew_grid(N * Fh), dim3(256), 0, st, N, Fh, C, drop_mask,
+                     Wout, atoms, peak_std, dpeaks, dg);
+  hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)nb), dim3(256), 0, st, N, Fh, C, rows, g,
+                     drop_mask, atoms, peak_std, dpeaks, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, ew_grid(items), dim3(256), 0, st, partial, (int)nb, items,
+                     summed);
+  NG_HIP(ctx, hipMemcpyAsync(dWout, summed, (size_t)Fh * C * 4, hipMemcpyDeviceToDevice, st));
+  NG_HIP(ctx, hipMemcpyAsync(dbout, summed + (size_t)Fh * C, (size_t)C * 4, hipMemcpyDeviceToDevice,
+                             st));
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_loss_l2(ng_ctx* ctx, void* stream, int64_t N, int G, const int32_t* graph_ptr,
+                          const float* y, const float* w, const float* pred, float* loss_out,
+                          float* dpred) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, G >= 1, "loss: at least one graph");
+  (void)N;
+  float* per_graph = (float*)workspace(ctx, (size_t)G * 4);
+  if (!per_graph) return NG_ERR_NOMEM;
+  ProfScope ps(ctx, st, "loss_l2");
+  hipLaunchKernelGGL(loss_graph_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, G, graph_ptr,
+                     y, w, pred, per_graph, dpred);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, G, per_graph, loss_out);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_adam_step(ng_ctx* ctx, void* stream, int64_t n, float* p, const float* g, float* m,
+                            float* v, float lr, float beta1, float beta2, float eps, int64_t step,
+                            float grad_scale) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, step >= 1, "adam: step counts from 1");
+  if (n == 0) return NG_OK;
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) /
+                      (1.0 - std::pow((double)beta1, (double)step));
+  ProfScope ps(ctx, (hipStream_t)stream, "adam");
+  hipLaunchKernelGGL(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v,
+                     (float)lr_t, beta1, beta2, eps, grad_scale);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}

@@ -1,0 +1,244 @@
+"""The hot-path engine: forward and hand-derived backward of GNNModel.call
+(nmrgnn/model.py:245-274) as a sequence of C-ABI calls into libnmrgnn_hip.so.
+
+torch is used for device memory and streams only; every arithmetic step is a HIP kernel.
+There is no CPU fallback — constructing an Engine without the library / a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr, ptr_array
+from .graph import GraphBatch
+from .params import ParamStore
+
+ACT = {None: 0, "linear": 0, "softplus": 1, "relu": 2, "tanh": 3}
+DROPOUT_RATE = 0.2   # nmrgnn/model.py:217
+
+
+def rbf_grid(low, high, count):
+    """nmrgnn/layers.py:126-129 — float32 linspace as tf.linspace computes it, gap = c[1]-c[0]."""
+    lo, hi = np.float32(low), np.float32(high)
+    delta = (hi - lo) / np.float32(count - 1)
+    c = (lo + delta * np.arange(count, dtype=np.float32)).astype(np.float32)
+    c[-1] = hi
+    return c, float(np.float32(c[1] - c[0]))
+
+
+class Tape:
+    """activations kept between forward(training=True) and backward()"""
+    __slots__ = ("batch", "d_eff", "z_save", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
+                 "peaks")
+
+
+class Engine:
+    def __init__(self, hp, num_elem, peak_std=None, peak_avg=None, device=None, seed=1234):
+        if not torch.cuda.is_available():
+            raise _lib.NGError("nmrgnn_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.ctx = _lib.get_context(self.device.index)
+        self.lib = self.ctx.lib
+        self.hp = hp
+        self.C = int(num_elem)
+        self.F = hp.get('atom_feature_size')
+        self.E = hp.get('edge_feature_size')
+        self.H = hp.get('edge_hidden_size')
+        self.L = hp.get('mp_layers')
+        self.Le = hp.get('edge_fc_layers')
+        self.Lf = hp.get('fc_layers')
+        self.sigma = float(hp.get('noise'))
+        self.use_dropout = bool(hp.get('dropout'))
+        if hp.get('fc_activation') != 'softplus':
+            # the edge MLP hidden activation is fixed to softplus in the kernels
+            raise NotImplementedError("fc_activation other than 'softplus' is not supported yet")
+        self.fc_act = ACT[hp.get('fc_activation')]
+        self.mp_act = ACT[hp.get('mp_activation')]
+        self.params = ParamStore(hp, self.C, self.device, seed=seed)
+        c, gap = rbf_grid(hp.get('rbf_low'), hp.get('rbf_high'), self.H)
+        self.centers = torch.from_numpy(c).to(self.device)
+        self.gap = gap
+        std = np.ones(self.C, np.float32) if peak_std is None else np.asarray(peak_std, np.float32)[:self.C]
+        avg = np.zeros(self.C, np.float32) if peak_avg is None else np.asarray(peak_avg, np.float32)[:self.C]
+        self.peak_std = torch.from_numpy(np.ascontiguousarray(std)).to(self.device)
+        self.peak_avg = torch.from_numpy(np.ascontiguousarray(avg)).to(self.device)
+        # Adam state (keras defaults, nmrgnn/model.py:44-45)
+        self.adam_m = torch.zeros_like(self.params.flat)
+        self.adam_v = torch.zeros_like(self.params.flat)
+        self.adam_t = 0
+        self.tape = None
+        self._rng_calls = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _st(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _ck(self, rc, what):
+        self.ctx.check(rc, what)
+
+    def randn(self, n, seed, offset=0):
+        out = self._new(n)
+        self._ck(self.lib.ng_randn(self.ctx.handle, self._st(), seed, offset, ptr(out), n), "ng_randn")
+        return out
+
+    def dropout_mask(self, n, seed, offset=0, keep=1.0 - DROPOUT_RATE):
+        out = self._new(n)
+        self._ck(self.lib.ng_dropout_mask(self.ctx.handle, self._st(), seed, offset, keep, ptr(out), n),
+                 "ng_dropout_mask")
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch: GraphBatch, training=False, noise=None, dropout_mask=None, seed=0):
+        """peaks[N].  training=True keeps the tape for backward().
+        ``noise`` (xi[N,K], standard normal) / ``dropout_mask`` ([N,F/2], values 0 or 1/keep) may be
+        supplied explicitly (parity tests); otherwise they are drawn on the GPU from ``seed``."""
+        lib, h, st = self.lib, self.ctx.handle, self._st()
+        P = self.params
+        N, K, F, E, H = batch.N, batch.K, self.F, self.E, self.H
+        if batch.C != self.C:
+            raise ValueError(f"atoms has {batch.C} element columns, model was built for {self.C}")
+        ne = N * K
+        d_src = batch.edges.reshape(-1)
+        d_eff = d_src
+        if training and self.sigma > 0:
+            if noise is None:
+                noise = self.randn(ne, seed, 0)
+            noise = noise.reshape(-1)
+            d_eff = self._new(ne)
+            self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
+                     "ng_add_scaled")
+        z_save = self._new(self.Le - 1, ne, H) if training else None
+        e = self._new(ne, E)
+        W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
+        B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
+        self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, ptr(d_src), ptr(d_eff),
+                                     ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
+                                     ptr(e), ptr(z_save)), "ng_edge_mlp_fwd")
+        h0 = self._new(N, F)
+        self._ck(lib.ng_embed_fwd(h, st, N, self.C, F, ptr(batch.atoms), ptr(P["embed/kernel"]),
+                                  ptr(h0)), "ng_embed_fwd")
+        hs, As, Ss = [h0], [], []
+        for l in range(self.L):
+            hn = self._new(N, F)
+            A = self._new(N, E, F) if training else None
+            S = self._new(N, F) if (training and self.mp_act != 0) else None
+            self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, ptr(hs[-1]),
+                                         ptr(batch.nlist), ptr(e), ptr(batch.inv_degree),
+                                         ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A), ptr(S)),
+                     "ng_mp_layer_fwd")
+            hs.append(hn)
+            As.append(A)
+            Ss.append(S)
+        fx, fs = [hs[-1]], []
+        for t in range(self.Lf - 1):
+            y = self._new(N, F)
+            s = self._new(N, F) if training else None
+            self._ck(lib.ng_dense_fwd(h, st, N, F, F, self.fc_act, 1, ptr(fx[-1]),
+                                      ptr(P[f"fc/{t}/kernel"]), ptr(P[f"fc/{t}/bias"]), ptr(y),
+                                      ptr(s)), "ng_dense_fwd")
+            fx.append(y)
+            fs.append(s)
+        Fh = F // 2
+        g = self._new(N, Fh)
+        t = self.Lf - 1
+        self._ck(lib.ng_dense_fwd(h, st, N, F, Fh, self.fc_act, 0, ptr(fx[-1]),
+                                  ptr(P[f"fc/{t}/kernel"]), ptr(P[f"fc/{t}/bias"]), ptr(g), None),
+                 "ng_dense_fwd")
+        mask = None
+        if training and self.use_dropout:
+            mask = dropout_mask
+            if mask is None:
+                mask = self.dropout_mask(N * Fh, seed, 1 << 40)
+            mask = mask.reshape(N, Fh).contiguous()
+        peaks = self._new(N)
+        self._ck(lib.ng_head_fwd(h, st, N, Fh, self.C, ptr(g), ptr(mask), ptr(P["out/kernel"]),
+                                 ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
+                                 ptr(self.peak_avg), ptr(peaks)), "ng_head_fwd")
+        if training:
+            tp = Tape()
+            tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e
+            tp.h, tp.A, tp.S, tp.fx, tp.fs, tp.g, tp.drop_mask, tp.peaks = hs, As, Ss, fx, fs, g, mask, peaks
+            self.tape = tp
+        return peaks
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpeaks):
+        """fills params.grad (overwrite) from the upstream gradient dpeaks[N]."""
+        tp = self.tape
+        if tp is None:
+            raise RuntimeError("backward() without forward(training=True)")
+        lib, h, st = self.lib, self.ctx.handle, self._st()
+        P = self.params
+        b = tp.batch
+        N, K, F, E, H = b.N, b.K, self.F, self.E, self.H
+        Fh = F // 2
+        ne = N * K
+        dpeaks = dpeaks.contiguous()
+        dg = self._new(N, Fh)
+        self._ck(lib.ng_head_bwd(h, st, N, Fh, self.C, ptr(tp.g), ptr(tp.drop_mask),
+                                 ptr(P["out/kernel"]), ptr(b.atoms), ptr(self.peak_std),
+                                 ptr(dpeaks), ptr(dg), ptr(P.g("out/kernel")), ptr(P.g("out/bias"))),
+                 "ng_head_bwd")
+        t = self.Lf - 1
+        dx = self._new(N, F)
+        self._ck(lib.ng_dense_bwd(h, st, N, F, Fh, self.fc_act, 0, ptr(tp.fx[t]),
+                                  ptr(P[f"fc/{t}/kernel"]), ptr(tp.g), ptr(dg), ptr(dx),
+                                  ptr(P.g(f"fc/{t}/kernel")), ptr(P.g(f"fc/{t}/bias"))), "ng_dense_bwd")
+        for t in reversed(range(self.Lf - 1)):
+            dxn = self._new(N, F)
+            self._ck(lib.ng_dense_bwd(h, st, N, F, F, self.fc_act, 1, ptr(tp.fx[t]),
+                                      ptr(P[f"fc/{t}/kernel"]), ptr(tp.fs[t]), ptr(dx), ptr(dxn),
+                                      ptr(P.g(f"fc/{t}/kernel")), ptr(P.g(f"fc/{t}/bias"))),
+                     "ng_dense_bwd")
+            dx = dxn
+        csc_ptr, csc_edge = b.csc()
+        de = self._new(ne, E)
+        dh = dx
+        for l in reversed(range(self.L)):
+            dhn = self._new(N, F)
+            self._ck(lib.ng_mp_layer_bwd(h, st, N, K, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.nlist),
+                                         ptr(tp.e), ptr(b.inv_degree), ptr(P[f"mp/{l}/w"]),
+                                         ptr(tp.A[l]), ptr(tp.S[l]), ptr(csc_ptr), ptr(csc_edge),
+                                         ptr(dh), ptr(dhn), ptr(de), 0 if l == self.L - 1 else 1,
+                                         ptr(P.g(f"mp/{l}/w"))), "ng_mp_layer_bwd")
+            dh = dhn
+        self._ck(lib.ng_embed_bwd(h, st, N, self.C, F, ptr(b.atoms), ptr(dh),
+                                  ptr(P.g("embed/kernel"))), "ng_embed_bwd")
+        W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
+        dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
+        dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
+        self._ck(lib.ng_edge_mlp_bwd(h, st, ne, H, E, self.Le, ptr(b.edges), ptr(tp.d_eff),
+                                     ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
+                                     ptr(de), ptr_array(dW), ptr_array(dB)), "ng_edge_mlp_bwd")
+        self.tape = None
+
+    # ------------------------------------------------------------------ loss / optimiser
+    def loss_l2(self, batch, y, w, peaks):
+        """NameLoss with s = 1 (nmrgnn/losses.py:30-39), mean over the batch's graphs.
+        Returns (loss[1] device tensor, dloss/dpeaks[N])."""
+        loss = self._new(1)
+        dpred = self._new(batch.N)
+        self._ck(self.lib.ng_loss_l2(self.ctx.handle, self._st(), batch.N, batch.G,
+                                     ptr(batch.graph_ptr), ptr(y), ptr(w), ptr(peaks), ptr(loss),
+                                     ptr(dpred)), "ng_loss_l2")
+        return loss, dpred
+
+    def adam_step(self, lr=None, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-7):
+        if lr is None:
+            lr = float(self.hp.get('learning_rate'))
+        self.adam_t += 1
+        P = self.params
+        self._ck(self.lib.ng_adam_step(self.ctx.handle, self._st(), P.numel, ptr(P.flat), ptr(P.grad),
+                                       ptr(self.adam_m), ptr(self.adam_v), lr, beta1, beta2, eps,
+                                       self.adam_t, grad_scale), "ng_adam_step")

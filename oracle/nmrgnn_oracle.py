@@ -1,0 +1,468 @@
+"""CPU oracle for the nmrgnn message-passing hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a float64 NumPy *restatement* of the reference algorithm
+(ur-whitelab/nmrgnn v0.7).  It exists so that the HIP kernels in
+``nmrgnn_amd/csrc`` can be checked against something; it is never imported by
+the product package.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.
+
+PARITY STATUS: **parity unpinned by the reference's own runtime.**
+The reference is TensorFlow/Keras code whose imports (tensorflow, kerastuner,
+nmrdata, MDAnalysis) are absent here and whose weight shard is missing, and its
+test-suite holds shape assertions only for this path (tests/test_nmrgnn.py:18-108,
+197-223).  What *is* pinned: the analytic known-answer tests derived from the
+reference's own test inputs (tests/test_nmrgnn.py:20-31) and the constants
+decoded from the reference's bundled SavedModel graph (RBF centres, gap,
+peak std/avg, noise sigma, dropout scale; see tests/golden/savedmodel_constants.json
+and tests/golden/make_savedmodel_constants.py).
+
+Every function cites the reference file:line it restates.
+All arrays are NumPy; ``dtype`` defaults to float64 (the "truth"), and float32
+can be requested to emulate reference precision.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# hyper-parameters (reference: nmrgnn/model.py:22-36 defaults)
+# --------------------------------------------------------------------------
+DEFAULT_HYPERS = dict(
+    atom_feature_size=256,
+    edge_feature_size=3,
+    edge_hidden_size=128,
+    mp_layers=4,
+    fc_layers=4,
+    edge_fc_layers=4,
+    noise=0.025,
+    dropout=True,
+    rbf_low=0.005,
+    rbf_high=0.20,
+    mp_activation="softplus",
+    fc_activation="softplus",
+    learning_rate=1e-4,
+)
+DROPOUT_RATE = 0.2  # nmrgnn/model.py:217
+
+
+def hypers(**kw):
+    h = dict(DEFAULT_HYPERS)
+    h.update(kw)
+    return h
+
+
+# --------------------------------------------------------------------------
+# activations (Keras names -> functions); softplus = log(1+exp(x))
+# --------------------------------------------------------------------------
+def softplus(x):
+    # numerically stable form of log1p(exp(x)); identical in exact arithmetic
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def sigmoid(x):
+    return np.where(x >= 0, 1.0 / (1.0 + np.exp(-np.abs(x))),
+                    np.exp(-np.abs(x)) / (1.0 + np.exp(-np.abs(x))))
+
+
+def _act(name):
+    if name is None or name == "linear":
+        return lambda x: x
+    if name == "softplus":
+        return softplus
+    if name == "relu":
+        return lambda x: np.maximum(x, 0)
+    if name == "tanh":
+        return np.tanh
+    raise ValueError(name)
+
+
+def _act_grad(name):
+    """derivative as a function of the pre-activation"""
+    if name is None or name == "linear":
+        return lambda p: np.ones_like(p)
+    if name == "softplus":
+        return sigmoid
+    if name == "relu":
+        return lambda p: (p > 0).astype(p.dtype)
+    if name == "tanh":
+        return lambda p: 1 - np.tanh(p) ** 2
+    raise ValueError(name)
+
+
+# --------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------
+def param_shapes(hp, num_elem=10):
+    """Ordered (name, shape) list.  Names follow the reference's Keras variable
+    tree: edge-fc-block/dense_t, mp-block/MPLayer/w, fc-block/dense_t,
+    out_layer, embed_layer."""
+    F, E, H = hp["atom_feature_size"], hp["edge_feature_size"], hp["edge_hidden_size"]
+    out = []
+    Le = hp["edge_fc_layers"]
+    for t in range(Le):  # nmrgnn/model.py:119-128
+        kin = H
+        kout = H if t < Le - 1 else E
+        out.append((f"edge_fc/{t}/kernel", (kin, kout)))
+        out.append((f"edge_fc/{t}/bias", (kout,)))
+    for l in range(hp["mp_layers"]):  # nmrgnn/layers.py:11-18  w[F,F,E]
+        out.append((f"mp/{l}/w", (F, F, E)))
+    Lf = hp["fc_layers"]
+    for t in range(Lf):  # nmrgnn/model.py:184-188
+        kout = F if t < Lf - 1 else F // 2
+        out.append((f"fc/{t}/kernel", (F, kout)))
+        out.append((f"fc/{t}/bias", (kout,)))
+    out.append(("out/kernel", (F // 2, num_elem)))  # nmrgnn/model.py:239
+    out.append(("out/bias", (num_elem,)))
+    out.append(("embed/kernel", (num_elem, F)))  # nmrgnn/model.py:241 (no bias)
+    return out
+
+
+def glorot_uniform_limit(shape):
+    """Keras GlorotUniform fans (keras/initializers: _compute_fans)."""
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    return np.sqrt(6.0 / (fan_in + fan_out))
+
+
+def init_params(hp, num_elem=10, seed=1234, dtype=np.float64, bias_scale=0.0):
+    """glorot-uniform kernels, zero biases (Keras Dense defaults).  ``bias_scale``>0
+    draws non-zero biases so that tests exercise the bias / mask paths."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in param_shapes(hp, num_elem):
+        if name.endswith("bias"):
+            p[name] = (bias_scale * rng.standard_normal(shape)).astype(dtype)
+        else:
+            lim = glorot_uniform_limit(shape)
+            p[name] = rng.uniform(-lim, lim, size=shape).astype(dtype)
+    return p
+
+
+# --------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------
+def rbf_centers(low, high, count):
+    """nmrgnn/layers.py:126-129: tf.cast(tf.linspace(low, high, count), float32);
+    gap = centers[1]-centers[0] (float32).  tf.linspace on python floats runs in
+    float32: start + delta*i."""
+    lo, hi = np.float32(low), np.float32(high)
+    delta = (hi - lo) / np.float32(count - 1)
+    c = (lo + delta * np.arange(count, dtype=np.float32)).astype(np.float32)
+    c[-1] = hi  # tf.linspace pins the end point
+    gap = np.float32(c[1] - c[0])
+    return c, gap
+
+
+def rbf_expand(d, centers, gap, dtype=np.float64):
+    """nmrgnn/layers.py:137-140: exp(-(d[...,None]-centers)**2 / gap)"""
+    d = np.asarray(d, dtype)
+    return np.exp(-(d[..., None] - centers.astype(dtype)) ** 2 / dtype(gap))
+
+
+def dense(x, kernel, bias=None):
+    """Keras Dense: x @ kernel + bias (rank-3 input = reshape/matmul, SURVEY [pb])."""
+    y = x @ kernel
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+def edge_fc_block(rbf, p, hp):
+    """nmrgnn/model.py:132-138"""
+    act = _act(hp["fc_activation"])
+    Le = hp["edge_fc_layers"]
+    x = rbf
+    acts = [x]
+    for t in range(Le - 1):
+        x = act(dense(x, p[f"edge_fc/{t}/kernel"], p[f"edge_fc/{t}/bias"]))
+        acts.append(x)
+    x = dense(x, p[f"edge_fc/{Le-1}/kernel"], p[f"edge_fc/{Le-1}/bias"])
+    return x, acts
+
+
+def mp_layer(nodes, nlist, edges, inv_degree, w, activation="softplus"):
+    """nmrgnn/layers.py:26-46 — LITERAL: gather + the 4-operand einsum."""
+    sliced = nodes[nlist]  # tf.gather(nodes, nlist)  layers.py:33
+    reduced = np.einsum("ijn,ijl,lmn,i->im", edges, sliced, w, inv_degree,
+                        optimize=True)  # layers.py:39-40
+    return _act(activation)(reduced), reduced
+
+
+def mp_layer_alg(nodes, nlist, edges, inv_degree, w, activation="softplus"):
+    """Independent 'aggregate-then-GEMM' order: A[i,l,n] then [N,F*E]x[F*E,F]."""
+    sliced = nodes[nlist]
+    A = np.einsum("ijn,ijl->iln", edges, sliced)
+    P = inv_degree[:, None] * np.einsum("iln,lmn->im", A, w)
+    return _act(activation)(P), P
+
+
+def mp_block(nodes, nlist, edges, inv_degree, p, hp):
+    """nmrgnn/model.py:158-169: nodes = mp(nodes) + nodes"""
+    for l in range(hp["mp_layers"]):
+        out, _ = mp_layer(nodes, nlist, edges, inv_degree, p[f"mp/{l}/w"],
+                          hp["mp_activation"])
+        nodes = out + nodes
+    return nodes
+
+
+def fc_block(nodes, p, hp):
+    """nmrgnn/model.py:191-196"""
+    act = _act(hp["fc_activation"])
+    Lf = hp["fc_layers"]
+    for t in range(Lf - 1):
+        nodes = act(dense(nodes, p[f"fc/{t}/kernel"], p[f"fc/{t}/bias"])) + nodes
+    nodes = act(dense(nodes, p[f"fc/{Lf-1}/kernel"], p[f"fc/{Lf-1}/bias"]))
+    return nodes
+
+
+def gnn_forward(inputs, p, hp, peak_std=None, peak_avg=None, training=False,
+                noise=None, dropout_mask=None, dtype=np.float64, return_all=False):
+    """nmrgnn/model.py:245-274 (GNNModel.call).
+
+    inputs = (atoms[N,C] one-hot float, nlist[N,K] int, edges[N,K] distances, inv_degree[N]).
+    ``noise``: explicit standard-normal draw xi[N,K] used when training (the reference
+    draws it inside GaussianNoise, model.py:253; sigma = hp['noise']).
+    ``dropout_mask``: explicit keep-mask [N,F/2] in {0,1}; kept units are scaled 1/(1-0.2)
+    (model.py:266-267, keras Dropout).
+    """
+    atoms, nlist, edge_input, inv_degree = inputs
+    atoms = np.asarray(atoms, dtype)
+    nlist = np.asarray(nlist).astype(np.int64)
+    edge_input = np.asarray(edge_input, dtype)
+    inv_degree = np.asarray(inv_degree, dtype)
+    p = {k: np.asarray(v, dtype) for k, v in p.items()}
+    C = atoms.shape[-1]
+    if peak_std is None:
+        peak_std = np.ones(C)
+    if peak_avg is None:
+        peak_avg = np.zeros(C)
+    peak_std = np.asarray(peak_std, dtype)[:C]
+    peak_avg = np.asarray(peak_avg, dtype)[:C]
+
+    edge_mask = (edge_input > 0).astype(dtype)[..., None]            # model.py:251
+    noised = edge_input
+    if training and hp["noise"] > 0:
+        assert noise is not None, "training=True needs an explicit noise draw"
+        noised = edge_input + dtype(hp["noise"]) * np.asarray(noise, dtype)  # model.py:253
+    centers, gap = rbf_centers(hp["rbf_low"], hp["rbf_high"], hp["edge_hidden_size"])
+    rbf = rbf_expand(noised, centers, gap, dtype)                    # model.py:254
+    rbf = rbf * edge_mask                                            # model.py:257
+    e, _ = edge_fc_block(rbf, p, hp)                                 # model.py:258
+    e = e * edge_mask                                                # model.py:261
+    h0 = dense(atoms, p["embed/kernel"])                             # model.py:262
+    h = mp_block(h0, nlist, e, inv_degree, p, hp)                    # model.py:263-264
+    g = fc_block(h, p, hp)                                           # model.py:265
+    if training and hp["dropout"]:
+        assert dropout_mask is not None
+        g = g * np.asarray(dropout_mask, dtype) / dtype(1.0 - DROPOUT_RATE)  # model.py:266-267
+    full = dense(g, p["out/kernel"], p["out/bias"])                  # model.py:268
+    peaks = np.sum(full * atoms * peak_std + atoms * peak_avg, axis=-1)  # model.py:272-273
+    if return_all:
+        return dict(peaks=peaks, e=e, h0=h0, h=h, g=g, full=full, rbf=rbf)
+    return peaks
+
+
+# --------------------------------------------------------------------------
+# loss / optimiser
+# --------------------------------------------------------------------------
+def divide_no_nan(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    out = np.zeros(np.broadcast(a, b).shape)
+    np.divide(a, b, out=out, where=(b != 0))
+    return out
+
+
+def corr_coeff(x, y, w=None):
+    """nmrgnn/losses.py:4-15"""
+    if w is None:
+        w = np.ones_like(x)
+    m = np.sum(w)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xm = np.sum(w * x) / m
+        ym = np.sum(w * y) / m
+        xm2 = np.sum(w * x ** 2) / m
+        ym2 = np.sum(w * y ** 2) / m
+        cov = np.sum(w * (x - xm) * (y - ym))
+        den = m * np.sqrt(np.clip((xm2 - xm ** 2) * (ym2 - ym ** 2), 0, 1e32))
+    if not np.isfinite(den) or den == 0:
+        return 0.0
+    return float(cov / den)
+
+
+def name_loss(y_true, y_pred, label_idx, s=1.0):
+    """nmrgnn/losses.py:30-39 for ONE graph.  y_true[:,0]=label, [:,1]=name id, [:,-1]=weight."""
+    y_true = np.asarray(y_true, np.float64)
+    y_pred = np.asarray(y_pred, np.float64)
+    ln = np.asarray(label_idx, np.int32)
+    w = y_true[:, -1] * np.any(y_true[:, 1].astype(np.int32)[:, None] == ln[None, :], axis=-1)
+    l2 = float(divide_no_nan(np.sum(w * (y_true[:, 0] - y_pred) ** 2), np.sum(w)))
+    if s == 1.0:
+        return l2
+    r = corr_coeff(y_pred, y_true[:, 0], w)
+    return l2 * s + (1 - s) * (1 - r)
+
+
+def batch_loss_s1(y, w, pred, graph_ptr):
+    """Batched s=1 NameLoss: mean over graphs of  sum_i w_i (y_i-pred_i)^2 / sum_i w_i
+    (0 for a graph with sum w = 0; divide_no_nan, losses.py:37).  Returns (loss, dloss/dpred)."""
+    y = np.asarray(y, np.float64)
+    w = np.asarray(w, np.float64)
+    pred = np.asarray(pred, np.float64)
+    G = len(graph_ptr) - 1
+    loss = 0.0
+    grad = np.zeros_like(pred)
+    for g in range(G):
+        a, b = graph_ptr[g], graph_ptr[g + 1]
+        sw = np.sum(w[a:b])
+        if sw == 0:
+            continue
+        diff = y[a:b] - pred[a:b]
+        loss += np.sum(w[a:b] * diff ** 2) / sw
+        grad[a:b] = -2.0 * w[a:b] * diff / sw
+    return loss / G, grad / G
+
+
+def adam_step(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
+    """Keras (TF 2.3) Adam, non-amsgrad: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t m/(sqrt(v)+eps).
+    (nmrgnn/model.py:44-45 uses the Keras defaults; t starts at 1.)"""
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    p = p - lr_t * m / (np.sqrt(v) + eps)
+    return p, m, v
+
+
+# --------------------------------------------------------------------------
+# hand-derived backward — checked against finite differences
+# and torch autograd in tests/test_oracle.py
+# --------------------------------------------------------------------------
+def gnn_forward_backward(inputs, p, hp, dpeaks, peak_std=None, peak_avg=None,
+                         training=False, noise=None, dropout_mask=None):
+    """Returns (peaks, grads dict) for upstream gradient ``dpeaks`` [N]; float64."""
+    dtype = np.float64
+    atoms, nlist, edge_input, inv_degree = inputs
+    atoms = np.asarray(atoms, dtype)
+    nlist = np.asarray(nlist).astype(np.int64)
+    d = np.asarray(edge_input, dtype)
+    v = np.asarray(inv_degree, dtype)
+    p = {k: np.asarray(val, dtype) for k, val in p.items()}
+    N, K = d.shape
+    C = atoms.shape[-1]
+    F, E, H = hp["atom_feature_size"], hp["edge_feature_size"], hp["edge_hidden_size"]
+    std = np.ones(C) if peak_std is None else np.asarray(peak_std, dtype)[:C]
+    avg = np.zeros(C) if peak_avg is None else np.asarray(peak_avg, dtype)[:C]
+    fa, fa_g = _act(hp["fc_activation"]), _act_grad(hp["fc_activation"])
+    ma, ma_g = _act(hp["mp_activation"]), _act_grad(hp["mp_activation"])
+    Le, L, Lf = hp["edge_fc_layers"], hp["mp_layers"], hp["fc_layers"]
+
+    # ---------------- forward, keeping intermediates
+    mask = (d > 0).astype(dtype)[..., None]
+    dn = d + (hp["noise"] * np.asarray(noise, dtype) if (training and hp["noise"] > 0) else 0.0)
+    centers, gap = rbf_centers(hp["rbf_low"], hp["rbf_high"], H)
+    z = [rbf_expand(dn, centers, gap) * mask]
+    pre_e = []
+    for t in range(Le - 1):
+        pre = z[-1] @ p[f"edge_fc/{t}/kernel"] + p[f"edge_fc/{t}/bias"]
+        pre_e.append(pre)
+        z.append(fa(pre))
+    e = (z[-1] @ p[f"edge_fc/{Le-1}/kernel"] + p[f"edge_fc/{Le-1}/bias"]) * mask
+    hs = [atoms @ p["embed/kernel"]]
+    As, Ps = [], []
+    for l in range(L):
+        sliced = hs[-1][nlist]
+        A = np.einsum("ijn,ijl->iln", e, sliced)
+        P = v[:, None] * np.einsum("iln,lmn->im", A, p[f"mp/{l}/w"])
+        As.append(A)
+        Ps.append(P)
+        hs.append(ma(P) + hs[-1])
+    xs = [hs[-1]]
+    pre_f = []
+    for t in range(Lf - 1):
+        pre = xs[-1] @ p[f"fc/{t}/kernel"] + p[f"fc/{t}/bias"]
+        pre_f.append(pre)
+        xs.append(fa(pre) + xs[-1])
+    pre = xs[-1] @ p[f"fc/{Lf-1}/kernel"] + p[f"fc/{Lf-1}/bias"]
+    pre_f.append(pre)
+    g = fa(pre)
+    scale = 1.0
+    if training and hp["dropout"]:
+        scale = np.asarray(dropout_mask, dtype) / (1.0 - DROPOUT_RATE)
+    gd = g * scale
+    full = gd @ p["out/kernel"] + p["out/bias"]
+    peaks = np.sum(full * atoms * std + atoms * avg, axis=-1)
+
+    # ---------------- backward
+    grads = {}
+    dpeaks = np.asarray(dpeaks, dtype)
+    dfull = dpeaks[:, None] * atoms * std
+    grads["out/kernel"] = gd.T @ dfull
+    grads["out/bias"] = dfull.sum(0)
+    dg = (dfull @ p["out/kernel"].T) * scale
+    dpre = dg * fa_g(pre_f[-1])
+    grads[f"fc/{Lf-1}/kernel"] = xs[-1].T @ dpre
+    grads[f"fc/{Lf-1}/bias"] = dpre.sum(0)
+    dx = dpre @ p[f"fc/{Lf-1}/kernel"].T
+    for t in reversed(range(Lf - 1)):
+        dpre = dx * fa_g(pre_f[t])
+        grads[f"fc/{t}/kernel"] = xs[t].T @ dpre
+        grads[f"fc/{t}/bias"] = dpre.sum(0)
+        dx = dx + dpre @ p[f"fc/{t}/kernel"].T
+    dh = dx
+    de = np.zeros_like(e)
+    for l in reversed(range(L)):
+        w = p[f"mp/{l}/w"]
+        dP = dh * ma_g(Ps[l]) * v[:, None]
+        grads[f"mp/{l}/w"] = np.einsum("iln,im->lmn", As[l], dP)
+        dA = np.einsum("im,lmn->iln", dP, w)
+        hprev = hs[l]
+        sliced = hprev[nlist]
+        de += np.einsum("iln,ijl->ijn", dA, sliced)
+        msg = np.einsum("ijn,iln->ijl", e, dA)           # contribution to h[nlist[i,j]]
+        dhprev = dh.copy()
+        np.add.at(dhprev, nlist.reshape(-1), msg.reshape(N * K, F))
+        dh = dhprev
+    grads["embed/kernel"] = atoms.T @ dh
+    dz = (de * mask)
+    grads[f"edge_fc/{Le-1}/kernel"] = z[-1].reshape(-1, H).T @ dz.reshape(-1, E)
+    grads[f"edge_fc/{Le-1}/bias"] = dz.reshape(-1, E).sum(0)
+    dzz = dz @ p[f"edge_fc/{Le-1}/kernel"].T
+    for t in reversed(range(Le - 1)):
+        dpre = dzz * fa_g(pre_e[t])
+        grads[f"edge_fc/{t}/kernel"] = z[t].reshape(-1, H).T @ dpre.reshape(-1, H)
+        grads[f"edge_fc/{t}/bias"] = dpre.reshape(-1, H).sum(0)
+        dzz = dpre @ p[f"edge_fc/{t}/kernel"].T
+    return peaks, grads
+
+
+# --------------------------------------------------------------------------
+# library-level helpers
+# --------------------------------------------------------------------------
+def inv_degree_from_nlist(nlist):
+    """nmrgnn/library.py:115-116: squeeze(divide_no_nan(1, sum(cast(nlist>0)))).
+    NB: counts nlist>0, so a real neighbour with atom index 0 is not counted."""
+    deg = np.sum((np.asarray(nlist) > 0).astype(np.float32), axis=1)
+    out = np.zeros_like(deg)
+    np.divide(1.0, deg, out=out, where=deg > 0)
+    return out.astype(np.float32)
+
+
+def check_peaks(atoms, peaks, standards, cutoff_sigma=4, warn_sigma=2.5):
+    """nmrgnn/library.py:30-47 (np.bool -> bool).  ``standards``: {elem: (name, avg, std)}."""
+    atoms = np.asarray(atoms)
+    peaks = np.asarray(peaks)
+    confident = np.ones(atoms.shape[0], dtype=bool)
+    for i in range(len(atoms)):
+        ps = standards[int(np.nonzero(atoms[i])[0][0])]
+        if ps[2] == 0 or (peaks[i] - ps[1]) ** 2 / ps[2] ** 2 > warn_sigma ** 2:
+            confident[i] = False
+    if np.sum(confident) / confident.shape[0] < 0.75:
+        raise Warning("Your peaks look awful. Likely solvent or missing hydrogens or bad units. "
+                      "Check README for suggestions")
+    return confident
