@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py — atoms/s (fwd+bwd+Adam) of the nmrgnn message-passing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]/[3]): per GPU 512 synthetic graphs x 256 atoms
+(N = 131,072 atom rows), K = 16 neighbours, F = 64, E = 3, H = 128, 4 MP / 4 edge-FC / 4 FC layers,
+fp32, noise + dropout on, weighted-MSE NameLoss (s = 1), Adam(lr 1e-4).  One "step" = forward +
+loss + backward + gradient all-reduce (N > 1) + Adam over one batch already resident in HBM.
+Weak scaling: per-GPU work is fixed; ranks hold different graphs (seed 42 + rank).
+
+Prints ONE JSON line on rank 0 with `value` = whole-job atoms/s, plus
+  roofline     — dominant kernel: algorithmic flops per launch / its mean launch duration
+                 (hipEvent-bracketed inside the C library on the launch stream) vs the fp32 MFMA peak
+  roofline_all — the same for every profiled kernel (HBM-bound ones against 8 TB/s)
+  cpu_baseline — the reference's op order restated in torch-CPU fp32 (oracle/torch_ref.py; TensorFlow
+                 is not installed) timed on this box's host cores on a bounded sample of the workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # spec; ~6300 achievable
+
+ARCH = dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
+            fc_layers=4, edge_fc_layers=4)
+GRAPHS_PER_GPU, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM = 512, 256, 16, 10
+
+
+def kernel_work(N, K, F, E, H, Le, L, Lf, C):
+    """ALGORITHMIC work per launch of each profiled kernel: (bound, flops, bytes)  (DESIGN.md §4)."""
+    ne = N * K
+    Fh = F // 2
+    KF = E * F
+    f4 = 4.0
+    w = {
+        # fused edge kernels (edge_fused.hip)
+        "edge_fused_fwd": ("mfma", 2.0 * ne * ((Le - 1) * H * H + H * E),
+                           f4 * ne * (1 + 1 + E + (Le - 1) * H)),
+        "edge_fused_bwd": ("mfma", 2.0 * ne * ((2 * (Le - 1) - 1) * H * H + 2 * H * E),
+                           f4 * ne * (1 + 1 + E + (Le - 1) * H)),
+        # layered edge path
+        "rbf": ("hbm", 0.0, f4 * ne * (2 + H)),
+        "edge_dense_fwd": ("mfma", 2.0 * ne * H * H, f4 * ne * 2 * H),
+        "edge_dense_dx": ("mfma", 2.0 * ne * H * H, f4 * ne * 3 * H),
+        "edge_dense_dw": ("mfma", 2.0 * ne * H * H, f4 * ne * 3 * H),
+        "edge_out_fwd": ("hbm", 2.0 * ne * H * E, f4 * ne * (H + E + 1)),
+        "edge_out_bwd": ("hbm", 4.0 * ne * H * E, f4 * ne * (2 * H + E + 1)),
+        "bias_grad": ("hbm", 0.0, f4 * ne * 2 * H),
+        # node path
+        "mp_aggregate": ("hbm", 2.0 * N * K * F * E, f4 * N * (F + K + K * E + F * E)),
+        "mp_update_fwd": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + 3 * F)),
+        "mp_layer_fused_fwd": ("hbm", 2.0 * N * (K * F * E + KF * F), f4 * N * (2 * F + K + K * E + 1)),
+        "mp_dw": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + 2 * F)),
+        "mp_dA": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + 2 * F)),
+        "mp_edge_grad": ("hbm", 2.0 * N * K * F * E, f4 * N * (F + K + K * E + F * E)),
+        "mp_scatter_pull": ("hbm", 2.0 * N * K * F * E, f4 * N * (2 * F + K + K * E + F * E)),
+        "dense_fwd": ("mfma", 2.0 * N * F * F, f4 * N * 3 * F),
+        "dense_dx": ("mfma", 2.0 * N * F * F, f4 * N * 3 * F),
+        "dense_dw": ("mfma", 2.0 * N * F * F, f4 * N * 3 * F),
+    }
+    return w
+
+
+def usable_cores():
+    """cores this process may actually run on: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(hp_dict, sample_graphs, seed, budget_s=20.0):
+    """reference op order (torch CPU fp32), fwd+bwd+Adam, atoms/s on a bounded sample.
+    The intra-op thread count is calibrated (one step each over a few candidates) because the GPU
+    box reports far more logical CPUs than a container is allowed to use."""
+    from oracle import nmrgnn_oracle as O
+    from oracle import torch_ref as R
+    from nmrgnn_amd import synth
+    cores = usable_cores()
+    hp = O.hypers(**hp_dict)
+    b = synth.make_batch(sample_graphs, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM, 0.05, seed)
+    p = R.to_torch_params(O.init_params(hp, NUM_ELEM, dtype=np.float32), dtype=torch.float32,
+                          requires_grad=True)
+    opt = torch.optim.Adam(list(p.values()), lr=1e-4, eps=1e-7)
+    N, K = b["edges"].shape
+    gen = torch.Generator().manual_seed(seed)
+    gids = torch.as_tensor(np.repeat(np.arange(sample_graphs), ATOMS_PER_GRAPH))
+    y, w = torch.as_tensor(b["y"]), torch.as_tensor(b["w"])
+    inputs = (b["atoms"], b["nlist"], b["edges"], b["inv_degree"])
+
+    def one():
+        xi = torch.randn(N, K, generator=gen)
+        mask = (torch.rand(N, hp["atom_feature_size"] // 2, generator=gen) < 0.8).float()
+        opt.zero_grad(set_to_none=True)
+        pred = R.forward(inputs, p, hp, training=True, noise=xi, dropout_mask=mask, order="ref")
+        loss = R.batch_loss_s1(y, w, pred, gids, sample_graphs)
+        loss.backward()
+        opt.step()
+
+    cands = sorted({c for c in (cores, cores // 2, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True)
+    best_thr, best_t = cands[0], float("inf")
+    for c in cands:
+        torch.set_num_threads(c)
+        one()  # warm-up at this setting
+        t0 = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best_thr, best_t = c, dt
+        if dt > 4 * best_t:
+            continue
+    torch.set_num_threads(best_thr)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 or (time.perf_counter() - t_all < budget_s and len(times) < 50):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 3 * budget_s:
+            break
+    med = float(np.median(times))
+    return {"value": N / med, "unit": "atoms/s", "cores": best_thr, "cores_available": cores,
+            "kind": "port",
+            "sample": f"{sample_graphs} graphs x {ATOMS_PER_GRAPH} atoms (one concatenated call), "
+                      f"fwd+bwd+Adam, reference op order (lmn,ijl->mnij; mnij,ijn->mi; mi,i->im), "
+                      f"torch-CPU fp32 eager, median of {len(times)} runs",
+            "ms_per_step": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs", type=int, default=GRAPHS_PER_GPU, help="graphs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    from nmrgnn_amd import parallel, synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
+    from nmrgnn_amd.train import Trainer
+
+    world, rank, local = parallel.init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    hp = declare_gnn_space(HyperParameters(**ARCH))
+    eng = Engine(hp, NUM_ELEM, device=dev, seed=1234)          # same weights on every rank
+    b = synth.make_batch(args.graphs, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM, 0.05, seed=42 + rank)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"],
+                    device=dev)
+    gb.csc()
+    y = torch.from_numpy(b["y"]).to(dev)
+    w = torch.from_numpy(b["w"]).to(dev)
+    tr = Trainer(eng, lr=1e-4)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = tr.step(gb, y, w)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(gb, y, w)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    atoms_total = gb.N * world
+    value = atoms_total * args.steps / elapsed
+    final_loss = float(loss.cpu())
+
+    out = {
+        "metric": "atoms/s (fwd+bwd) on 256-atom/16-neighbor synthetic graphs",
+        "value": value, "unit": "atoms/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[2]: training step (fwd+loss+bwd+Adam) on {args.graphs} "
+                               f"graphs x {ATOMS_PER_GRAPH} atoms per GPU, K={K_NEIGH}, F=64, E=3, "
+                               f"H=128, 4 MP / 4 edge-FC / 4 FC layers, noise+dropout on",
+                   "atoms_per_gpu": gb.N, "edges_per_gpu": gb.N * K_NEIGH,
+                   "parallelism": f"graph-parallel dp{world}", "params": eng.params.count()},
+        "loss": final_loss,
+    }
+
+    # ---- per-kernel hipEvent pass (same step, events bracketed inside the C library)
+    if rank == 0 and not args.no_profile:
+        torch.cuda.synchronize()
+        eng.ctx.prof_reset()
+        eng.ctx.prof_enable(True)
+        psteps = min(args.steps, 5)
+        for _ in range(psteps):
+            tr.step(gb, y, w)
+        torch.cuda.synchronize()
+        prof = eng.ctx.prof_read()
+        eng.ctx.prof_enable(False)
+        eng.ctx.prof_reset()
+        work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM)
+        rows = []
+        for name, (tot_ms, cnt) in prof.items():
+            avg_ms = tot_ms / max(cnt, 1)
+            row = {"kernel": name, "launches_per_step": cnt / psteps, "avg_ms": avg_ms,
+                   "ms_per_step": tot_ms / psteps}
+            if name in work and avg_ms > 0:
+                bound, fl, by = work[name]
+                if bound == "mfma":
+                    ach = fl / (avg_ms * 1e-3) / 1e12
+                    row.update(bound="mfma", achieved=ach, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
+                               frac=ach / PEAK_MFMA_F32_TFLOPS)
+                else:
+                    ach = by / (avg_ms * 1e-3) / 1e9
+                    row.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                               frac=ach / PEAK_HBM_GBS)
+            rows.append(row)
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        out["roofline_all"] = rows
+        dom = next((r for r in rows if "bound" in r), None)
+        if dom is not None:
+            out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"],
+                               "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                               "frac": dom["frac"], "traffic": None,
+                               "avg_launch_ms": dom["avg_ms"]}
+        out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(ARCH, sample_graphs=8, seed=42)
+        except Exception as ex:  # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"error": repr(ex)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -234,7 +234,7 @@ int edge_mlp_fwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
   for (int t = 0; t < Le - 1; ++t) {
     float* y = z_save ? z_save + (int64_t)t * tile : ws + (int64_t)(1 + (t & 1)) * tile;
     int rc = dense_fwd(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, x, W[t], b[t], nullptr, nullptr, y,
-                       nullptr);
+                       nullptr, "edge_dense_fwd");
     if (rc) return rc;
     x = y;
   }
@@ -276,10 +276,11 @@ int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
       x_in = X0;
     }
     rc = dense_dw(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, x_in, dz, s_t, nullptr, dW[t], db[t], 0, 0,
-                  0, scratch);
+                  0, scratch, "edge_dense_dw");
     if (rc) return rc;
     if (t > 0) {
-      rc = dense_dx(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, dz, s_t, nullptr, W[t], nullptr, dz_next);
+      rc = dense_dx(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, dz, s_t, nullptr, W[t], nullptr, dz_next,
+                    "edge_dense_dx");
       if (rc) return rc;
       std::swap(dz, dz_next);
     }

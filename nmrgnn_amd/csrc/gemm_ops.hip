@@ -124,10 +124,10 @@ static void launch_gemm(hipStream_t st, int64_t M, int N, int64_t K, int64_t k_c
 
 int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
               const float* W, const float* b, const float* rowscale, const float* R, float* Y,
-              float* S) {
+              float* S, const char* tag) {
   NG_REQUIRE(ctx, Kin % 8 == 0 && Nout % 4 == 0, "dense_fwd: Kin%8, Nout%4");
   if (M == 0) return NG_OK;
-  ProfScope ps(ctx, st, "dense_fwd");
+  ProfScope ps(ctx, st, tag);
   LoadPlain lq{X, M, Kin, Kin};
   LoadPlain lp{W, Kin, Nout, Nout};
   EpiDense ep{Y, S, b, rowscale, R, Nout, act};
@@ -140,10 +140,11 @@ int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act
 }
 
 int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY,
-             const float* S, const float* rowscale, const float* W, const float* add, float* dX) {
+             const float* S, const float* rowscale, const float* W, const float* add, float* dX,
+             const char* tag) {
   NG_REQUIRE(ctx, Nout % 8 == 0 && Kin % 4 == 0, "dense_dx: Nout%8, Kin%4");
   if (M == 0) return NG_OK;
-  ProfScope ps(ctx, st, "dense_dx");
+  ProfScope ps(ctx, st, tag);
   LoadGradAct lq{dY, act == NG_ACT_NONE ? nullptr : S, rowscale, M, Nout, act};
   LoadPlain lp{W, Kin, Nout, Nout};  // [k_out][n]: K-contiguous along the contraction n
   EpiAdd ep{dX, add, Kin};
@@ -183,7 +184,7 @@ size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool h
 
 int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
              const float* dY, const float* S, const float* rowscale, float* dW, float* db,
-             int w_map, int F, int E, float* scratch) {
+             int w_map, int F, int E, float* scratch, const char* tag) {
   if (act == NG_ACT_NONE) S = nullptr;
   NG_REQUIRE(ctx, Kin % 4 == 0 && Nout % 4 == 0, "dense_dw: Kin%4, Nout%4");
   const int64_t n_elem = (int64_t)Kin * Nout;
@@ -196,7 +197,7 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   float* partial = scratch;
   float* cs_partial = scratch + p.nz * n_elem;
   {
-    ProfScope ps(ctx, st, "dense_dw");
+    ProfScope ps(ctx, st, tag);
     LoadPlain lq{X, M, Kin, Kin};
     LoadGradAct lp{dY, S, rowscale, M, Nout, act};
     EpiPartial ep{partial, Kin, Nout};

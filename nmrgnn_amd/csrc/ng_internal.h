@@ -7,15 +7,16 @@ namespace ng {
 // Y = act(rowscale[m] * (X @ W) + b) (+ R);  S (optional) receives the activation output.
 int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
               const float* W, const float* b, const float* rowscale, const float* R, float* Y,
-              float* S);
+              float* S, const char* tag = "dense_fwd");
 // dX[m][k] = (add ? add[m][k] : 0) + sum_n dP[m][n] W[k][n];  dP = dY * act'(S) * rowscale
 int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY,
-             const float* S, const float* rowscale, const float* W, const float* add, float* dX);
+             const float* S, const float* rowscale, const float* W, const float* add, float* dX,
+             const char* tag = "dense_dx");
 // dW[k][n] = sum_m X[m][k] dP[m][n]  (+ db[n] = sum_m dP[m][n] when db != nullptr)
 // w_map = 0: dW stored [Kin][Nout];  w_map = 1: MPLayer layout, k = n_e*F + l -> dw[l][m][n_e]
 int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
              const float* dY, const float* S, const float* rowscale, float* dW, float* db,
-             int w_map, int F, int E, float* scratch);
+             int w_map, int F, int E, float* scratch, const char* tag = "dense_dw");
 size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db);
 
 // elementwise helpers (node_ops.hip)

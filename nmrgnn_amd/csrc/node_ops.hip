@@ -517,7 +517,8 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, A);
   if (rc) return rc;
   // P = inv * (A @ Wp);  h_out = act(P) + h
-  return dense_fwd(ctx, st, N, (int)KF, F, act, A, Wp, nullptr, inv_degree, h, h_out, s_save);
+  return dense_fwd(ctx, st, N, (int)KF, F, act, A, Wp, nullptr, inv_degree, h, h_out, s_save,
+                   "mp_update_fwd");
 }
 
 extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
@@ -544,10 +545,11 @@ extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   int rc = mp_repack_w(ctx, st, F, E, w, Wp);
   if (rc) return rc;
   // dw[l][m][n] = sum_i A[i][(n,l)] dP[i][m],   dP = dh_out * act'(P) * inv
-  rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, S, inv_degree, dw, nullptr, 1, F, E, scr);
+  rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, S, inv_degree, dw, nullptr, 1, F, E, scr,
+                "mp_dw");
   if (rc) return rc;
   // dA[i][(n,l)] = sum_m dP[i][m] Wp[(n,l)][m]
-  rc = dense_dx(ctx, st, N, (int)KF, F, act, dh_out, S, inv_degree, Wp, nullptr, dA);
+  rc = dense_dx(ctx, st, N, (int)KF, F, act, dh_out, S, inv_degree, Wp, nullptr, dA, "mp_dA");
   if (rc) return rc;
   if (N == 0) return NG_OK;
   const int apb = 256 / (F / 4);

@@ -173,8 +173,10 @@ class Engine:
         return peaks
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dpeaks):
-        """fills params.grad (overwrite) from the upstream gradient dpeaks[N]."""
+    def backward(self, dpeaks, on_node_grads=None):
+        """fills params.grad (overwrite) from the upstream gradient dpeaks[N].
+        ``on_node_grads`` is called once every non-edge gradient has been enqueued (the data-parallel
+        trainer launches the node-side all-reduce there, overlapping the edge-MLP backward)."""
         tp = self.tape
         if tp is None:
             raise RuntimeError("backward() without forward(training=True)")
@@ -215,6 +217,8 @@ class Engine:
             dh = dhn
         self._ck(lib.ng_embed_bwd(h, st, N, self.C, F, ptr(b.atoms), ptr(dh),
                                   ptr(P.g("embed/kernel"))), "ng_embed_bwd")
+        if on_node_grads is not None:
+            on_node_grads()
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]

@@ -1,0 +1,35 @@
+"""Training step for the hot path: forward (noise + dropout) -> NameLoss(s=1) -> backward ->
+gradient all-reduce -> Adam.  Mirrors what keras ``model.fit`` does per record in the reference
+(nmrgnn/main.py:79-80 with nmrgnn/model.py:44-52), batched over many graphs."""
+from __future__ import annotations
+
+import torch
+
+from .engine import Engine
+from .graph import GraphBatch
+from .parallel import GradBuckets
+
+
+class Trainer:
+    def __init__(self, engine: Engine, lr=None):
+        self.engine = engine
+        self.lr = lr
+        P = engine.params
+        # edge-MLP parameters sit first in the flat buffer (params.param_shapes)
+        first_node = next(k for k in P.offsets if not k.startswith("edge_fc/"))
+        self.buckets = GradBuckets(P.grad, P.offsets[first_node])
+        self.step_count = 0
+
+    def step(self, batch: GraphBatch, y: torch.Tensor, w: torch.Tensor, seed=None):
+        eng = self.engine
+        if seed is None:
+            seed = 0x9E3779B97F4A7C15 ^ (self.step_count * 1000003)
+        seed &= (1 << 63) - 1
+        peaks = eng.forward(batch, training=True, seed=seed)
+        loss, dpred = eng.loss_l2(batch, y, w, peaks)
+        eng.backward(dpred, on_node_grads=self.buckets.launch_node)
+        self.buckets.launch_edge()
+        self.buckets.wait()
+        eng.adam_step(lr=self.lr, grad_scale=self.buckets.grad_scale())
+        self.step_count += 1
+        return loss
