@@ -288,6 +288,12 @@ int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
   return NG_OK;
 }
 
+// NG_EDGE_PATH=layered forces the one-launch-per-layer path (A/B measurements, tests)
+static bool force_layered() {
+  const char* v = getenv("NG_EDGE_PATH");
+  return v && std::string(v) == "layered";
+}
+
 }  // namespace ng
 
 using namespace ng;
@@ -302,6 +308,9 @@ extern "C" int ng_edge_mlp_fwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H
   NG_REQUIRE(ctx, Le >= 2, "edge_mlp: edge_fc_layers >= 2");
   NG_REQUIRE(ctx, gap > 0.f, "edge_mlp: rbf gap > 0");
   if (n_edges == 0) return NG_OK;
+  if (edge_fused_supported(H, E, Le) && !force_layered())
+    return edge_fused_fwd(ctx, (hipStream_t)stream, n_edges, E, d_src, d_eff, centers, gap, W, b,
+                          e_out, z_save);
   return edge_mlp_fwd_layered(ctx, (hipStream_t)stream, n_edges, H, E, Le, d_src, d_eff, centers,
                               gap, W, b, e_out, z_save);
 }

@@ -19,6 +19,12 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
              int w_map, int F, int E, float* scratch, const char* tag = "dense_dw");
 size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db);
 
+// fused persistent edge path (edge_fused.hip), edge_hidden_size == 128, edge_fc_layers == 4
+bool edge_fused_supported(int H, int E, int Le);
+int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
+                   const float* d_eff, const float* centers, float gap, const float* const* W,
+                   const float* const* b, float* e_out, float* z_save);
+
 // elementwise helpers (node_ops.hip)
 int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp);
 
