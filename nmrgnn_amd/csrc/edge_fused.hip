@@ -19,14 +19,10 @@
 #include <algorithm>
 
 #include "mfma_gemm.cuh"
-#include "ng_internal.h"
+#include "edge_fused.h"
 
 namespace ng {
 
-constexpr int FH = 128;          // hidden width handled by the fused path
-constexpr int FTM = 64;          // edges per tile
-constexpr int FLD = FH + 4;      // LDS row stride (floats): 16-B slots shift by one per row
-constexpr int FMAX_E = 8;
 
 // fast softplus for the epilogue: max(x,0) + log1p(exp(-|x|)); series below 2^-11 keeps the
 // relative accuracy where 1+t would round

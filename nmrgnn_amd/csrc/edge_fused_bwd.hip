@@ -1,0 +1,365 @@
+// Fused persistent backward of the edge path (edge_hidden_size == 128, edge_fc_layers == 4).
+// Backward of nmrgnn/model.py:251-261 (mask, RBF, EdgeFCBlock, mask); math in SURVEY App. B.
+//
+// Layers:  R --W1,b1--> Z1 --W2,b2--> Z2 --W3,b3--> Z3 --Wo,bo--> e   (Zt = softplus(.), e masked)
+// Given de[n_edges,E] and the saved Z1..Z3, per 64-edge tile, all on-chip:
+//   A:  dE = m*de ;  G3 = (dE Wo^T) * s'(Z3)            [VALU]   dWo += Z3^T dE, dbo += sum dE
+//   B:  dW3 += Z2^T G3 [MFMA] ; db3 += colsum G3 ; dZ2 = G3 W3^T [MFMA] ; G2 = dZ2 * s'(Z2)
+//   C:  dW2 += Z1^T G2 [MFMA] ; db2 += colsum G2 ; dZ1 = G2 W2^T [MFMA] ; G1 = dZ1 * s'(Z1)
+//   D:  R = m*rbf(d) recomputed ; dW1 += R^T G1 [MFMA] ; db1 += colsum G1
+// with s'(Z) = 1 - exp(-Z) (sigmoid of the pre-activation, recovered from the softplus output).
+// The three 128x128 weight-gradient accumulators stay in registers for the whole launch (96 VGPRs
+// per wave: 8 waves x 2 tiles of 32x32 x 3 layers); every workgroup writes ONE partial at the end
+// and a small second kernel sums the partials (deterministic, no atomics).
+//
+// Mapping.  512 threads = 8 waves, one workgroup per CU (persistent), 3 LDS tiles [64][132] f32.
+//   dW GEMM (contraction over the tile's 64 rows): wave w -> k-slab w>>1, n-slabs 2(w&1), 2(w&1)+1;
+//     both operands are read K-strided (conflict-free ds_read_b32, natural [row][col] tiles).
+//   dZ GEMM (contraction over n): wave w -> k-slab w&3, row-tile w>>2; A fragments = W rows streamed
+//     from a fragment-ordered copy in L2 in 4-step chunks (double-buffered), B = G via ds_read_b128.
+#include <algorithm>
+
+#include "mfma_gemm.cuh"
+#include "edge_fused.h"
+
+namespace ng {
+
+constexpr int BW_THREADS = 512;
+
+struct EdgeBwdArgs {
+  int64_t n_edges;
+  const float* d_src;
+  const float* d_eff;
+  const float* centers;
+  float neg_inv_gap;
+  const float* WpkT;    // [3][4][16][64][4]: W_l[k = 32w + (lane&31)][n = 8t + 4*(lane>>5) + s]
+  const float* Wo;      // [128][E]
+  const float* z_save;  // [3][n_edges][128]
+  const float* de;      // [n_edges][E]
+  float* partial;       // [grid][part_stride]
+  int part_stride;
+};
+
+// partial layout (floats): dW[3][128*128] | db[3][128] | dWo[128*E] | dbo[E]
+__host__ __device__ inline int bwd_part_floats(int E) { return 3 * FH * FH + 3 * FH + FH * E + E; }
+
+__device__ __forceinline__ void tile_to_regs(float4 (&pz)[4], const float* __restrict__ src,
+                                             int64_t row0, int64_t n_rows, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lin = tid + i * BW_THREADS;
+    const int row = lin >> 5, c4 = lin & 31;
+    pz[i] = (row0 + row < n_rows)
+                ? *reinterpret_cast<const float4*>(src + (row0 + row) * FH + c4 * 4)
+                : f4zero();
+  }
+}
+__device__ __forceinline__ void regs_to_lds(const float4 (&pz)[4], float* __restrict__ buf, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lin = tid + i * BW_THREADS;
+    const int row = lin >> 5, c4 = lin & 31;
+    *reinterpret_cast<float4*>(buf + row * FLD + c4 * 4) = pz[i];
+  }
+}
+
+// acc[j][n][k] += sum_rows G[row][n] * Zp[row][k]     (D rows i = n, cols j = k)
+__device__ __forceinline__ void dw_gemm(f32x16 (&acc)[2], const float* __restrict__ Zp,
+                                        const float* __restrict__ G, int kslab, int nsl0, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* zp = Zp + (4 * half) * FLD + kslab * 32 + l31;
+  const float* g0 = G + (4 * half) * FLD + nsl0 * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = (8 * t + s) * FLD;
+      const float b = zp[off];
+      const float a0 = g0[off];
+      const float a1 = g0[off + 32];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+    }
+  }
+}
+
+// dZ[row][k] = sum_n G[row][n] W[k][n]  for k-slab zk, row-tile zrt;  then
+// Gout[row][k] = dZ * (1 - exp(-Z[row][k]))
+__device__ __forceinline__ void dz_gemm_epilogue(const float* __restrict__ G,
+                                                 const float* __restrict__ Z,
+                                                 float* __restrict__ Gout,
+                                                 const float* __restrict__ WpkT, int layer, int zk,
+                                                 int zrt, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float4* wp = reinterpret_cast<const float4*>(WpkT) + ((layer * 4 + zk) * 16) * 64 + lane;
+  const float* g = G + (zrt * 32 + l31) * FLD + 4 * half;
+  float4 wc[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wc[0][i] = wp[i * 64];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wc[(c + 1) & 1][i] = wp[(4 * (c + 1) + i) * 64];
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int t = 4 * c + tt;
+      const float4 x = *reinterpret_cast<const float4*>(g + 8 * t);
+      const float4 w = wc[c & 1][tt];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x.w, acc, 0, 0, 0);
+    }
+  }
+  // lane holds dZ[row = 32*zrt + l31][k = 32*zk + 8q + 4*half + (0..3)]
+  const int row = zrt * 32 + l31;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = zk * 32 + 8 * q + 4 * half;
+    const float4 z = *reinterpret_cast<const float4*>(Z + row * FLD + k);
+    float4 o;
+    o.x = acc[4 * q + 0] * (1.0f - __expf(-z.x));
+    o.y = acc[4 * q + 1] * (1.0f - __expf(-z.y));
+    o.z = acc[4 * q + 2] * (1.0f - __expf(-z.z));
+    o.w = acc[4 * q + 3] * (1.0f - __expf(-z.w));
+    *reinterpret_cast<float4*>(Gout + row * FLD + k) = o;
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;                    // Z3 -> G2 -> R
+  float* bufB = bufA + FTM * FLD;        // Z2 -> G1
+  float* bufC = bufB + FTM * FLD;        // G3 -> Z1
+  float* sWo = bufC + FTM * FLD;         // [128*E]
+  float* sdE = sWo + FH * FMAX_E;        // [64*E] masked upstream gradient
+  float* sD = sdE + FTM * FMAX_E;        // [64] d_eff
+  float* sM = sD + FTM;                  // [64] mask
+  float* sCen = sM + FTM;                // [128]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kslab = wave >> 1, nsl0 = 2 * (wave & 1);   // dW tiles
+  const int zk = wave & 3, zrt = wave >> 2;             // dZ tile
+  const int cn = tid & 127, rq = tid >> 7;              // column-sum / dWo ownership
+
+  for (int t = tid; t < FH * E; t += BW_THREADS) sWo[t] = a.Wo[t];
+  if (tid < FH) sCen[tid] = a.centers[tid];
+
+  f32x16 accW[3][2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW[l][j][r] = 0.f;
+  float accb[3] = {0.f, 0.f, 0.f};
+  float accWo[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) accWo[n] = 0.f;
+  float accbo = 0.f;
+
+  const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
+  const float* Z1g = a.z_save;
+  const float* Z2g = a.z_save + a.n_edges * FH;
+  const float* Z3g = a.z_save + 2 * a.n_edges * FH;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * FTM;
+    float4 pzA[4], pzB[4];
+    // ------------------------------------------------------------------ phase A
+    tile_to_regs(pzA, Z3g, row0, a.n_edges, tid);
+    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
+    if (tid < FTM) {
+      const int64_t gr = row0 + tid;
+      float ds = 0.f, dn = 0.f;
+      if (gr < a.n_edges) { ds = a.d_src[gr]; dn = a.d_eff[gr]; }
+      sD[tid] = dn;
+      sM[tid] = ds > 0.f ? 1.f : 0.f;
+    }
+    if (tid < FTM * E) {
+      const int r = tid / E;
+      const int64_t gr = row0 + r;
+      float v = 0.f;
+      if (gr < a.n_edges && a.d_src[gr] > 0.f) v = a.de[row0 * E + tid];
+      sdE[tid] = v;
+    }
+    regs_to_lds(pzA, bufA, tid);
+    regs_to_lds(pzB, bufB, tid);
+    __syncthreads();
+    tile_to_regs(pzA, Z1g, row0, a.n_edges, tid);   // lands in bufC at the end of phase B
+    // G3 = (dE Wo^T) * s'(Z3) -> bufC
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lin = tid + i * BW_THREADS;
+      const int row = lin >> 5, c4 = lin & 31;
+      const float4 z = *reinterpret_cast<const float4*>(bufA + row * FLD + c4 * 4);
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < E; ++n) {
+        const float d = sdE[row * E + n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] += d * sWo[(c4 * 4 + j) * E + n];
+      }
+      float4 o;
+      o.x = g[0] * (1.0f - __expf(-z.x));
+      o.y = g[1] * (1.0f - __expf(-z.y));
+      o.z = g[2] * (1.0f - __expf(-z.z));
+      o.w = g[3] * (1.0f - __expf(-z.w));
+      *reinterpret_cast<float4*>(bufC + row * FLD + c4 * 4) = o;
+    }
+    // dWo[k][n] += sum_rows Z3[row][k] dE[row][n]   (thread: k = cn, rows 16rq..16rq+15)
+#pragma unroll 4
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) {
+      const float z = bufA[r * FLD + cn];
+#pragma unroll
+      for (int n = 0; n < E; ++n) accWo[n] += z * sdE[r * E + n];
+    }
+    if (tid < E) {
+      float s = 0.f;
+      for (int r = 0; r < FTM; ++r) s += sdE[r * E + tid];
+      accbo += s;
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase B (layer 3)
+    dw_gemm(accW[2], bufB, bufC, kslab, nsl0, lane);
+#pragma unroll 4
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[2] += bufC[r * FLD + cn];
+    dz_gemm_epilogue(bufC, bufB, bufA, a.WpkT, 2, zk, zrt, lane);
+    __syncthreads();
+    regs_to_lds(pzA, bufC, tid);    // Z1
+    __syncthreads();
+    // ------------------------------------------------------------------ phase C (layer 2)
+    dw_gemm(accW[1], bufC, bufA, kslab, nsl0, lane);
+#pragma unroll 4
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[1] += bufA[r * FLD + cn];
+    dz_gemm_epilogue(bufA, bufC, bufB, a.WpkT, 1, zk, zrt, lane);
+    __syncthreads();
+    // R = m * rbf(d_eff) -> bufA
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lin = tid + i * BW_THREADS;
+      const int row = lin >> 5, c4 = lin & 31;
+      const float d = sD[row], m = sM[row];
+      const float4 mu = *reinterpret_cast<const float4*>(sCen + c4 * 4);
+      const float u0 = d - mu.x, u1 = d - mu.y, u2 = d - mu.z, u3 = d - mu.w;
+      float4 o;
+      o.x = m * __expf(u0 * u0 * a.neg_inv_gap);
+      o.y = m * __expf(u1 * u1 * a.neg_inv_gap);
+      o.z = m * __expf(u2 * u2 * a.neg_inv_gap);
+      o.w = m * __expf(u3 * u3 * a.neg_inv_gap);
+      *reinterpret_cast<float4*>(bufA + row * FLD + c4 * 4) = o;
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase D (layer 1)
+    dw_gemm(accW[0], bufA, bufB, kslab, nsl0, lane);
+#pragma unroll 4
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[0] += bufB[r * FLD + cn];
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------------- write this WG's partial
+  float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
+  {
+    const int half = lane >> 5, l31 = lane & 31;
+    const int k = kslab * 32 + l31;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = (nsl0 + j) * 32 + 8 * q + 4 * half;
+          *reinterpret_cast<float4*>(part + l * FH * FH + k * FH + n) =
+              make_float4(accW[l][j][4 * q + 0], accW[l][j][4 * q + 1], accW[l][j][4 * q + 2],
+                          accW[l][j][4 * q + 3]);
+        }
+  }
+  // cross-row-quarter reduction of the column sums and dWo through LDS (bufA is free now)
+  float* red = bufA;   // [4][3*128 + 128*E]
+  const int red_stride = 3 * FH + FH * E;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = accb[l];
+#pragma unroll
+  for (int n = 0; n < E; ++n) red[rq * red_stride + 3 * FH + cn * E + n] = accWo[n];
+  __syncthreads();
+  for (int t = tid; t < red_stride; t += BW_THREADS)
+    part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
+  if (tid < E) part[3 * FH * FH + red_stride + tid] = accbo;
+}
+
+struct BwdOut {
+  float* dW[3];
+  float* db[3];
+  float* dWo;
+  float* dbo;
+};
+
+// out[...] = sum_wg partial[wg][idx], scattered to the individual gradient tensors
+__global__ void edge_bwd_reduce_kernel(const float* __restrict__ partial, int n_wg, int stride,
+                                       int E, BwdOut o) {
+  const int total = bwd_part_floats(E);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += partial[(int64_t)w * stride + idx];
+    int r = idx;
+    if (r < 3 * FH * FH) { o.dW[r / (FH * FH)][r % (FH * FH)] = s; continue; }
+    r -= 3 * FH * FH;
+    if (r < 3 * FH) { o.db[r / FH][r % FH] = s; continue; }
+    r -= 3 * FH;
+    if (r < FH * E) { o.dWo[r] = s; continue; }
+    r -= FH * E;
+    o.dbo[r] = s;
+  }
+}
+
+int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
+                   const float* d_eff, const float* centers, float gap, const float* const* W,
+                   const float* z_save, const float* de, float* const* dW, float* const* db) {
+  const int64_t ntiles = cdiv(n_edges, FTM);
+  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
+  const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
+  const size_t pk_floats = (size_t)3 * FH * FH;
+  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)grid * stride) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* Wpk = ws;
+  float* WpkT = ws + pk_floats;
+  float* partial = ws + 2 * pk_floats;
+  int rc = edge_fused_pack(ctx, st, W, Wpk, WpkT);
+  if (rc) return rc;
+  EdgeBwdArgs a;
+  a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
+  a.neg_inv_gap = (float)(-1.0 / (double)gap);
+  a.WpkT = WpkT; a.Wo = W[3]; a.z_save = z_save; a.de = de;
+  a.partial = partial; a.part_stride = stride;
+  const size_t lds = (size_t)(3 * FTM * FLD + FH * FMAX_E + FTM * FMAX_E + 2 * FTM + FH) * 4;
+  {
+    ProfScope ps(ctx, st, "edge_fused_bwd");
+#define NG_BW(EE)                                                                                   \
+  case EE:                                                                                          \
+    hipLaunchKernelGGL((edge_fused_bwd_kernel<EE>), dim3(grid), dim3(BW_THREADS), lds, st, a);      \
+    break;
+    switch (E) { NG_BW(1) NG_BW(2) NG_BW(3) NG_BW(4) NG_BW(5) NG_BW(6) NG_BW(7) NG_BW(8) }
+#undef NG_BW
+    NG_HIP(ctx, hipGetLastError());
+  }
+  {
+    ProfScope ps(ctx, st, "edge_bwd_reduce");
+    BwdOut o;
+    for (int l = 0; l < 3; ++l) { o.dW[l] = dW[l]; o.db[l] = db[l]; }
+    o.dWo = dW[3]; o.dbo = db[3];
+    hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3(200), dim3(256), 0, st, partial, grid, stride, E, o);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  return NG_OK;
+}
+
+}  // namespace ng

@@ -10,7 +10,7 @@
 #include <algorithm>
 
 #include "mfma_gemm.cuh"
-#include "ng_internal.h"
+#include "edge_fused.h"
 
 namespace ng {
 
@@ -333,6 +333,8 @@ extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H
     }
     return NG_OK;
   }
+  if (edge_fused_supported(H, E, Le) && !force_layered())
+    return edge_fused_bwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de, dW, db);
   return edge_mlp_bwd_layered(ctx, st, n_edges, H, E, Le, d_src, d_eff, centers, gap, W, z_save, de,
                               dW, db);
 }
