@@ -133,3 +133,121 @@ def test_loss_and_adam_match_oracle(gpu_device):
         eng.adam_step(lr=1e-3)
         p, m, v = O.adam_step(p, g.astype(np.float64), m, v, t, lr=1e-3)
     np.testing.assert_allclose(eng.params.flat.cpu().numpy(), p, rtol=2e-5, atol=1e-7)
+
+
+def test_golden_fixture_bench_arch(gpu_device):
+    """committed golden vectors (tests/golden/golden_f64.npz, generated by tests/golden/make_golden.py)"""
+    import os
+    import torch
+    from oracle import nmrgnn_oracle as O
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_f64.npz"))
+    hp = make_hp(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
+    p = O.init_params(hp_to_oracle(hp), 10, seed=int(g["param_seed"]), dtype=np.float32,
+                      bias_scale=float(g["bias_scale"]))
+    eng = Engine(hp, 10, device=gpu_device)
+    eng.params.load_state_dict(p)
+    gb = GraphBatch(g["atoms"], g["nlist"], g["edges"], g["inv_degree"], graph_ptr=g["graph_ptr"],
+                    device=gpu_device)
+    peaks = eng.forward(gb).cpu().numpy()
+    assert np.max(np.abs(peaks - g["peaks"])) < PEAK_ATOL
+    dev = gpu_device
+    pt = eng.forward(gb, training=True, noise=torch.from_numpy(g["noise"]).to(dev),
+                     dropout_mask=torch.from_numpy(g["dropout_mask"] / 0.8).to(dev))
+    assert np.max(np.abs(pt.cpu().numpy() - g["peaks_train"])) < PEAK_ATOL
+    eng.backward(torch.from_numpy(g["dpeaks"]).to(dev))
+    grads = eng.params.grads_dict()
+    for k in grads:
+        if "g:" + k in g.files:
+            assert rel_err(grads[k], g["g:" + k]) < GRAD_RTOL, k
+        s = g["gs:" + k]
+        assert abs(grads[k].sum() - s[0]) <= GRAD_RTOL * s[1] + 1e-6, k
+        assert abs(np.abs(grads[k]).max() - s[2]) <= GRAD_RTOL * s[2] + 1e-7, k
+
+
+def test_ring_fixture_reference_test_graph(gpu_device):
+    """the reference's own test graph (reference tests/test_nmrgnn.py:197-223): 5 atoms, ring, 16 elements"""
+    import os
+    import torch
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ring.npz"))
+    hp = make_hp(atom_feature_size=32, edge_feature_size=2, edge_hidden_size=16, mp_layers=2,
+                 fc_layers=2, edge_fc_layers=2)
+    eng = Engine(hp, 16, g["peak_std"], g["peak_avg"], device=gpu_device)
+    eng.params.load_state_dict({k[2:]: g[k] for k in g.files if k.startswith("p:")})
+    gb = GraphBatch(g["atoms"], g["nlist"], g["edges"], g["inv_degree"], device=gpu_device)
+    peaks = eng.forward(gb)
+    assert peaks.shape == (5,)
+    assert np.max(np.abs(peaks.cpu().numpy() - g["peaks"])) < PEAK_ATOL
+    hp0 = make_hp(atom_feature_size=32, edge_feature_size=2, edge_hidden_size=16, mp_layers=2,
+                  fc_layers=2, edge_fc_layers=2, noise=0.0, dropout=False)
+    eng0 = Engine(hp0, 16, g["peak_std"], g["peak_avg"], device=gpu_device)
+    eng0.params.load_state_dict({k[2:]: g[k] for k in g.files if k.startswith("p:")})
+    eng0.forward(gb, training=True)
+    eng0.backward(torch.ones(5, device=gpu_device))
+    grads = eng0.params.grads_dict()
+    for k in grads:
+        assert rel_err(grads[k], g["g:" + k]) < GRAD_RTOL, k
+
+
+def test_full_size_fused_equals_layered_and_batch_invariance(gpu_device, monkeypatch):
+    """BASELINE configs[1] size (512 x 256 atoms): size-independent properties —
+    (i) the fused persistent edge kernels and the one-launch-per-layer path agree;
+    (ii) any sub-batch of graphs gives the same peaks as inside the full batch;
+    (iii) the oracle agrees on a sample of graphs."""
+    import torch
+    from oracle import nmrgnn_oracle as O
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    hp = make_hp(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
+    b = synth.make_batch(512, 256, 16, 10, 0.05, seed=42)
+    eng = Engine(hp, 10, device=gpu_device, seed=1234)
+    sd = randomize_biases(eng, scale=0.05)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"],
+                    device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=7)
+    mask = eng.dropout_mask(N * 32, seed=8)
+    dpe = torch.from_numpy(np.random.default_rng(0).standard_normal(N).astype(np.float32)).to(gpu_device)
+
+    def run():
+        pk = eng.forward(gb, training=True, noise=xi, dropout_mask=mask).clone()
+        eng.backward(dpe)
+        return pk.cpu().numpy(), eng.params.grads_dict()
+
+    pk_f, g_f = run()
+    monkeypatch.setenv("NG_EDGE_PATH", "layered")
+    pk_l, g_l = run()
+    monkeypatch.delenv("NG_EDGE_PATH")
+    assert np.max(np.abs(pk_f - pk_l)) < 5e-5
+    for k in g_f:
+        assert rel_err(g_f[k], g_l[k]) < GRAD_RTOL, k
+    # sub-batch invariance + oracle on 2 graphs out of 512
+    inf = eng.forward(gb).cpu().numpy()
+    for gidx in (0, 311):
+        sl = slice(gidx * 256, (gidx + 1) * 256)
+        sub = (b["atoms"][sl], b["nlist"][sl] - gidx * 256, b["edges"][sl], b["inv_degree"][sl])
+        part = eng.forward(GraphBatch(*sub, device=gpu_device)).cpu().numpy()
+        np.testing.assert_allclose(part, inf[sl], rtol=0, atol=1e-5)
+        ref = O.gnn_forward(sub, sd, hp_to_oracle(hp))
+        assert np.max(np.abs(part - ref)) < PEAK_ATOL
+
+
+def test_empty_and_tiny_graphs(gpu_device):
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from oracle import nmrgnn_oracle as O
+    hp = make_hp(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
+    eng = Engine(hp, 10, device=gpu_device)
+    sd = eng.params.state_dict()
+    # one atom, no real neighbour: every slot padded, inv_degree 0
+    atoms = np.zeros((1, 10), np.float32); atoms[0, 4] = 1
+    tup = (atoms, np.zeros((1, 16), np.int32), np.zeros((1, 16), np.float32), np.zeros(1, np.float32))
+    pk = eng.forward(GraphBatch(*tup, device=gpu_device)).cpu().numpy()
+    np.testing.assert_allclose(pk, O.gnn_forward(tup, sd, hp_to_oracle(hp)), atol=PEAK_ATOL)
+    empty = (np.zeros((0, 10), np.float32), np.zeros((0, 16), np.int32), np.zeros((0, 16), np.float32),
+             np.zeros(0, np.float32))
+    assert eng.forward(GraphBatch(*empty, device=gpu_device)).shape == (0,)

@@ -1,0 +1,210 @@
+"""CPU tests of the oracle itself: analytic known-answer tests built on the reference's own test
+inputs (reference tests/test_nmrgnn.py:20-31), constants decoded from the reference's SavedModel,
+gradient checks, and regression against the committed golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nmrgnn_oracle as O
+from oracle import torch_ref as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def ring(F=16, E=2):
+    """reference tests/test_nmrgnn.py:20-31"""
+    nodes = np.eye(F)[[2, 4, 0, 1, 3]]
+    nlist = np.zeros((5, 2), dtype=np.int64)
+    for i in range(5):
+        for k, j in enumerate(range(-1, 3, 2)):
+            nlist[i, k] = (i + j) % 5
+    edges = np.ones((5, 2, E))
+    inv_degree = np.ones(5) / 2
+    return nodes, nlist, edges, inv_degree
+
+
+def test_kat1_ones_weights():
+    nodes, nlist, edges, inv = ring()
+    out, _ = O.mp_layer(nodes, nlist, edges, inv, np.ones((16, 16, 2)), activation=None)
+    np.testing.assert_allclose(out, 2.0)           # 0.5 * 2 neighbours * 2 edge features * 1
+
+
+def test_kat2_structured_weights():
+    nodes, nlist, edges, inv = ring()
+    l, m, n = np.meshgrid(np.arange(16), np.arange(16), np.arange(2), indexing="ij")
+    w = (l + 1) * (m + 1) * (n + 1) / 100.0
+    out, _ = O.mp_layer(nodes, nlist, edges, inv, w, activation=None)
+    # atom 0: neighbours atoms 4,1 -> one-hot columns 3,4
+    np.testing.assert_allclose(out[0], 0.135 * (np.arange(16) + 1), rtol=1e-12)
+
+
+def test_literal_einsum_equals_aggregate_then_gemm():
+    rng = np.random.default_rng(0)
+    N, K, F, E = 40, 16, 32, 3
+    h = rng.standard_normal((N, F)); nl = rng.integers(0, N, (N, K))
+    e = rng.standard_normal((N, K, E)); v = rng.random(N); w = rng.standard_normal((F, F, E))
+    a, _ = O.mp_layer(h, nl, e, v, w)
+    b, _ = O.mp_layer_alg(h, nl, e, v, w)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
+def test_rbf_constants_match_savedmodel():
+    c = json.load(open(os.path.join(GOLD, "savedmodel_constants.json")))
+    centers, gap = O.rbf_centers(0.005, 0.20, 128)
+    ref = np.asarray(c["rbf_centers"], np.float32)
+    assert np.max(np.abs(centers - ref)) <= 2 * np.spacing(np.float32(0.2))
+    assert abs(float(gap) - c["rbf_gap_candidates"][0]) <= 1e-9
+    assert c["noise_stddev"] == pytest.approx(0.025)
+    assert c["dropout_keep_scale"] == pytest.approx(1.0 / (1.0 - O.DROPOUT_RATE))
+    assert c["dropout_rate"] == pytest.approx(O.DROPOUT_RATE)
+    assert c["mask_threshold"] == 0.0 and c["rbf_pow"] == 2.0
+
+
+def test_kat5_rbf_values():
+    centers, gap = O.rbf_centers(0.005, 0.20, 128)
+    k = 17
+    r = O.rbf_expand(np.array([centers[k]], np.float64), centers, gap)
+    assert r[0, k] == pytest.approx(1.0)
+    r = O.rbf_expand(np.array([centers[k] + np.sqrt(float(gap))], np.float64), centers, gap)
+    assert r[0, k] == pytest.approx(np.exp(-1.0), rel=1e-6)
+
+
+def _small_model(seed=0, **kw):
+    hp = O.hypers(atom_feature_size=16, edge_feature_size=2, edge_hidden_size=16, mp_layers=2,
+                  fc_layers=3, edge_fc_layers=3, **kw)
+    p = O.init_params(hp, 10, seed=seed, bias_scale=0.2)
+    rng = np.random.default_rng(seed + 1)
+    N, K = 12, 4
+    atoms = np.eye(10)[rng.integers(2, 5, N)]
+    nlist = rng.integers(0, N, (N, K))
+    edges = rng.uniform(0.05, 0.2, (N, K))
+    edges[:, -1] = 0.0
+    nlist[:, -1] = 0
+    inv = O.inv_degree_from_nlist(nlist).astype(np.float64)
+    return hp, p, (atoms, nlist, edges, inv)
+
+
+def test_kat3_mask_kills_bias_leak_and_padded_index():
+    hp, p, inp = _small_model()
+    out = O.gnn_forward(inp, p, hp, return_all=True)
+    assert np.all(out["e"][:, -1, :] == 0.0)          # biases are non-zero, mask must zero the slot
+    atoms, nlist, edges, inv = inp
+    nl2 = nlist.copy(); nl2[:, -1] = 7
+    np.testing.assert_array_equal(O.gnn_forward((atoms, nl2, edges, inv), p, hp), out["peaks"])
+
+
+def test_kat4_head_standardisation():
+    hp, p, inp = _small_model()
+    std = np.zeros(10); avg = np.zeros(10)
+    assert np.all(O.gnn_forward(inp, p, hp, std, avg) == 0.0)
+    std = np.ones(10)
+    out = O.gnn_forward(inp, p, hp, std, avg, return_all=True)
+    elem = np.argmax(inp[0], 1)
+    np.testing.assert_allclose(out["peaks"], out["full"][np.arange(len(elem)), elem])
+
+
+def test_kat6_batch_invariance():
+    hp, p, (atoms, nlist, edges, inv) = _small_model()
+    N = atoms.shape[0]
+    cat = (np.concatenate([atoms, atoms]), np.concatenate([nlist, nlist + N]),
+           np.concatenate([edges, edges]), np.concatenate([inv, inv]))
+    one = O.gnn_forward((atoms, nlist, edges, inv), p, hp)
+    two = O.gnn_forward(cat, p, hp)
+    np.testing.assert_allclose(two[:N], one, rtol=1e-13)
+    np.testing.assert_allclose(two[N:], one, rtol=1e-13)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_hand_backward_matches_torch_autograd(training):
+    hp, p, inp = _small_model(3)
+    rng = np.random.default_rng(5)
+    N, K = inp[2].shape
+    xi = rng.standard_normal((N, K)); mask = (rng.random((N, 8)) < 0.8).astype(np.float64)
+    dpe = rng.standard_normal(N)
+    kw = dict(training=training, noise=xi, dropout_mask=mask)
+    peaks, grads = O.gnn_forward_backward(inp, p, hp, dpe, **kw)
+    tp = R.to_torch_params(p, requires_grad=True)
+    for order in ("ref", "alg"):
+        for t in tp.values():
+            t.grad = None
+        out = R.forward(inp, tp, hp, order=order, **kw)
+        np.testing.assert_allclose(out.detach().numpy(), peaks, rtol=1e-10, atol=1e-10)
+        (out * torch.tensor(dpe)).sum().backward()
+        for k, g in grads.items():
+            np.testing.assert_allclose(tp[k].grad.numpy(), g, rtol=1e-8, atol=1e-10, err_msg=k)
+
+
+def test_finite_differences():
+    hp, p, inp = _small_model(4)
+    rng = np.random.default_rng(6)
+    dpe = rng.standard_normal(inp[0].shape[0])
+    _, grads = O.gnn_forward_backward(inp, p, hp, dpe)
+    for name in ["mp/0/w", "edge_fc/0/kernel", "edge_fc/2/bias", "fc/1/kernel", "out/bias",
+                 "embed/kernel"]:
+        nz = np.argwhere(np.abs(grads[name]) > 0)
+        idx = tuple(nz[len(nz) // 2])
+        eps = 1e-6
+        pp = {k: v.copy() for k, v in p.items()}; pp[name][idx] += eps
+        pm = {k: v.copy() for k, v in p.items()}; pm[name][idx] -= eps
+        fd = (O.gnn_forward(inp, pp, hp) @ dpe - O.gnn_forward(inp, pm, hp) @ dpe) / (2 * eps)
+        assert fd == pytest.approx(grads[name][idx], rel=1e-5, abs=1e-8), name
+
+
+def test_golden_regression():
+    g = np.load(os.path.join(GOLD, "golden_ring.npz"))
+    hp = O.hypers(atom_feature_size=32, edge_feature_size=2, edge_hidden_size=16, mp_layers=2,
+                  fc_layers=2, edge_fc_layers=2)
+    p = {k[2:]: g[k] for k in g.files if k.startswith("p:")}
+    inp = (g["atoms"], g["nlist"], g["edges"], g["inv_degree"])
+    peaks, grads = O.gnn_forward_backward(inp, p, hp, np.ones(5), g["peak_std"], g["peak_avg"])
+    np.testing.assert_allclose(peaks, g["peaks"], rtol=1e-12)
+    for k in grads:
+        np.testing.assert_allclose(grads[k], g["g:" + k], rtol=1e-10, atol=1e-12)
+    g2 = np.load(os.path.join(GOLD, "golden_f64.npz"))
+    hp2 = O.hypers(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
+    p2 = O.init_params(hp2, 10, seed=int(g2["param_seed"]), dtype=np.float32,
+                       bias_scale=float(g2["bias_scale"]))
+    cs = [sum(float(v.sum()) for v in p2.values()), sum(float(np.abs(v).sum()) for v in p2.values())]
+    np.testing.assert_allclose(cs, g2["param_checksum"], rtol=1e-6)
+    inp2 = (g2["atoms"], g2["nlist"], g2["edges"], g2["inv_degree"])
+    np.testing.assert_allclose(O.gnn_forward(inp2, p2, hp2), g2["peaks"], rtol=1e-11)
+
+
+def test_loss_and_corr():
+    # reference tests/test_nmrgnn.py:188-195 inputs, s = 1 -> weighted L2 over matching names
+    y = np.stack([np.zeros(5), np.array([4., 3, 3, 2, 4]), np.ones(5)], axis=1)
+    assert O.name_loss(y, np.ones(5), [3], s=1.0) == pytest.approx(1.0)
+    assert O.name_loss(y, np.ones(5), [9], s=1.0) == 0.0        # divide_no_nan
+    x = np.arange(6.0); assert O.corr_coeff(x, 2 * x + 1) == pytest.approx(1.0)
+    loss, grad = O.batch_loss_s1(np.zeros(4), np.ones(4), np.array([1., 1, 2, 2]), [0, 2, 4])
+    assert loss == pytest.approx((1.0 + 4.0) / 2)
+    np.testing.assert_allclose(grad, [0.5, 0.5, 1.0, 1.0])
+
+
+def test_adam_matches_torch():
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal(50); g = rng.standard_normal(50)
+    tp = torch.tensor(p0.copy(), requires_grad=True)
+    opt = torch.optim.Adam([tp], lr=1e-3, eps=1e-7)
+    p, m, v = p0.copy(), np.zeros(50), np.zeros(50)
+    for t in range(1, 6):
+        tp.grad = torch.tensor(g)
+        opt.step()
+        p, m, v = O.adam_step(p, g, m, v, t, lr=1e-3)
+    # torch puts eps inside the bias-corrected denominator, keras outside -> agree to ~eps
+    np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_inv_degree_quirk_and_check_peaks():
+    nl = np.array([[0, 3, 2], [1, 0, 0], [0, 0, 0]])
+    np.testing.assert_allclose(O.inv_degree_from_nlist(nl), [0.5, 1.0, 0.0])   # index 0 never counts
+    std = {2: ("C", 126.0, 10.6), 4: ("H", 5.63, 6.04), 7: ("X", 0.0, 0.0)}
+    atoms = np.eye(10)[[2, 4, 4, 2]]
+    conf = O.check_peaks(atoms, np.array([130.0, 5.0, 30.0, 120.0]), std)
+    np.testing.assert_array_equal(conf, [True, True, False, True])
+    with pytest.raises(Warning):
+        O.check_peaks(atoms, np.array([900.0, 500.0, 30.0, 120.0]), std)
