@@ -5,6 +5,7 @@
 
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
+#include "reduce.cuh"
 
 namespace ng {
 
@@ -172,7 +173,7 @@ static DwPlan dw_plan(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
   nz = std::max<int64_t>(std::min(nz, max_z), 1);
   p.k_chunk = std::max<int64_t>(cdiv(cdiv(M, nz), 32) * 32, 32);
   p.nz = std::max<int64_t>(cdiv(M, p.k_chunk), 1);
-  p.cs_blocks = has_db ? std::min<int64_t>(std::max<int64_t>(cdiv(M, 4096), 1), 1024) : 0;
+  p.cs_blocks = has_db ? std::min<int64_t>(std::max<int64_t>(cdiv(M, 512), 1), 2048) : 0;
   p.cs_rows = has_db ? cdiv(M, p.cs_blocks) : 0;
   return p;
 }
@@ -209,9 +210,7 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   }
   {
     ProfScope ps(ctx, st, "reduce_partials");
-    const int blocks = (int)std::min<int64_t>(cdiv(n_elem, 256), 1024);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, partial, (int)p.nz,
-                       n_elem, dW, w_map, F, E, Nout);
+    launch_reduce_z(st, partial, (int)p.nz, n_elem, dW, w_map, F, E, Nout);
     NG_HIP(ctx, hipGetLastError());
   }
   if (db) {
@@ -220,8 +219,7 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
     LoadGradAct lp{dY, S, rowscale, M, Nout, act};
     hipLaunchKernelGGL((colsum_kernel<LoadGradAct>), dim3((unsigned)p.cs_blocks), dim3(256), 0, st,
                        M, Nout, p.cs_rows, lp, cs_partial);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, cs_partial,
-                       (int)p.cs_blocks, (int64_t)Nout, db, 0, 0, 0, Nout);
+    launch_reduce_z(st, cs_partial, (int)p.cs_blocks, (int64_t)Nout, db);
     NG_HIP(ctx, hipGetLastError());
   }
   return NG_OK;

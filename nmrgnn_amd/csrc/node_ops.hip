@@ -6,11 +6,38 @@
 
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
+#include "reduce.cuh"
 
 namespace ng {
 
 constexpr int MAX_E = 8;   // edge_feature_size choices {1,2,3,8} (64 is not supported yet)
 constexpr int MAX_C = 32;  // one-hot width
+
+// element functors for small_tn_kernel
+struct LoadElem {            // plain row-major [N][ld]
+  const float* p;
+  int ld;
+  __device__ __forceinline__ float operator()(int64_t r, int c) const { return p[r * ld + c]; }
+};
+struct LoadHeadX {           // [g * dropout_mask | 1]
+  const float* g;
+  const float* mask;
+  int Fh;
+  __device__ __forceinline__ float operator()(int64_t r, int f) const {
+    if (f == Fh) return 1.0f;
+    const float x = g[r * Fh + f];
+    return mask ? x * mask[r * Fh + f] : x;
+  }
+};
+struct LoadHeadY {           // dfull[i][c] = dpeaks[i] * atoms[i][c] * std[c]
+  const float* dpeaks;
+  const float* atoms;
+  const float* pstd;
+  int C;
+  __device__ __forceinline__ float operator()(int64_t r, int c) const {
+    return dpeaks[r] * atoms[r * C + c] * pstd[c];
+  }
+};
 
 // ------------------------------------------------------------------------------------ embedding
 // h0[i][f] = sum_c atoms[i][c] * Wemb[c][f]      (model.py:262; Dense without bias)
@@ -479,15 +506,18 @@ extern "C" int ng_embed_bwd(ng_ctx* ctx, void* stream, int64_t N, int C, int F, 
     NG_HIP(ctx, hipMemsetAsync(dWemb, 0, items * 4, st));
     return NG_OK;
   }
-  const int64_t rows = 256;
+  // dWemb[c][f] = sum_i atoms[i][c] dh0[i][f]: small transposed product, rows staged through LDS
+  const int64_t rows = 512;
   const int64_t nb = cdiv(N, rows);
   float* partial = (float*)workspace(ctx, nb * items * 4);
   if (!partial) return NG_ERR_NOMEM;
   ProfScope ps(ctx, st, "embed_bwd");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, N, C, F, rows, atoms,
-                     dh0, partial);
-  hipLaunchKernelGGL(sum_partials_kernel, ew_grid(items), dim3(256), 0, st, partial, (int)nb, items,
-                     dWemb);
+  LoadElem fx{atoms, C};
+  LoadElem fy{dh0, F};
+  const dim3 grid((unsigned)nb, (unsigned)cdiv(items, 256 * SMALL_TN_ITEMS));
+  hipLaunchKernelGGL((small_tn_kernel<LoadElem, LoadElem>), grid, dim3(256),
+                     (size_t)64 * (C + F) * 4, st, N, C, F, rows, fx, fy, partial);
+  launch_reduce_z(st, partial, (int)nb, items, dWemb);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -607,7 +637,7 @@ extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
     NG_HIP(ctx, hipMemsetAsync(dbout, 0, (size_t)C * 4, st));
     return NG_OK;
   }
-  const int64_t rows = 256;
+  const int64_t rows = 512;
   const int64_t nb = cdiv(N, rows);
   float* ws = (float*)workspace(ctx, (size_t)(nb * items + items) * 4);
   if (!ws) return NG_ERR_NOMEM;
@@ -616,10 +646,13 @@ extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
   ProfScope ps(ctx, st, "head_bwd");
   hipLaunchKernelGGL(head_bwd_dg_kernel, ew_grid(N * Fh), dim3(256), 0, st, N, Fh, C, drop_mask,
                      Wout, atoms, peak_std, dpeaks, dg);
-  hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)nb), dim3(256), 0, st, N, Fh, C, rows, g,
-                     drop_mask, atoms, peak_std, dpeaks, partial);
-  hipLaunchKernelGGL(sum_partials_kernel, ew_grid(items), dim3(256), 0, st, partial, (int)nb, items,
-                     summed);
+  // [dWout ; dbout][f][c] = sum_i [g*mask | 1][i][f] * dfull[i][c]
+  LoadHeadX fx{g, drop_mask, Fh};
+  LoadHeadY fy{dpeaks, atoms, peak_std, C};
+  const dim3 grid((unsigned)nb, (unsigned)cdiv(items, 256 * SMALL_TN_ITEMS));
+  hipLaunchKernelGGL((small_tn_kernel<LoadHeadX, LoadHeadY>), grid, dim3(256),
+                     (size_t)64 * (Fh + 1 + C) * 4, st, N, Fh + 1, C, rows, fx, fy, partial);
+  launch_reduce_z(st, partial, (int)nb, items, summed);
   NG_HIP(ctx, hipMemcpyAsync(dWout, summed, (size_t)Fh * C * 4, hipMemcpyDeviceToDevice, st));
   NG_HIP(ctx, hipMemcpyAsync(dbout, summed + (size_t)Fh * C, (size_t)C * 4, hipMemcpyDeviceToDevice,
                              st));

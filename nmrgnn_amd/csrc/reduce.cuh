@@ -1,0 +1,88 @@
+// Second-stage reductions and the small transposed product used by the embedding / head weight
+// gradients.  Deterministic (fixed summation order), no atomics.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ng_common.h"
+
+namespace ng {
+
+// out[map(idx)] = sum_z partial[z][idx].   One 1024-thread block per 64 consecutive elements; the
+// 16 waves split z, so every lane has nz/16 independent, fully coalesced loads in flight (the
+// one-thread-per-element form was latency-bound: 60-120 us for a 12K-element gradient).
+//   w_map = 0: identity;  w_map = 1: MPLayer weight, idx = k*Nout + m with k = ne*F + l -> (l*F+m)*E+ne
+static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __restrict__ partial, int nz,
+                                                        int64_t n_elem, float* __restrict__ out,
+                                                        int w_map, int F, int E, int Nout) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (idx < n_elem)
+    for (int z = w; z < nz; z += 16) s += partial[(int64_t)z * n_elem + idx];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && idx < n_elem) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) t += red[j][lane];
+    int64_t o = idx;
+    if (w_map == 1) {
+      const int k = (int)(idx / Nout), m = (int)(idx % Nout);
+      const int ne = k / F, l = k % F;
+      o = ((int64_t)l * F + m) * E + ne;
+    }
+    out[o] = t;
+  }
+}
+
+static inline void launch_reduce_z(hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out,
+                            int w_map = 0, int F = 0, int E = 0, int Nout = 1) {
+  hipLaunchKernelGGL(reduce_z_kernel, dim3((unsigned)cdiv(n_elem, 64)), dim3(1024), 0, st, partial,
+                     nz, n_elem, out, w_map, F, E, Nout);
+}
+
+// partial[blk][a*B + b] = sum_{rows of blk} X(row, a) * Y(row, b)      (A <= 32, any B)
+// rows are staged 64 at a time in LDS; thread t owns items t, t+256, ... (<= SMALL_TN_ITEMS each);
+// blockIdx.y selects a batch of 256*SMALL_TN_ITEMS items.
+constexpr int SMALL_TN_ITEMS = 12;
+
+template <class FX, class FY>
+__global__ __launch_bounds__(256) void small_tn_kernel(int64_t N, int A, int B,
+                                                       int64_t rows_per_block, FX fx, FY fy,
+                                                       float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Xs = sm;           // [64][A]
+  float* Ys = sm + 64 * A;  // [64][B]
+  const int items = A * B;
+  const int item0 = blockIdx.y * 256 * SMALL_TN_ITEMS;
+  float acc[SMALL_TN_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SMALL_TN_ITEMS; ++j) acc[j] = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  for (int64_t rb = r0; rb < r1; rb += 64) {
+    const int nr = (int)(r1 - rb < 64 ? r1 - rb : 64);
+    __syncthreads();
+    for (int t = threadIdx.x; t < nr * A; t += 256) Xs[t] = fx(rb + t / A, t % A);
+    for (int t = threadIdx.x; t < nr * B; t += 256) Ys[t] = fy(rb + t / B, t % B);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SMALL_TN_ITEMS; ++j) {
+      const int it = item0 + threadIdx.x + 256 * j;
+      if (it < items) {
+        const int a = it / B, b = it % B;
+        float s = acc[j];
+        for (int r = 0; r < nr; ++r) s += Xs[r * A + a] * Ys[r * B + b];
+        acc[j] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SMALL_TN_ITEMS; ++j) {
+    const int it = item0 + threadIdx.x + 256 * j;
+    if (it < items) partial[(int64_t)blockIdx.x * items + it] = acc[j];
+  }
+}
+
+}  // namespace ng
