@@ -65,6 +65,11 @@ int ng_dropout_mask(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, float
 int ng_add_scaled(ng_ctx*, void* stream, int64_t n, const float* x, const float* y, float alpha,
                   float* out);
 
+/* RBFExpansion alone, nmrgnn/layers.py:137-140: out[n,H] = (d_src>0) * exp(-(d_eff-centers)^2/gap)
+ * (pass d_src = d_eff for the unmasked layer on positive distances) */
+int ng_rbf_expand(ng_ctx*, void* stream, int64_t n, int H, const float* d_src, const float* d_eff,
+                  const float* centers, float gap, float* out);
+
 /* ---- edge path: mask + RBFExpansion + EdgeFCBlock ------------------------------------------
  * replaces nmrgnn/model.py:251-261, nmrgnn/layers.py:137-140, nmrgnn/model.py:132-138.
  *   d_src  [n_edges]  raw distances (mask = d_src > 0)
@@ -96,10 +101,11 @@ int ng_mp_aggregate(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const
                     const int32_t* nlist, const float* e, float* A);
 
 /* MPLayer + residual, nmrgnn/layers.py:26-46 and nmrgnn/model.py:165-167:
- *   P = inv_degree * einsum('ijn,ijl,lmn->im', e, h[nlist], w);  h_out = act(P) + h
+ *   P = inv_degree * einsum('ijn,ijl,lmn->im', e, h[nlist], w);  h_out = act(P) (+ h if residual:
+ *   MPBlock, model.py:167; residual = 0 gives the bare MPLayer of layers.py:26-46)
  *   w is the reference layout [F,F,E].  A_save [N,E,F] and s_save [N,F] (= act(P)) are written
  *   when non-NULL (training). */
-int ng_mp_layer_fwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act,
+int ng_mp_layer_fwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act, int residual,
                     const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
                     const float* w, float* h_out, float* A_save, float* s_save);
 /* backward of the above.  csc_ptr[N+1], csc_edge[nnz]: incoming-edge lists (edge id = i*K+j

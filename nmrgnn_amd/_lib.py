@@ -35,6 +35,7 @@ SIGNATURES = {
     "ng_randn": (_int, [_vp, _vp, _u64, _u64, _vp, _i64]),
     "ng_dropout_mask": (_int, [_vp, _vp, _u64, _u64, _f, _vp, _i64]),
     "ng_add_scaled": (_int, [_vp, _vp, _i64, _vp, _vp, _f, _vp]),
+    "ng_rbf_expand": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _f, _vp]),
     "ng_edge_mlp_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _f,
                                C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "ng_edge_mlp_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _f,
@@ -42,7 +43,7 @@ SIGNATURES = {
     "ng_embed_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "ng_embed_bwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "ng_mp_aggregate": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "ng_mp_layer_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp,
+    "ng_mp_layer_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
     "ng_mp_layer_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),

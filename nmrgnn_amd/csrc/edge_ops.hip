@@ -298,6 +298,18 @@ static bool force_layered() {
 
 using namespace ng;
 
+extern "C" int ng_rbf_expand(ng_ctx* ctx, void* stream, int64_t n, int H, const float* d_src,
+                             const float* d_eff, const float* centers, float gap, float* out) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, H % 4 == 0 && gap > 0.f, "rbf_expand: H % 4 == 0, gap > 0");
+  if (n == 0) return NG_OK;
+  ProfScope ps(ctx, (hipStream_t)stream, "rbf");
+  hipLaunchKernelGGL(rbf_kernel, ew_grid(n * (H / 4)), dim3(256), 0, (hipStream_t)stream, n, H, d_src,
+                     d_eff, centers, (float)(-1.0 / (double)gap), out);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 extern "C" int ng_edge_mlp_fwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
                                const float* d_src, const float* d_eff, const float* centers,
                                float gap, const float* const* W, const float* const* b,

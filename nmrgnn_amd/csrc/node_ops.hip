@@ -529,7 +529,7 @@ extern "C" int ng_mp_aggregate(ng_ctx* ctx, void* stream, int64_t N, int K, int 
 }
 
 extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
-                               const float* h, const int32_t* nlist, const float* e,
+                               int residual, const float* h, const int32_t* nlist, const float* e,
                                const float* inv_degree, const float* w, float* h_out, float* A_save,
                                float* s_save) {
   if (!ctx) return NG_ERR_INVALID;
@@ -547,7 +547,8 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, A);
   if (rc) return rc;
   // P = inv * (A @ Wp);  h_out = act(P) + h
-  return dense_fwd(ctx, st, N, (int)KF, F, act, A, Wp, nullptr, inv_degree, h, h_out, s_save,
+  return dense_fwd(ctx, st, N, (int)KF, F, act, A, Wp, nullptr, inv_degree, residual ? h : nullptr,
+                   h_out, s_save,
                    "mp_update_fwd");
 }
 

@@ -133,7 +133,7 @@ class Engine:
             hn = self._new(N, F)
             A = self._new(N, E, F) if training else None
             S = self._new(N, F) if (training and self.mp_act != 0) else None
-            self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, ptr(hs[-1]),
+            self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
                                          ptr(batch.nlist), ptr(e), ptr(batch.inv_degree),
                                          ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A), ptr(S)),
                      "ng_mp_layer_fwd")

@@ -1,0 +1,129 @@
+"""``GNNModel`` / ``build_GNNModel`` — the reference's model object (nmrgnn/model.py:12-105, 205-274)
+on top of the HIP engine.  ``model((atoms, nlist, edges, inv_degree), training=False)`` returns one
+chemical shift per atom, exactly like the Keras model's ``call``.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from .engine import Engine
+from .graph import GraphBatch
+from .hypers import HyperParameters, declare_gnn_space
+from .standards import load_standards
+
+LOTS_OF_ELEMENTS = 100   # nmrgnn/model.py:222
+
+
+class Peaks(np.ndarray):
+    """numpy array that also answers ``.numpy()`` like the TF eager tensor the reference returns."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+class GNNModel:
+    def __init__(self, hypers, peak_standards, name='gnn-model', device=None, seed=1234, **kwargs):
+        self.hypers = hypers
+        self.name = name
+        self.peak_standards = dict(peak_standards)
+        # nmrgnn/model.py:220-228: large std/avg tables, cut to num_elem at build time
+        self.peak_std = np.ones(LOTS_OF_ELEMENTS, dtype=np.float32)
+        self.peak_avg = np.zeros(LOTS_OF_ELEMENTS, dtype=np.float32)
+        for k, v in self.peak_standards.items():
+            self.peak_std[k] = v[2]
+            self.peak_avg[k] = v[1]
+        self.embed_dim = hypers.get('atom_feature_size')
+        self._device = device
+        self._seed = seed
+        self.engine = None
+        self._pending_state = None
+
+    # -- keras-like build: the number of elements comes from the first input (model.py:236-243)
+    def build(self, num_elem):
+        if self.engine is not None:
+            if self.engine.C != num_elem:
+                raise ValueError(f"model was built for {self.engine.C} elements, got {num_elem}")
+            return
+        self.engine = Engine(self.hypers, num_elem, self.peak_std[:num_elem], self.peak_avg[:num_elem],
+                             device=self._device, seed=self._seed)
+        if self._pending_state is not None:
+            self.engine.params.load_state_dict(self._pending_state)
+            self._pending_state = None
+
+    def _as_batch(self, inputs):
+        if isinstance(inputs, GraphBatch):
+            return inputs, True
+        atoms, nlist, edges, inv_degree = inputs
+        on_device = all(isinstance(x, torch.Tensor) and x.is_cuda for x in (atoms, nlist, edges))
+        num_elem = int(atoms.shape[-1])
+        self.build(num_elem)
+        return GraphBatch(atoms, nlist, edges, inv_degree, device=self.engine.device), on_device
+
+    def __call__(self, inputs, training=False):
+        batch, on_device = self._as_batch(inputs)
+        if self.engine is None:
+            self.build(batch.C)
+        peaks = self.engine.forward(batch, training=training)
+        if on_device:
+            return peaks
+        return peaks.cpu().numpy().view(Peaks)
+
+    call = __call__
+    predict = __call__
+
+    # -- weights
+    def get_weights(self):
+        self._need_engine()
+        return self.engine.params.state_dict()
+
+    def set_weights(self, state):
+        if self.engine is None:
+            self._pending_state = state
+        else:
+            self.engine.params.load_state_dict(state)
+
+    def count_params(self):
+        self._need_engine()
+        return self.engine.params.count()
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError("model is not built yet: call it once (or model.build(num_elem))")
+
+    def get_config(self):
+        return {'hypers': self.hypers.as_dict(), 'peak_standards': self.peak_standards}
+
+    def save(self, path):
+        """own flat format: <path>/weights.npz + <path>/config.json (names follow the Keras variable tree)"""
+        self._need_engine()
+        os.makedirs(path, exist_ok=True)
+        np.savez(os.path.join(path, "weights.npz"), **{k.replace("/", "."): v for k, v in
+                                                        self.engine.params.state_dict().items()})
+        cfg = {"hypers": self.hypers.as_dict(), "num_elem": self.engine.C,
+               "peak_standards": {str(k): list(v) for k, v in self.peak_standards.items()}}
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+
+    def load_weights(self, path):
+        f = path if path.endswith(".npz") else os.path.join(path, "weights.npz")
+        z = np.load(f)
+        self.set_weights({k.replace(".", "/"): z[k] for k in z.files})
+
+
+def build_GNNModel(hp=None, metrics=True, loss_balance=1.0, device=None):
+    """nmrgnn/model.py:12-105.  Declares the hyper-parameter space on ``hp`` (same names/defaults),
+    loads the peak standards and returns a GNNModel with ``optimizer`` / ``loss`` attributes set
+    (Adam at hp['learning_rate'], NameLoss(s=loss_balance)).  The 15 keras metrics of the
+    reference are training observability and are not part of the engine."""
+    from .losses import NameLoss
+    hp = HyperParameters() if hp is None else hp
+    declare_gnn_space(hp)
+    model = GNNModel(hp, load_standards(), device=device)
+    model.loss = NameLoss(label_idx=None, s=loss_balance)
+    model.optimizer = {"name": "Adam", "learning_rate": hp.get('learning_rate'),
+                       "beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7}
+    return model
