@@ -29,3 +29,16 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
 int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp);
 
 }  // namespace ng
+
+namespace ng {
+// fused MPLayer kernels (mp_fused.hip): atom_feature_size == 64, edge_feature_size <= 3
+bool mp_fused_enabled(int F, int E);
+int mp_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,
+                 const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
+                 const float* w, float* h_out, float* A_save, float* s_save);
+int mp_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
+                 const int32_t* nlist, const float* e, const float* inv_degree, const float* w,
+                 const float* A_save, const float* s_save, const int32_t* csc_ptr,
+                 const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
+                 float* dw);
+}  // namespace ng

@@ -535,6 +535,9 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   if (!ctx) return NG_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, (E * F) % 8 == 0, "mp_layer: (E*F) % 8");
+  if (N > 0 && mp_fused_enabled(F, E))
+    return mp_fused_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, A_save,
+                        s_save);
   const int64_t KF = (int64_t)E * F;
   // scratch: Wp [KF*F] (+ A [N*KF] when the caller does not keep it)
   const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;
@@ -565,6 +568,9 @@ extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
              "mp_layer_bwd: F in {16,32,64,128,256}");
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "mp_layer_bwd: edge_feature_size <= 8");
+  if (N > 0 && mp_fused_enabled(F, E))
+    return mp_fused_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
+                        csc_edge, dh_out, dh_in, de, de_accum, dw);
   const int64_t KF = (int64_t)E * F;
   const float* S = s_save;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
