@@ -24,14 +24,12 @@
 namespace ng {
 
 
-// fast softplus for the epilogue: max(x,0) + log1p(exp(-|x|)); series below 2^-11 keeps the
-// relative accuracy where 1+t would round
+// softplus for the epilogue in 6 VALU instructions: max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e)).
+// v_exp_f32 / v_log_f32 are ~1 ulp; forming 1+t rounds at 6e-8 ABSOLUTE, which is the rounding level
+// of the O(1) activations this feeds (parity tests hold the 1e-4 budget on the final shifts).
 __device__ __forceinline__ float softplus_fast(float x) {
-  const float t = __expf(-fabsf(x));
-  const float l_big = __logf(1.0f + t);          // both arms are computed: a v_cndmask, no branch
-  const float l_small = t * (1.0f - 0.5f * t);
-  const float l = t > 4.8828125e-4f ? l_big : l_small;
-  return fmaxf(x, 0.0f) + l;
+  const float t = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+  return fmaf(0.6931471805599453f, __builtin_amdgcn_logf(1.0f + t), fmaxf(x, 0.0f));
 }
 
 // Wpk[layer][w][t][lane][s] = W[layer][k = 8t + 4*(lane>>5) + s][n = 32w + (lane&31)]   (forward)
@@ -79,9 +77,20 @@ __device__ __forceinline__ void load_wfrag(float (&wf)[64], const float* __restr
   }
 }
 
-// one hidden layer for this wave's 32-column slab: Xout[:, slab] = softplus(Xin W[:, slab] + b)
-// After the MFMA chain the slab registers are dead: the NEXT layer's slab is loaded into them right
-// there, so its L2 latency hides under this layer's softplus epilogue (one 64-VGPR set, no spills).
+// one hidden layer for this wave's 32-column slab: Xout[:, slab] = softplus(Xin W[:, slab] + b).
+// Rows 0-31 are accumulated first; their softplus epilogue is then issued BETWEEN the MFMAs of rows
+// 32-63 (an MFMA occupies the matrix pipe for 64 cycles after it issues, so the VALU work rides under
+// it), leaving only the second half's epilogue exposed.  After the MFMA chain the slab registers are
+// dead: the NEXT layer's slab is loaded into them, its L2 latency hiding under that last epilogue.
+__device__ __forceinline__ void epilogue_q(const f32x16& acc, int q, const float* __restrict__ bias,
+                                           float* __restrict__ dst) {
+  const float4 bv = *reinterpret_cast<const float4*>(bias + 8 * q);
+  float4 v;
+  v.x = softplus_fast(acc[4 * q + 0] + bv.x); v.y = softplus_fast(acc[4 * q + 1] + bv.y);
+  v.z = softplus_fast(acc[4 * q + 2] + bv.z); v.w = softplus_fast(acc[4 * q + 3] + bv.w);
+  *reinterpret_cast<float4*>(dst + 8 * q) = v;
+}
+
 __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __restrict__ Xin,
                                              float* __restrict__ Xout,
                                              const float* __restrict__ bias, int wave, int lane,
@@ -92,33 +101,31 @@ __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __res
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   const float* x0 = Xin + l31 * FLD + half * 4;
   const float* x1 = x0 + 32 * FLD;
+  // lane holds, for rows l31 and 32+l31, columns 32*wave + 8q + 4*half + (0..3)
+  const int ncol = 32 * wave + 4 * half;
+  const float* bcol = bias + ncol;
+  float* o0 = Xout + l31 * FLD + ncol;
+  float* o1 = o0 + 32 * FLD;
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const float4 a = *reinterpret_cast<const float4*>(x0 + 8 * t);
-    const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * t);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 0], a.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 0], b.x, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 1], a.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 1], b.y, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 2], a.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 2], b.z, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 3], a.w, acc0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * t);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 0], b.x, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 1], b.y, acc1, 0, 0, 0);
+    if ((t & 3) == 1) epilogue_q(acc0, t >> 2, bcol, o0);   // rides under the surrounding MFMAs
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 2], b.z, acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 3], b.w, acc1, 0, 0, 0);
   }
   load_wfrag(wf, Wpk, next_layer, wave, lane);
-  // lane holds, for rows l31 and 32+l31, columns 32*wave + 8q + 4*half + (0..3)
-  const int ncol = 32 * wave + 4 * half;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 bv = *reinterpret_cast<const float4*>(bias + ncol + 8 * q);
-    float4 v0, v1;
-    v0.x = softplus_fast(acc0[4 * q + 0] + bv.x); v0.y = softplus_fast(acc0[4 * q + 1] + bv.y);
-    v0.z = softplus_fast(acc0[4 * q + 2] + bv.z); v0.w = softplus_fast(acc0[4 * q + 3] + bv.w);
-    v1.x = softplus_fast(acc1[4 * q + 0] + bv.x); v1.y = softplus_fast(acc1[4 * q + 1] + bv.y);
-    v1.z = softplus_fast(acc1[4 * q + 2] + bv.z); v1.w = softplus_fast(acc1[4 * q + 3] + bv.w);
-    *reinterpret_cast<float4*>(Xout + l31 * FLD + ncol + 8 * q) = v0;
-    *reinterpret_cast<float4*>(Xout + (32 + l31) * FLD + ncol + 8 * q) = v1;
-  }
+  for (int q = 0; q < 4; ++q) epilogue_q(acc1, q, bcol, o1);
 }
 
 // copy a finished [64][128] LDS tile to global as whole rows (wave w: rows 16w .. 16w+15)

