@@ -19,3 +19,14 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* z_save, const float* de, float* const* dW, float* const* db);
 }  // namespace ng
+
+// Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also drains vmcnt(0), which
+// would make every barrier wait for the register-destination prefetches (next tile's activations,
+// next layer's weight slab) and the activation stores that are deliberately left in flight across
+// phases; the compiler still inserts the vmcnt wait in front of the first USE of a loaded register.
+#define NG_LDS_BARRIER()                                   \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)

@@ -191,18 +191,18 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
         *reinterpret_cast<float4*>(dst + 4 * i) = v;
       }
     }
-    __syncthreads();
+    NG_LDS_BARRIER();
     // ---- hidden layer 0: X0 -> X1
     hidden_layer(wf, X0, X1, sBias, wave, lane, a.Wpk, 1);
-    __syncthreads();
+    NG_LDS_BARRIER();
     if (SAVE) save_tile(X1, a.z_save, row0, a.n_edges, wave, lane);
     // ---- hidden layer 1: X1 -> X0
     hidden_layer(wf, X1, X0, sBias + FH, wave, lane, a.Wpk, 2);
-    __syncthreads();
+    NG_LDS_BARRIER();
     if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, row0, a.n_edges, wave, lane);
     // ---- hidden layer 2: X0 -> X1   (reloads layer 0's slab for the next tile)
     hidden_layer(wf, X0, X1, sBias + 2 * FH, wave, lane, a.Wpk, 0);
-    __syncthreads();
+    NG_LDS_BARRIER();
     if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, row0, a.n_edges, wave, lane);
     // ---- output layer: wave w -> rows 16w..16w+15, 4 lanes per row (k = 16i + 4*(lane&3) + s)
     {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
     }
     // (the barrier after the next tile's RBF phase orders these X1 / sMask reads before they are
     //  overwritten: X1 is next written in layer 0's epilogue, sMask in the RBF phase — see below)
-    __syncthreads();
+    NG_LDS_BARRIER();
   }
 }
 

@@ -83,6 +83,12 @@ __device__ __forceinline__ void dw_gemm(f32x16 (&acc)[2], const float* __restric
   }
 }
 
+// bias gradient: column cn over the 16 rows of quarter rq
+__device__ __forceinline__ void colsum16(float& acc, const float* __restrict__ G, int cn, int rq) {
+#pragma unroll 4
+  for (int r = 16 * rq; r < 16 * rq + 16; ++r) acc += G[r * FLD + cn];
+}
+
 // dZ[row][k] = sum_n G[row][n] W[k][n]  for k-slab zk, row-tile zrt;  then
 // Gout[row][k] = dZ * (1 - exp(-Z[row][k]))
 __device__ __forceinline__ void dz_gemm_epilogue(const float* __restrict__ G,
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
     if (tid < FTM * E) sdE[tid] = pf_de;
     regs_to_lds(pzA, bufA, tid);
     regs_to_lds(pzB, bufB, tid);
-    __syncthreads();
+    NG_LDS_BARRIER();
     tile_to_regs(pzA, Z1g, row0, a.n_edges, tid);   // lands in bufC at the end of phase B
     // G3 = (dE Wo^T) * s'(Z3) -> bufC
 #pragma unroll
@@ -229,27 +235,21 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
       const float z = bufA[r * FLD + cn];
 #pragma unroll
       for (int n = 0; n < E; ++n) accWo[n] += z * sdE[r * E + n];
+      if (cn < E) accbo += sdE[r * E + cn];
     }
-    if (tid < E) {
-      float s = 0.f;
-      for (int r = 0; r < FTM; ++r) s += sdE[r * E + tid];
-      accbo += s;
-    }
-    __syncthreads();
+    NG_LDS_BARRIER();
     // ------------------------------------------------------------------ phase B (layer 3)
     dw_gemm(accW[2], bufB, bufC, kslab, nsl0, lane);
-#pragma unroll 4
-    for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[2] += bufC[r * FLD + cn];
+    colsum16(accb[2], bufC, cn, rq);
     dz_gemm_epilogue(bufC, bufB, bufA, a.WpkT, 2, zk, zrt, lane);
-    __syncthreads();
+    NG_LDS_BARRIER();
     regs_to_lds(pzA, bufC, tid);    // Z1
-    __syncthreads();
+    NG_LDS_BARRIER();
     // ------------------------------------------------------------------ phase C (layer 2)
     dw_gemm(accW[1], bufC, bufA, kslab, nsl0, lane);
-#pragma unroll 4
-    for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[1] += bufA[r * FLD + cn];
+    colsum16(accb[1], bufA, cn, rq);
     dz_gemm_epilogue(bufA, bufC, bufB, a.WpkT, 1, zk, zrt, lane);
-    __syncthreads();
+    NG_LDS_BARRIER();
     // R = m * rbf(d_eff) -> bufA
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -265,13 +265,12 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
       o.w = m * __expf(u3 * u3 * a.neg_inv_gap);
       *reinterpret_cast<float4*>(bufA + row * FLD + c4 * 4) = o;
     }
-    __syncthreads();
+    NG_LDS_BARRIER();
     // ------------------------------------------------------------------ phase D (layer 1)
     if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * FTM);
     dw_gemm(accW[0], bufA, bufB, kslab, nsl0, lane);
-#pragma unroll 4
-    for (int r = 16 * rq; r < 16 * rq + 16; ++r) accb[0] += bufB[r * FLD + cn];
-    __syncthreads();
+    colsum16(accb[0], bufB, cn, rq);
+    NG_LDS_BARRIER();
   }
 
   // ---------------------------------------------------------------------- write this WG's partial
@@ -293,15 +292,15 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   }
   // cross-row-quarter reduction of the column sums and dWo through LDS (bufA is free now)
   float* red = bufA;   // [4][3*128 + 128*E]
-  const int red_stride = 3 * FH + FH * E;
+  const int red_stride = 3 * FH + FH * E + E;
 #pragma unroll
   for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = accb[l];
 #pragma unroll
   for (int n = 0; n < E; ++n) red[rq * red_stride + 3 * FH + cn * E + n] = accWo[n];
+  if (cn < E) red[rq * red_stride + 3 * FH + FH * E + cn] = accbo;
   __syncthreads();
   for (int t = tid; t < red_stride; t += BW_THREADS)
     part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
-  if (tid < E) part[3 * FH * FH + red_stride + tid] = accbo;
 }
 
 struct BwdOut {
