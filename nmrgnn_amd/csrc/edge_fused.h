@@ -30,3 +30,11 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
     __builtin_amdgcn_s_barrier();                          \
     asm volatile("" ::: "memory");                         \
   } while (0)
+
+namespace ng {
+// one-wave-per-SIMD backward kernel (edge_fused_bwd2.hip); partial layout as in edge_fused_bwd.hip
+int edge_fused_bwd2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
+                           const float* d_eff, const float* centers, float gap, const float* WpkT,
+                           const float* Wo, const float* z_save, const float* de, float* partial,
+                           int part_stride, int grid);
+}  // namespace ng
