@@ -227,14 +227,36 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
 
 }  // namespace ng
 
+namespace ng {
+// shapes the register-resident tall-skinny kernels cover (tall_gemm.hip); NG_DENSE_PATH=generic disables
+bool tall_dense_ok(int k_in, int n_out) {
+  const char* v = getenv("NG_DENSE_PATH");
+  if (v && std::string(v) == "generic") return false;
+  if (k_in % 4 || n_out % 4 || k_in > 192 || n_out > 192) return false;
+  const int kpad = (k_in + 63) / 64 * 64, npad = (n_out + 63) / 64 * 64;
+  return tall_gemm_supported(kpad, npad);
+}
+}  // namespace ng
+
 // ------------------------------------------------------------------- C ABI
 extern "C" int ng_dense_fwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int Nout, int act,
                             int residual, const float* X, const float* W, const float* b, float* Y,
                             float* s_save) {
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, !residual || Kin == Nout, "ng_dense_fwd: residual needs Kin == Nout");
-  return ng::dense_fwd(ctx, (hipStream_t)stream, M, Kin, Nout, act, X, W, b, nullptr,
-                       residual ? X : nullptr, Y, s_save);
+  hipStream_t st = (hipStream_t)stream;
+  if (ng::tall_dense_ok(Kin, Nout)) {   // 64-feature model: weights resident in registers
+    const int kpad = (Kin + 63) / 64 * 64, npad = (Nout + 63) / 64 * 64;
+    float* Wfrag = (float*)ng::workspace(ctx, (size_t)kpad * npad * 4);
+    if (!Wfrag) return NG_ERR_NOMEM;
+    int rc = ng::tall_pack(ctx, st, Kin, Nout, kpad, npad, Nout, 1, W, Wfrag);
+    if (rc) return rc;
+    ng::TallArgs a{};
+    a.N = M; a.X = X; a.ldx = Kin; a.k_valid = Kin; a.Wfrag = Wfrag; a.bias = b; a.act = act;
+    a.S_save = s_save; a.resid = residual ? X : nullptr; a.out = Y; a.ldo = Nout; a.n_valid = Nout;
+    return ng::tall_gemm(ctx, st, kpad, npad, a, false, "dense_fwd");
+  }
+  return ng::dense_fwd(ctx, st, M, Kin, Nout, act, X, W, b, nullptr, residual ? X : nullptr, Y, s_save);
 }
 
 extern "C" int ng_dense_bwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int Nout, int act,
@@ -245,7 +267,21 @@ extern "C" int ng_dense_bwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int N
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "ng_dense_bwd: activation backward needs s_save");
   const float* S = s_save;
   hipStream_t st = (hipStream_t)stream;
-  if (dX) {
+  if (dX && ng::tall_dense_ok(Nout, Kin)) {
+    // dX[m][k] = (dY) + sum_n dP[m][n] W[k][n]: contraction over n, W(kk = n, o = k) = w[k*Nout + n]
+    const int kpad = (Nout + 63) / 64 * 64, npad = (Kin + 63) / 64 * 64;
+    float* Wfrag = (float*)ng::workspace(ctx, (size_t)kpad * npad * 4);
+    if (!Wfrag) return NG_ERR_NOMEM;
+    int rc = ng::tall_pack(ctx, st, Nout, Kin, kpad, npad, 1, Nout, W, Wfrag);
+    if (rc) return rc;
+    ng::TallArgs a{};
+    a.N = M; a.X = dY; a.ldx = Nout; a.k_valid = Nout;
+    a.S_in = act == NG_ACT_NONE ? nullptr : S; a.act_in = act;
+    a.Wfrag = Wfrag; a.act = NG_ACT_NONE; a.resid = residual ? dY : nullptr; a.out = dX; a.ldo = Kin;
+    a.n_valid = Kin;
+    rc = ng::tall_gemm(ctx, st, kpad, npad, a, true, "dense_dx");
+    if (rc) return rc;
+  } else if (dX) {
     int rc = ng::dense_dx(ctx, st, M, Kin, Nout, act, dY, S, nullptr, W, residual ? dY : nullptr, dX);
     if (rc) return rc;
   }

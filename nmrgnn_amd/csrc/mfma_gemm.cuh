@@ -56,6 +56,15 @@ __device__ __forceinline__ float act_grad_from_out(int act, float s) {
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// XCD-aware workgroup -> tile remap (bijective for any grid size).  The dispatcher is observed to
+// place workgroup b on XCD b % 8; this gives XCD x the contiguous tile range [x*n/8, (x+1)*n/8) so
+// that neighbouring tiles (which share gathered rows) share one L2.  Placement is used for speed only.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n) {
+  const unsigned q = n / 8, r = n % 8, x = b % 8, k = b / 8;
+  const unsigned base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + k;
+}
+
 // ---- generic operand loaders -----------------------------------------------------------------
 // A loader returns the float4 at (r, c..c+3) of a row-major [R][C] array, zero outside.
 struct LoadPlain {

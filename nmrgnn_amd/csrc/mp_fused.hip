@@ -375,13 +375,13 @@ __global__ __launch_bounds__(256, 2) void mp_bwd_edge_kernel(MpEdgeBwdArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-static bool mp_force_layered() {
+// selected with NG_MP_PATH=fused (default is the split path of mp_split.hip, which measures faster)
+bool mp_fused_enabled(int F, int E) {
   const char* v = getenv("NG_MP_PATH");
-  return v && std::string(v) == "layered";
+  return v && std::string(v) == "fused" && mp_fused_supported(F, E);
 }
-bool mp_fused_enabled(int F, int E) { return mp_fused_supported(F, E) && !mp_force_layered(); }
 
-static int mp_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
+int mp_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
   hipLaunchKernelGGL(mp_pack_kernel, dim3(48), dim3(256), 0, st, E, mode, w, out);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;

@@ -41,4 +41,49 @@ int mp_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
                  const float* A_save, const float* s_save, const int32_t* csc_ptr,
                  const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
                  float* dw);
+
+// MPLayer weight fragment packing (mp_fused.hip): mode 0 forward Wp, 1 back-to-nodes Wq, 2 dA = dP Wp^T
+int mp_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out);
+
+// tall-skinny dense products with register-resident weights (tall_gemm.hip)
+struct TallArgs {
+  int64_t N;
+  const float* X;        // [N][ldx]; columns >= k_valid read as 0
+  int ldx, k_valid;
+  const float* S_in;     // prologue (dP = X * act'(S_in) * rs_in), same layout as X
+  const float* rs_in;
+  int act_in;
+  float* dP_out;         // optional copy of the prologue result
+  const float* Wfrag;    // packed by tall_pack / mp_pack
+  const float* bias;     // [n_valid] or nullptr
+  const float* rowscale; // [N] or nullptr
+  int act;
+  float* S_save;         // activation output (before the residual) or nullptr
+  const float* resid;    // [N][ldo] or nullptr
+  float* out;            // [N][ldo]; columns >= n_valid are not written
+  int ldo, n_valid;
+};
+bool tall_gemm_supported(int kpad, int npad);
+int tall_pack(ng_ctx* ctx, hipStream_t st, int k_in, int n_out, int kpad, int npad, int sk, int so,
+              const float* w, float* out);
+int tall_gemm(ng_ctx* ctx, hipStream_t st, int kpad, int npad, const TallArgs& a, bool prologue,
+              const char* tag);
+
+// split MPLayer path for atom_feature_size == 64 (mp_split.hip): XCD-aware gather kernels + tall GEMMs
+bool mp_split_enabled(int F, int E);
+int mp_split_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,
+                 const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
+                 const float* w, float* h_out, float* A_save, float* s_save);
+int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
+                 const int32_t* nlist, const float* e, const float* inv_degree, const float* w,
+                 const float* A_save, const float* s_save, const int32_t* csc_ptr,
+                 const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
+                 float* dw);
+
+// LDS-window neighbour aggregation (mp_window.hip)
+bool aggregate_window_supported(int F, int E);
+int aggregate_window(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* src,
+                     const int32_t* nlist, const float* e, float* A);
+int aggregate_window_csc(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* src,
+                         const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, float* B);
 }  // namespace ng

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void aggregate_kernel(int64_t N, int K, int F,
   const int apb = 256 / c4n;  // atoms per block
   int32_t* s_nl = reinterpret_cast<int32_t*>(smem_raw);          // [apb*K]
   float* s_e = reinterpret_cast<float*>(smem_raw) + apb * K;     // [apb*K*E]
-  const int64_t i0 = (int64_t)blockIdx.x * apb;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed; used for speed only), so give every
+  // XCD a CONTIGUOUS eighth of the atoms — the tiles of one molecule then share one L2, and a gathered
+  // row misses once instead of once per XCD (L2 hit rate 46 % -> 90 %+ on the bench batch)
+  const int64_t i0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb;
   const int64_t n_at = std::min<int64_t>(apb, N - i0);
   for (int t = threadIdx.x; t < n_at * K; t += 256) s_nl[t] = nlist[i0 * K + t];
   for (int t = threadIdx.x; t < n_at * K * E; t += 256) s_e[t] = e[i0 * K * E + t];
@@ -114,13 +117,24 @@ __global__ __launch_bounds__(256) void aggregate_kernel(int64_t N, int K, int F,
 #pragma unroll
   for (int n = 0; n < E; ++n) acc[n] = f4zero();
   const float4* h4 = reinterpret_cast<const float4*>(h);
-  for (int j = 0; j < K; ++j) {
-    const int idx = s_nl[a * K + j];
-    const float4 hv = h4[(int64_t)idx * c4n + c4];
+  // 8 row gathers in flight per lane before the first is consumed (the kernel is latency-bound)
+  for (int j0 = 0; j0 < K; j0 += 8) {
+    float4 hv[8];
 #pragma unroll
-    for (int n = 0; n < E; ++n) {
-      const float ev = s_e[(a * K + j) * E + n];
-      acc[n].x += ev * hv.x; acc[n].y += ev * hv.y; acc[n].z += ev * hv.z; acc[n].w += ev * hv.w;
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u < K ? j0 + u : K - 1;
+      hv[u] = h4[(int64_t)s_nl[a * K + j] * c4n + c4];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u < K) {
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+          const float ev = s_e[(a * K + j0 + u) * E + n];
+          acc[n].x += ev * hv[u].x; acc[n].y += ev * hv[u].y;
+          acc[n].z += ev * hv[u].z; acc[n].w += ev * hv[u].w;
+        }
+      }
     }
   }
   float4* A4 = reinterpret_cast<float4*>(A);
@@ -134,6 +148,14 @@ static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
              "aggregate: F in {16,32,64,128,256,512,1024}");
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "aggregate: edge_feature_size <= 8");
   if (N == 0) return NG_OK;
+  {
+    // NG_AGG_PATH=window selects the LDS-window kernel of mp_window.hip.  Measured at the bench shape it
+    // LOSES to the XCD-aware global-gather kernel below (87 us vs 36 us): with the tiles of a molecule on
+    // one XCD the gathered rows are L2 hits anyway, and the high-occupancy kernel hides their latency.
+    const char* v = getenv("NG_AGG_PATH");
+    if (v && std::string(v) == "window" && aggregate_window_supported(F, E))
+      return aggregate_window(ctx, st, N, K, F, E, h, nlist, e, A);
+  }
   ProfScope ps(ctx, st, "mp_aggregate");
   const int apb = 256 / (F / 4);
   const size_t lds = (size_t)apb * K * (1 + E) * 4;
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(int64_t N, int K, int F,
   const int c4n = F / 4;  // power of two, <= 64: an atom's lanes sit inside one wave
   const int apb = 256 / c4n;
   const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
-  const int64_t i = (int64_t)blockIdx.x * apb + a;
+  const int64_t i = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;   // XCD-aware (see aggregate_kernel)
   const bool live = i < N;
   const int64_t ii = live ? i : 0;
   const float4* dA4 = reinterpret_cast<const float4*>(dA);
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(256) void scatter_pull_kernel(int64_t N, int K, int
   const int c4n = F / 4;
   const int apb = 256 / c4n;
   const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
-  const int64_t t = (int64_t)blockIdx.x * apb + a;
+  const int64_t t = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;   // XCD-aware (see aggregate_kernel)
   if (t >= N) return;
   const float4* dA4 = reinterpret_cast<const float4*>(dA);
   float4 acc = reinterpret_cast<const float4*>(dh_out)[t * c4n + c4];
@@ -535,6 +557,10 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   if (!ctx) return NG_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, (E * F) % 8 == 0, "mp_layer: (E*F) % 8");
+  // F == 64: NG_MP_PATH = split (default) | fused | layered  — see mp_split.hip for the comparison
+  if (N > 0 && mp_split_enabled(F, E))
+    return mp_split_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, A_save,
+                        s_save);
   if (N > 0 && mp_fused_enabled(F, E))
     return mp_fused_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, A_save,
                         s_save);
@@ -568,6 +594,9 @@ extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
              "mp_layer_bwd: F in {16,32,64,128,256}");
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "mp_layer_bwd: edge_feature_size <= 8");
+  if (N > 0 && mp_split_enabled(F, E))
+    return mp_split_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
+                        csc_edge, dh_out, dh_in, de, de_accum, dw);
   if (N > 0 && mp_fused_enabled(F, E))
     return mp_fused_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
                         csc_edge, dh_out, dh_in, de, de_accum, dw);
