@@ -285,6 +285,12 @@ extern "C" int ng_dense_bwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int N
     int rc = ng::dense_dx(ctx, st, M, Kin, Nout, act, dY, S, nullptr, W, residual ? dY : nullptr, dX);
     if (rc) return rc;
   }
+  if (M > 0 && ng::tall_tn_supported(Kin, Nout)) {   // 64-feature model: persistent register accumulators
+    float* scr = (float*)ng::workspace(ctx, ng::tall_tn_scratch_floats(ctx, Kin) * sizeof(float));
+    if (!scr) return NG_ERR_NOMEM;
+    return ng::tall_tn(ctx, st, M, X, Kin, Kin, dY, Nout, Nout, act == NG_ACT_NONE ? nullptr : S, act, dW,
+                       db, 0, 0, 0, scr, "dense_dw");
+  }
   float* scratch = (float*)ng::workspace(
       ctx, ng::dense_dw_scratch_floats(ctx, M, Kin, Nout, db != nullptr) * sizeof(float));
   if (!scratch) return NG_ERR_NOMEM;

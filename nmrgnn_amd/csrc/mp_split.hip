@@ -172,6 +172,141 @@ __global__ __launch_bounds__(256) void split_edge_grad_kernel(int64_t N, int K,
   }
 }
 
+// ---- second-generation gather kernels ----------------------------------------------------------------
+// B[t][n][:] over incoming edges, with the block's edge ids and edge features staged in LDS first:
+// the ids are read coalesced, the dependent e[eid] gathers happen once up front (all in flight
+// together) instead of sitting in the inner loop behind every row gather.
+constexpr int CSC_CAP = 1024;   // staged incoming edges per 16-atom block (falls back to global beyond)
+
+template <int E>
+__global__ __launch_bounds__(256) void split_agg_csc2_kernel(int64_t N, int K,
+                                                             const float* __restrict__ src,
+                                                             const int32_t* __restrict__ ptr,
+                                                             const int32_t* __restrict__ eids,
+                                                             const float* __restrict__ e,
+                                                             float* __restrict__ B) {
+  __shared__ int s_src[CSC_CAP];
+  __shared__ float s_e[CSC_CAP * E];
+  const int a = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int64_t t0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * SAPB;
+  const int64_t t1 = std::min<int64_t>(t0 + SAPB, N);
+  const int p_lo = ptr[t0], p_hi = ptr[t1];
+  const int cnt = p_hi - p_lo;
+  const bool staged = cnt <= CSC_CAP;
+  if (staged) {
+    for (int q = threadIdx.x; q < cnt; q += 256) {
+      const int eid = eids[p_lo + q];
+      s_src[q] = eid / K;
+#pragma unroll
+      for (int n = 0; n < E; ++n) s_e[q * E + n] = e[(int64_t)eid * E + n];
+    }
+  }
+  __syncthreads();
+  const int64_t t = t0 + a;
+  if (t >= N) return;
+  float4 acc[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) acc[n] = f4zero();
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  const int p0 = ptr[t], p1 = ptr[t + 1];
+  for (int q0 = p0; q0 < p1; q0 += 8) {
+    int row[8];
+    float ev[8][E];
+    float4 hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u < p1 ? q0 + u : p1 - 1;
+      if (staged) {
+        row[u] = s_src[q - p_lo];
+#pragma unroll
+        for (int n = 0; n < E; ++n) ev[u][n] = s_e[(q - p_lo) * E + n];
+      } else {
+        const int eid = eids[q];
+        row[u] = eid / K;
+#pragma unroll
+        for (int n = 0; n < E; ++n) ev[u][n] = e[(int64_t)eid * E + n];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) hv[u] = s4[(int64_t)row[u] * SC4 + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (q0 + u < p1) {
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+          acc[n].x += ev[u][n] * hv[u].x; acc[n].y += ev[u][n] * hv[u].y;
+          acc[n].z += ev[u][n] * hv[u].z; acc[n].w += ev[u][n] * hv[u].w;
+        }
+      }
+    }
+  }
+  float4* B4 = reinterpret_cast<float4*>(B);
+#pragma unroll
+  for (int n = 0; n < E; ++n) B4[(t * E + n) * SC4 + c] = acc[n];
+}
+
+// de[i][j][n] (+)= <dA[i][n][:], h[nlist[i][j]][:]> with FOUR lanes per atom (16 features each,
+// interleaved in 16-B units so that the 4 lanes of an atom read 64 contiguous bytes per load): the
+// cross-lane reduction shrinks from 4 ds_bpermute stages to 2 quad-permute DPP adds per value.
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void split_edge_grad2_kernel(int64_t N, int K,
+                                                               const float* __restrict__ h,
+                                                               const int32_t* __restrict__ nlist,
+                                                               const float* __restrict__ dA,
+                                                               float* __restrict__ de, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float s_de[];   // [64][K*E]
+  constexpr int APB = 64;
+  const int a = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const int64_t i0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * APB;
+  const int64_t i = i0 + a;
+  const bool live = i < N;
+  const int64_t ii = live ? i : 0;
+  const int KE = K * E;
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  // lane c owns float4 columns c, c+4, c+8, c+12 of the 16 in a row
+  float4 g[E][4];
+#pragma unroll
+  for (int n = 0; n < E; ++n)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[n][u] = dA4[(ii * E + n) * SC4 + c + 4 * u];
+  for (int j0 = 0; j0 < K; j0 += 4) {
+    float4 hv[4][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = j0 + jj < K ? j0 + jj : K - 1;
+      const int64_t row = nlist[ii * K + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hv[jj][u] = h4[row * SC4 + c + 4 * u];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+      for (int n = 0; n < E; ++n) {
+        float p = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          p += g[n][u].x * hv[jj][u].x + g[n][u].y * hv[jj][u].y + g[n][u].z * hv[jj][u].z +
+               g[n][u].w * hv[jj][u].w;
+        p = quad_sum(p);
+        if (c == 0 && j0 + jj < K) s_de[a * KE + (j0 + jj) * E + n] = p;
+      }
+    }
+  }
+  __syncthreads();
+  const int n_at = (int)std::min<int64_t>(APB, N - i0);
+  for (int t = threadIdx.x; t < n_at * KE; t += 256) {
+    const int64_t o = i0 * KE + t;
+    de[o] = accumulate ? de[o] + s_de[t] : s_de[t];
+  }
+}
+
 #define NG_E_SWITCH(E, CALL)  \
   switch (E) {                \
     case 1: { CALL(1) } break; \
@@ -210,7 +345,7 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
                  const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
                  float* dw) {
   const int KF = E * SF;
-  const size_t dw_scr = dense_dw_scratch_floats(ctx, N, KF, SF, false);
+  const size_t dw_scr = tall_tn_scratch_floats(ctx, KF);
   // scratch: two packed weight copies | dP [N,64] | dA / B [N,KF] (shared) | dw partials
   float* ws = (float*)workspace(ctx, (size_t)(2 * KF * SF + N * SF + N * KF + dw_scr) * 4);
   if (!ws) return NG_ERR_NOMEM;
@@ -233,24 +368,24 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
   }
   if (N > 0) {
     ProfScope ps(ctx, st, "mp_edge_grad");
-    const dim3 grid((unsigned)cdiv(N, SAPB));
-    const size_t lds = (size_t)SAPB * K * E * 4;
-#define CALL(EE)                                                                                     \
-  hipLaunchKernelGGL((split_edge_grad_kernel<EE>), grid, dim3(256), lds, st, N, K, h, nlist, dAB, de, \
+    const dim3 grid((unsigned)cdiv(N, 64));
+    const size_t lds = (size_t)64 * K * E * 4;
+#define CALL(EE)                                                                                      \
+  hipLaunchKernelGGL((split_edge_grad2_kernel<EE>), grid, dim3(256), lds, st, N, K, h, nlist, dAB, de, \
                      de_accum);
     NG_E_SWITCH(E, CALL)
 #undef CALL
     NG_HIP(ctx, hipGetLastError());
   }
   // dw[l][m][n] = sum_i A[i][(n,l)] dP[i][m]
-  rc = dense_dw(ctx, st, N, KF, SF, NG_ACT_NONE, A_save, dP, nullptr, nullptr, dw, nullptr, 1, SF, E, scr,
-                "mp_dw");
+  rc = tall_tn(ctx, st, N, A_save, KF, KF, dP, SF, SF, nullptr, NG_ACT_NONE, dw, nullptr, 1, SF, E, scr,
+               "mp_dw");
   if (rc) return rc;
   if (N > 0) {   // B = aggregation of dP over the incoming edges
     ProfScope ps(ctx, st, "mp_aggregate_csc");
     const dim3 grid((unsigned)cdiv(N, SAPB));
 #define CALL(EE)                                                                                       \
-  hipLaunchKernelGGL((split_agg_csc_kernel<EE>), grid, dim3(256), 0, st, N, K, dP, csc_ptr, csc_edge, e, \
+  hipLaunchKernelGGL((split_agg_csc2_kernel<EE>), grid, dim3(256), 0, st, N, K, dP, csc_ptr, csc_edge, e, \
                      dAB);
     NG_E_SWITCH(E, CALL)
 #undef CALL

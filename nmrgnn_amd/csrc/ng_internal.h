@@ -69,6 +69,13 @@ int tall_pack(ng_ctx* ctx, hipStream_t st, int k_in, int n_out, int kpad, int np
 int tall_gemm(ng_ctx* ctx, hipStream_t st, int kpad, int npad, const TallArgs& a, bool prologue,
               const char* tag);
 
+// persistent transposed product for weight gradients (tall_tn.hip): dW[ka][kb] = sum_rows A[row][ka] Bp[row][kb]
+bool tall_tn_supported(int ka, int kb);
+size_t tall_tn_scratch_floats(ng_ctx* ctx, int ka_valid);
+int tall_tn(ng_ctx* ctx, hipStream_t st, int64_t N, const float* A, int lda, int ka_valid, const float* B,
+            int ldb, int kb_valid, const float* S_in, int act_in, float* dW, float* db, int w_map, int F,
+            int E, float* scratch, const char* tag);
+
 // split MPLayer path for atom_feature_size == 64 (mp_split.hip): XCD-aware gather kernels + tall GEMMs
 bool mp_split_enabled(int F, int E);
 int mp_split_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,

@@ -13,13 +13,14 @@ namespace ng {
 //   w_map = 0: identity;  w_map = 1: MPLayer weight, idx = k*Nout + m with k = ne*F + l -> (l*F+m)*E+ne
 static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __restrict__ partial, int nz,
                                                         int64_t n_elem, float* __restrict__ out,
-                                                        int w_map, int F, int E, int Nout) {
+                                                        int w_map, int F, int E, int Nout,
+                                                        int64_t z_stride) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
   float s = 0.f;
   if (idx < n_elem)
-    for (int z = w; z < nz; z += 16) s += partial[(int64_t)z * n_elem + idx];
+    for (int z = w; z < nz; z += 16) s += partial[(int64_t)z * z_stride + idx];
   red[w][lane] = s;
   __syncthreads();
   if (w == 0 && idx < n_elem) {
@@ -37,9 +38,9 @@ static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __re
 }
 
 static inline void launch_reduce_z(hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out,
-                            int w_map = 0, int F = 0, int E = 0, int Nout = 1) {
+                            int w_map = 0, int F = 0, int E = 0, int Nout = 1, int64_t z_stride = 0) {
   hipLaunchKernelGGL(reduce_z_kernel, dim3((unsigned)cdiv(n_elem, 64)), dim3(1024), 0, st, partial,
-                     nz, n_elem, out, w_map, F, E, Nout);
+                     nz, n_elem, out, w_map, F, E, Nout, z_stride ? z_stride : n_elem);
 }
 
 // partial[blk][a*B + b] = sum_{rows of blk} X(row, a) * Y(row, b)      (A <= 32, any B)
