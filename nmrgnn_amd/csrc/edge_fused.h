@@ -38,3 +38,10 @@ int edge_fused_bwd2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, 
                            const float* Wo, const float* z_save, const float* de, float* partial,
                            int part_stride, int grid);
 }  // namespace ng
+
+namespace ng {
+// 32-edge-tile forward variant (edge_fused_fwd32.hip)
+int edge_fused_fwd32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
+                     const float* d_eff, const float* centers, float gap, const float* const* W,
+                     const float* const* b, float* e_out, float* z_save);
+}  // namespace ng
