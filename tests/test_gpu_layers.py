@@ -1,0 +1,90 @@
+"""Layer classes of the drop-in surface on the GPU: the reference's own shape tests
+(reference tests/test_nmrgnn.py:18-108) plus the analytic KATs of SURVEY App. C through the HIP path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_hp
+
+pytestmark = pytest.mark.gpu
+
+
+def ring(F=16, E=2):
+    nodes = np.eye(F, dtype=np.float32)[[2, 4, 0, 1, 3]]
+    nlist = np.zeros((5, 2), dtype=np.int64)
+    for i in range(5):
+        for k, j in enumerate(range(-1, 3, 2)):
+            nlist[i, k] = (i + j) % 5
+    return nodes, nlist, np.ones((5, 2, E), np.float32), (np.ones(5) / 2)
+
+
+def test_mplayer_kats(gpu_device):
+    import torch
+    import nmrgnn_amd
+    nodes, nlist, edges, inv = ring()
+    mpl = nmrgnn_amd.MPLayer()                      # activation=None, like the reference default
+    out = mpl([nodes, nlist, edges, inv])
+    assert tuple(out.shape) == nodes.shape          # reference assertion (tests:34)
+    mpl.w = torch.ones(16, 16, 2, device=gpu_device)
+    np.testing.assert_allclose(mpl([nodes, nlist, edges, inv]).cpu().numpy(), 2.0, rtol=1e-6)   # KAT-1
+    l, m, n = np.meshgrid(np.arange(16), np.arange(16), np.arange(2), indexing="ij")
+    mpl.w = torch.tensor(((l + 1) * (m + 1) * (n + 1) / 100.0).astype(np.float32), device=gpu_device)
+    out = mpl([nodes, nlist, edges, inv]).cpu().numpy()
+    np.testing.assert_allclose(out[0], 0.135 * (np.arange(16) + 1), rtol=1e-5)                  # KAT-2
+
+
+def test_rbf_kat5(gpu_device):
+    import nmrgnn_amd
+    from oracle import nmrgnn_oracle as O
+    rbf = nmrgnn_amd.RBFExpansion(0.005, 0.20, 128)
+    centers, gap = O.rbf_centers(0.005, 0.20, 128)
+    d = np.array([[centers[17], centers[40] + np.sqrt(gap)]], np.float32)
+    out = rbf(d).cpu().numpy()
+    assert out.shape == (1, 2, 128)
+    assert out[0, 0, 17] == pytest.approx(1.0, abs=1e-6)
+    assert out[0, 1, 40] == pytest.approx(np.exp(-1.0), rel=1e-4)
+    np.testing.assert_allclose(out, O.rbf_expand(d, centers, gap), atol=2e-6)
+
+
+def test_block_shapes_like_reference_tests(gpu_device):
+    import nmrgnn_amd
+    hp = nmrgnn_amd.build_GNNModel().hypers
+    e = nmrgnn_amd.EdgeFCBlock(hp)(np.ones((5, 2, 2), np.float32))            # tests:66-73
+    assert e.shape[-1] == hp.get('edge_feature_size') and tuple(e.shape[:-1]) == (5, 2)
+    nodes, nlist, edges, inv = ring(F=16, E=2)
+    out = nmrgnn_amd.MPBlock(hp)([nodes, nlist, edges, inv])                   # tests:78-96
+    assert tuple(out.shape) == nodes.shape
+    x = np.ones((5, hp.get('atom_feature_size')), np.float32)
+    y = nmrgnn_amd.FCBlock(hp)(x)                                              # tests:101-108
+    assert y.shape[-1] == hp.get('atom_feature_size') // 2
+
+
+def test_gnnmodel_call_like_reference_test(gpu_device):
+    import nmrgnn_amd
+    nodes = np.eye(16, dtype=np.float32)[[2, 4, 1, 3, 3]]                       # tests:198
+    _, nlist, _, inv = ring()
+    model = nmrgnn_amd.build_GNNModel()
+    out = model([nodes, nlist, np.ones((5, 2), np.float32), inv])
+    assert out.shape == (5,)
+    assert model([nodes, nlist, np.ones((5, 2), np.float32), inv]).shape == (5,)   # tests:222-223
+
+
+@pytest.mark.parametrize("F,E", [(64, 3), (32, 2), (256, 3), (128, 8)])
+def test_aggregate_abi_matches_numpy(gpu_device, F, E):
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    rng = np.random.default_rng(0)
+    N, K = 301, 16
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    nl = rng.integers(0, N, (N, K)).astype(np.int32)
+    e = rng.standard_normal((N, K, E)).astype(np.float32)
+    ref = np.einsum("ijn,ijl->inl", e.astype(np.float64), h.astype(np.float64)[nl])
+    ctx = _lib.get_context(0)
+    dev = gpu_device
+    th, tn, te = (torch.from_numpy(x).to(dev) for x in (h, nl, e))
+    A = torch.empty(N, E, F, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.check(ctx.lib.ng_mp_aggregate(ctx.handle, st, N, K, F, E, ptr(th), ptr(tn), ptr(te), ptr(A)), "agg")
+    np.testing.assert_allclose(A.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)

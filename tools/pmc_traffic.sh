@@ -1,0 +1,35 @@
+#!/bin/bash
+# HBM traffic per launch of every kernel of the bench step (rocprofv3 PMC, separate passes as the
+# MI355X guide prescribes).  Writes gpurun_out/pmc_traffic.json — copy it to profiles/.
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for C in FETCH_SIZE WRITE_SIZE; do
+  OUT=gpurun_out/pmc_${C}; rm -rf "$OUT"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT" -o t -- \
+      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/pmc_${C}.log 2>&1
+done
+python - <<'PY'
+import csv, glob, json, collections
+res = collections.defaultdict(dict)
+names = {"edge_fused_bwd_kernel": "edge_fused_bwd", "edge_fused_bwd2_kernel": "edge_fused_bwd",
+         "edge_fused_fwd_kernel": "edge_fused_fwd", "split_agg_kernel": "mp_aggregate",
+         "split_agg_csc2_kernel": "mp_aggregate_csc", "split_edge_grad2_kernel": "mp_edge_grad",
+         "tall_tn_kernel<192": "mp_dw", "tall_gemm_kernel<192, 64, false>": "mp_update_fwd|mp_dh",
+         "tall_gemm_kernel<64, 192, true>": "mp_dA"}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"gpurun_out/pmc_{C}/**/*counter_collection.csv", recursive=True)
+    if not f:
+        continue
+    tot = collections.defaultdict(float); cnt = collections.Counter(); seen = set()
+    for row in csv.DictReader(open(f[0])):
+        k = row["Kernel_Name"]
+        tot[k] += float(row["Counter_Value"])
+        if (k, row["Dispatch_Id"]) not in seen:
+            seen.add((k, row["Dispatch_Id"])); cnt[k] += 1
+    for k in tot:
+        for pat, short in names.items():
+            if pat in k:
+                for s in short.split("|"):
+                    res[s][C + "_KB"] = tot[k] / cnt[k]
+json.dump(res, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
