@@ -142,6 +142,12 @@ int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
 int ng_loss_l2(ng_ctx*, void* stream, int64_t N, int G, const int32_t* graph_ptr, const float* y,
                const float* w, const float* pred, float* loss_out, float* dpred);
 
+/* NameLoss with balance s in [0,1], nmrgnn/losses.py:4-15,30-39, batched over graphs:
+ *   loss = mean_g [ s*l2_g + (1-s)*(1 - r_g) ],  r = cov/(m*sqrt(clip(var_x*var_y,0,1e32))) with the
+ *   weighted moments of corr_coeff (divide_no_nan); s = 1 equals ng_loss_l2.  dpred as above. */
+int ng_loss_name(ng_ctx*, void* stream, int64_t N, int G, const int32_t* graph_ptr, const float* y,
+                 const float* w, const float* pred, float s, float* loss_out, float* dpred);
+
 /* Keras Adam (nmrgnn/model.py:44-45): one fused pass over the flat parameter buffer.
  *   g is first multiplied by grad_scale (1/world_size after a summing all-reduce). */
 int ng_adam_step(ng_ctx*, void* stream, int64_t n, float* p, const float* g, float* m, float* v,

@@ -377,6 +377,60 @@ __global__ __launch_bounds__(256) void loss_graph_kernel(int G, const int32_t* _
   for (int i = a + lane; i < b; i += 64) dpred[i] = sc * w[i] * (y[i] - pred[i]);
 }
 
+// general NameLoss (losses.py:4-15,30-39): per graph  s*l2 + (1-s)*(1-r), r = weighted Pearson
+// correlation in the reference's moment form; the handful of per-graph sums is kept in double so
+// the xm2 - xm^2 cancellation does not eat the fp32 mantissa.  One wave per graph, three passes.
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void loss_name_kernel(int G, const int32_t* __restrict__ gptr,
+                                                        const float* __restrict__ y,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ pred, float s,
+                                                        float* __restrict__ per_graph,
+                                                        float* __restrict__ dpred) {
+  const int lane = threadIdx.x & 63;
+  const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gidx >= G) return;
+  const int a = gptr[gidx], b = gptr[gidx + 1];
+  double m = 0, sx = 0, sy = 0, sxx = 0, syy = 0, sl = 0;
+  for (int i = a + lane; i < b; i += 64) {
+    const double wi = w[i], xi = pred[i], yi = y[i], d = yi - xi;
+    m += wi; sx += wi * xi; sy += wi * yi; sxx += wi * xi * xi; syy += wi * yi * yi; sl += wi * d * d;
+  }
+  m = wave_sum_d(m); sx = wave_sum_d(sx); sy = wave_sum_d(sy);
+  sxx = wave_sum_d(sxx); syy = wave_sum_d(syy); sl = wave_sum_d(sl);
+  const double invm = m != 0 ? 1.0 / m : 0.0;
+  const double xm = sx * invm, ym = sy * invm;
+  const double vx = sxx * invm - xm * xm, vy = syy * invm - ym * ym;
+  double cov = 0, syc = 0;
+  for (int i = a + lane; i < b; i += 64) {
+    const double wi = w[i];
+    cov += wi * ((double)pred[i] - xm) * ((double)y[i] - ym);
+    syc += wi * ((double)y[i] - ym);
+  }
+  cov = wave_sum_d(cov); syc = wave_sum_d(syc);
+  const double prod = vx * vy;
+  const bool inside = prod >= 0.0 && prod <= 1e32;               // clip_by_value passes gradient here
+  const double root = sqrt(fmin(fmax(prod, 0.0), 1e32));
+  const double den = m * root;
+  const double r = den != 0 ? cov / den : 0.0;
+  const double l2 = sl * invm;
+  if (lane == 0) per_graph[gidx] = (float)(s * l2 + (1.0 - s) * (1.0 - r));
+  // d r / d x_i = w_i[(y_i - ym) - syc/m]/den - cov/den^2 * m * vy * w_i (x_i - xm) / (m root)
+  const double c1 = den != 0 ? 1.0 / den : 0.0;
+  const double c2 = (den != 0 && inside && root != 0) ? cov / (den * den) * vy / root : 0.0;
+  const double invG = 1.0 / (double)G;
+  for (int i = a + lane; i < b; i += 64) {
+    const double wi = w[i], xi = pred[i], yi = y[i];
+    const double dl2 = -2.0 * wi * (yi - xi) * invm;
+    const double dr = wi * ((yi - ym) - syc * invm) * c1 - c2 * wi * (xi - xm);
+    dpred[i] = (float)((s * dl2 - (1.0 - s) * dr) * invG);
+  }
+}
+
 __global__ __launch_bounds__(256) void loss_final_kernel(int G, const float* __restrict__ per_graph,
                                                          float* __restrict__ loss_out) {
   __shared__ float red[256];
@@ -708,6 +762,24 @@ extern "C" int ng_loss_l2(ng_ctx* ctx, void* stream, int64_t N, int G, const int
   ProfScope ps(ctx, st, "loss_l2");
   hipLaunchKernelGGL(loss_graph_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, G, graph_ptr,
                      y, w, pred, per_graph, dpred);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, G, per_graph, loss_out);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_loss_name(ng_ctx* ctx, void* stream, int64_t N, int G, const int32_t* graph_ptr,
+                            const float* y, const float* w, const float* pred, float s,
+                            float* loss_out, float* dpred) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, G >= 1, "loss: at least one graph");
+  NG_REQUIRE(ctx, s >= 0.f && s <= 1.f, "loss: balance s must lie in [0,1]");
+  (void)N;
+  float* per_graph = (float*)workspace(ctx, (size_t)G * 4);
+  if (!per_graph) return NG_ERR_NOMEM;
+  ProfScope ps(ctx, st, "loss_name");
+  hipLaunchKernelGGL(loss_name_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, G, graph_ptr,
+                     y, w, pred, s, per_graph, dpred);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, G, per_graph, loss_out);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;

@@ -238,6 +238,19 @@ class Engine:
                                      ptr(dpred)), "ng_loss_l2")
         return loss, dpred
 
+    def loss_name(self, batch, y, w, peaks, s=1.0):
+        """NameLoss with balance ``s`` (nmrgnn/losses.py:30-39): mean over graphs of
+        s*l2 + (1-s)*(1-r).  ``w`` is already the label-filtered weight column.
+        Returns (loss[1] device tensor, dloss/dpeaks[N])."""
+        if not 0.0 <= float(s) <= 1.0:
+            raise ValueError("NameLoss balance s must lie in [0, 1]")
+        loss = self._new(1)
+        dpred = self._new(batch.N)
+        self._ck(self.lib.ng_loss_name(self.ctx.handle, self._st(), batch.N, batch.G,
+                                       ptr(batch.graph_ptr), ptr(y), ptr(w), ptr(peaks), float(s),
+                                       ptr(loss), ptr(dpred)), "ng_loss_name")
+        return loss, dpred
+
     def adam_step(self, lr=None, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-7):
         if lr is None:
             lr = float(self.hp.get('learning_rate'))

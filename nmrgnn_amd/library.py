@@ -13,27 +13,57 @@ from .standards import load_standards
 from .structure import Structure, atoms_onehot, inv_degree_of, knn_graph, read_pdb
 
 
+def _bundle_prefix(path):
+    """SavedModel directory / variables directory / bundle prefix -> bundle prefix, or None."""
+    for cand in (os.path.join(path, "variables", "variables"), os.path.join(path, "variables"), path):
+        if os.path.isfile(cand + ".index"):
+            return cand
+    return None
+
+
+def _load_tf_bundle(prefix, device):
+    from .model import GNNModel
+    from .tfbundle import load_gnn_bundle
+    state, arch, num_elem = load_gnn_bundle(prefix)
+    hp = declare_gnn_space(HyperParameters(**arch))
+    model = GNNModel(hp, load_standards(), device=device)
+    model.set_weights(state)
+    model._num_elem_hint = num_elem
+    return model
+
+
 def load_model(model_file=None, device=None):
     """Load a chemical shift prediction model (nmrgnn/library.py:92-103).
 
-    ``model_file`` is a directory written by ``GNNModel.save`` (weights.npz + config.json).  With no
-    argument the reference loads its bundled pre-trained SavedModel; that bundle ships WITHOUT weight
-    values (the data shard is missing upstream), so the baseline ARCHITECTURE and peak
-    standards are restored and the weights are taken from $NMRGNN_AMD_BASELINE (a weights.npz) when
+    ``model_file`` is either a Keras SavedModel directory as the reference writes it (main.py:87-90:
+    the weights are read from ``variables/variables.{index,data-*}`` with the built-in bundle reader,
+    nmrgnn_amd/tfbundle.py; the architecture is inferred from the tensor shapes) or a directory
+    written by ``GNNModel.save`` (weights.npz + config.json).  With no argument the reference loads
+    its bundled pre-trained SavedModel; that bundle ships WITHOUT weight values (the data shard is
+    missing upstream), so the baseline ARCHITECTURE and peak standards are restored and
+    the weights are taken from $NMRGNN_AMD_BASELINE (a SavedModel directory or a weights.npz) when
     set, else seeded glorot — with a loud warning, because predictions are then meaningless."""
     from .model import GNNModel
     if model_file is None:
+        w = os.environ.get("NMRGNN_AMD_BASELINE")
+        if w and _bundle_prefix(w):
+            return _load_tf_bundle(_bundle_prefix(w), device)
         hp = declare_gnn_space(HyperParameters())
         model = GNNModel(hp, load_standards(), device=device)
-        w = os.environ.get("NMRGNN_AMD_BASELINE")
         if w:
             model.load_weights(w)
         else:
             warnings.warn("nmrgnn_amd.load_model(): the reference's bundled baseline has no weight "
                           "values (variables.data-00000-of-00001 is missing upstream); using seeded "
-                          "random weights. Set NMRGNN_AMD_BASELINE=/path/to/weights.npz.",
+                          "random weights. Set NMRGNN_AMD_BASELINE=/path/to/saved_model_dir (or weights.npz).",
                           RuntimeWarning, stacklevel=2)
         return model
+    if not os.path.exists(os.path.join(model_file, "config.json")):
+        prefix = _bundle_prefix(model_file)
+        if prefix is None:
+            raise ValueError(f"{model_file}: neither a SavedModel directory (variables/variables.index) "
+                             "nor a nmrgnn_amd model directory (config.json)")
+        return _load_tf_bundle(prefix, device)
     with open(os.path.join(model_file, "config.json")) as f:
         cfg = json.load(f)
     hp = declare_gnn_space(HyperParameters(**cfg["hypers"]))

@@ -107,8 +107,21 @@ class GNNModel:
                "peak_standards": {str(k): list(v) for k, v in self.peak_standards.items()}}
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(cfg, f, indent=1)
+        # the same weights as a TensorFlow checkpoint bundle under the reference's variable names
+        from .tfbundle import save_gnn_bundle
+        save_gnn_bundle(os.path.join(path, "variables", "variables"), self.engine.params.state_dict(),
+                        self.hypers)
 
     def load_weights(self, path):
+        """weights.npz (own format) or a TensorFlow checkpoint bundle / SavedModel directory."""
+        from .library import _bundle_prefix
+        if not path.endswith(".npz") and not os.path.exists(os.path.join(path, "weights.npz")):
+            prefix = _bundle_prefix(path)
+            if prefix is None:
+                raise ValueError(f"{path}: no weights.npz and no checkpoint bundle")
+            from .tfbundle import load_gnn_bundle
+            self.set_weights(load_gnn_bundle(prefix)[0])
+            return
         f = path if path.endswith(".npz") else os.path.join(path, "weights.npz")
         z = np.load(f)
         self.set_weights({k.replace(".", "/"): z[k] for k in z.files})

@@ -11,9 +11,10 @@ from .parallel import GradBuckets
 
 
 class Trainer:
-    def __init__(self, engine: Engine, lr=None):
+    def __init__(self, engine: Engine, lr=None, loss_balance=1.0):
         self.engine = engine
         self.lr = lr
+        self.loss_balance = float(loss_balance)      # NameLoss s (build_GNNModel's loss_balance)
         P = engine.params
         # edge-MLP parameters sit first in the flat buffer (params.param_shapes)
         first_node = next(k for k in P.offsets if not k.startswith("edge_fc/"))
@@ -26,7 +27,10 @@ class Trainer:
             seed = 0x9E3779B97F4A7C15 ^ (self.step_count * 1000003)
         seed &= (1 << 63) - 1
         peaks = eng.forward(batch, training=True, seed=seed)
-        loss, dpred = eng.loss_l2(batch, y, w, peaks)
+        if self.loss_balance == 1.0:
+            loss, dpred = eng.loss_l2(batch, y, w, peaks)
+        else:
+            loss, dpred = eng.loss_name(batch, y, w, peaks, self.loss_balance)
         eng.backward(dpred, on_node_grads=self.buckets.launch_node)
         self.buckets.launch_edge()
         self.buckets.wait()

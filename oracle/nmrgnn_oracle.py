@@ -328,6 +328,59 @@ def batch_loss_s1(y, w, pred, graph_ptr):
     return loss / G, grad / G
 
 
+def corr_coeff(x, y, w=None):
+    """losses.py:4-15 (weighted Pearson r in moment form, clipped variance product, divide_no_nan)."""
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+    w = np.ones_like(x) if w is None else np.asarray(w, np.float64)
+    m = np.sum(w)
+    if m == 0:
+        return 0.0
+    xm, ym = np.sum(w * x) / m, np.sum(w * y) / m
+    xm2, ym2 = np.sum(w * x ** 2) / m, np.sum(w * y ** 2) / m
+    cov = np.sum(w * (x - xm) * (y - ym))
+    den = m * np.sqrt(np.clip((xm2 - xm ** 2) * (ym2 - ym ** 2), 0, 1e32))
+    return cov / den if den != 0 else 0.0
+
+
+def batch_loss_name(y, w, pred, graph_ptr, s):
+    """Batched NameLoss with balance s (losses.py:30-39): mean over graphs of s*l2 + (1-s)*(1-r).
+    Returns (loss, dloss/dpred); the gradient is the analytic derivative of the formula as written
+    (moments xm, xm2 depend on pred; clip passes gradient inside [0,1e32]; divide_no_nan -> 0)."""
+    y = np.asarray(y, np.float64)
+    w = np.asarray(w, np.float64)
+    pred = np.asarray(pred, np.float64)
+    G = len(graph_ptr) - 1
+    loss = 0.0
+    grad = np.zeros_like(pred)
+    for g in range(G):
+        a, b = graph_ptr[g], graph_ptr[g + 1]
+        wi, x, yy = w[a:b], pred[a:b], y[a:b]
+        m = np.sum(wi)
+        if m == 0:
+            loss += (1 - s) * 1.0            # l2 = 0 and r = 0 (divide_no_nan)
+            continue
+        l2 = np.sum(wi * (yy - x) ** 2) / m
+        dl2 = -2.0 * wi * (yy - x) / m
+        xm, ym = np.sum(wi * x) / m, np.sum(wi * yy) / m
+        vx = np.sum(wi * x ** 2) / m - xm ** 2
+        vy = np.sum(wi * yy ** 2) / m - ym ** 2
+        cov = np.sum(wi * (x - xm) * (yy - ym))
+        prod = vx * vy
+        root = np.sqrt(np.clip(prod, 0, 1e32))
+        den = m * root
+        if den != 0:
+            r = cov / den
+            dcov = wi * ((yy - ym) - np.sum(wi * (yy - ym)) / m)
+            dden = vy * wi * (x - xm) / root if 0 <= prod <= 1e32 else 0.0
+            dr = dcov / den - cov / den ** 2 * dden
+        else:
+            r, dr = 0.0, 0.0
+        loss += s * l2 + (1 - s) * (1 - r)
+        grad[a:b] = s * dl2 - (1 - s) * dr
+    return loss / G, grad / G
+
+
 def adam_step(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
     """Keras (TF 2.3) Adam, non-amsgrad: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
     m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t m/(sqrt(v)+eps).

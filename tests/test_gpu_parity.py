@@ -251,3 +251,34 @@ def test_empty_and_tiny_graphs(gpu_device):
     empty = (np.zeros((0, 10), np.float32), np.zeros((0, 16), np.int32), np.zeros((0, 16), np.float32),
              np.zeros(0, np.float32))
     assert eng.forward(GraphBatch(*empty, device=gpu_device)).shape == (0,)
+
+
+@pytest.mark.parametrize("s", [0.0, 0.3, 1.0])
+def test_name_loss_balance_vs_oracle(gpu_device, s):
+    """ng_loss_name: s*l2 + (1-s)*(1-r) per graph (nmrgnn/losses.py:30-39) incl. an empty graph and a
+    graph with zero total weight; carbon-like shifts (120 +- 3) stress the moment cancellation."""
+    import torch
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from oracle import nmrgnn_oracle as O
+    hp = make_hp()
+    b = small_batch(4, 33, seed=2)
+    ptr = [0, 40, 40, 97, 132]
+    N = ptr[-1]
+    eng = Engine(hp, 10, device=gpu_device, seed=1)
+    gb = GraphBatch(b["atoms"][:N], b["nlist"][:N] % N, b["edges"][:N], b["inv_degree"][:N], graph_ptr=ptr,
+                    device=gpu_device)
+    rng = np.random.default_rng(5)
+    y = (rng.standard_normal(N) * 3 + 120).astype(np.float32)
+    pred = (y + rng.standard_normal(N)).astype(np.float32)
+    w = ((rng.random(N) > 0.3) * rng.random(N)).astype(np.float32)
+    w[97:] = 0.0
+    ty, tw, tp = (torch.from_numpy(x).to(gpu_device) for x in (y, w, pred))
+    loss, dpred = eng.loss_name(gb, ty, tw, tp, s)
+    ref_l, ref_g = O.batch_loss_name(y, w, pred, ptr, s)
+    assert loss.item() == pytest.approx(ref_l, rel=2e-6, abs=1e-7)
+    assert rel_err(dpred.cpu().numpy(), ref_g) < 1e-5
+    if s == 1.0:
+        l2, d2 = eng.loss_l2(gb, ty, tw, tp)
+        assert l2.item() == pytest.approx(loss.item(), rel=1e-6)
+        assert rel_err(d2.cpu().numpy(), dpred.cpu().numpy()) < 1e-6

@@ -99,6 +99,13 @@ def test_end_to_end_108M_and_trajectory(gpu_device, tmp_path):
     model.save(str(tmp_path / "m"))
     m2 = nmrgnn_amd.load_model(str(tmp_path / "m"))
     np.testing.assert_array_equal(np.asarray(m2(g)), np.asarray(peaks))
+    # the same directory read as a Keras SavedModel: only variables/variables.{index,data-*} (TF bundle)
+    import os
+    os.remove(tmp_path / "m" / "config.json")
+    os.remove(tmp_path / "m" / "weights.npz")
+    m3 = nmrgnn_amd.load_model(str(tmp_path / "m"))
+    assert m3.hypers.get('atom_feature_size') == 256
+    np.testing.assert_array_equal(np.asarray(m3(g)), np.asarray(peaks))
     # trajectory: frames differ
     s = read_pdb(PDB2)
     first = None
@@ -107,3 +114,44 @@ def test_end_to_end_108M_and_trajectory(gpu_device, tmp_path):
         assert pk.shape == (2770,)
         first = pk if first is None else first
     assert np.mean((pk - first) ** 2) > 0
+
+
+def test_eval_struct_requires_a_structure():
+    from nmrgnn_amd.main import eval_structure
+    with pytest.raises(ValueError, match="at least"):          # nmrgnn/main.py:201-202
+        eval_structure((), "out.csv")
+
+
+def test_eval_struct_cli_surface():
+    from click.testing import CliRunner
+    from nmrgnn_amd.main import main
+    res = CliRunner().invoke(main, ["eval-struct", "--help"])
+    assert res.exit_code == 0
+    for opt in ("--model-file", "--neighbor-number", "--stride", "STRUCT_FILES", "OUTPUT_CSV"):
+        assert opt in res.output
+
+
+@pytest.mark.gpu
+def test_eval_struct_trajectory_csv(gpu_device, tmp_path):
+    """config #5 driver: 10-model trajectory, stride 3, batched frames == frame-by-frame predictions."""
+    import csv
+    import nmrgnn_amd
+    from nmrgnn_amd.main import eval_structure
+    from nmrgnn_amd.structure import read_pdb
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        timing = eval_structure((PDB2,), str(tmp_path / "o.csv"), stride=3, frames_per_batch=3,
+                                keep_going=True, echo=lambda *_: None)
+        model = nmrgnn_amd.load_model()
+    assert set(timing) == {'Structure', 'Model Inference (MI355X)', 'Parsing'}
+    with open(tmp_path / "o.csv") as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == ['index', 'residues', 'resids', 'names', 'peaks', 'confident', 'time', 'frame']
+    assert len(rows) == 1 + 4 * 2770                              # frames 0,3,6,9
+    assert [r[7] for r in rows[1::2770]] == ['0', '3', '6', '9']
+    s = read_pdb(PDB2)
+    s.frame = 9
+    ref = np.round(np.asarray(model(nmrgnn_amd.universe2graph(s))).astype(np.float64), 2)
+    got = np.array([float(r[4]) for r in rows[1 + 3 * 2770:]])
+    assert np.max(np.abs(got - ref)) <= 0.011                     # rounding boundary only
+    assert rows[1][1] == s.resnames[0] and rows[1][3] == s.names[0]

@@ -208,3 +208,45 @@ def test_inv_degree_quirk_and_check_peaks():
     np.testing.assert_array_equal(conf, [True, True, False, True])
     with pytest.raises(Warning):
         O.check_peaks(atoms, np.array([900.0, 500.0, 30.0, 120.0]), std)
+
+
+def test_name_loss_balance_matches_reference_formula_autograd():
+    """batch_loss_name (analytic gradient) vs torch autograd on the formula as written in
+    nmrgnn/losses.py:4-15,30-39, incl. a graph with zero total weight and s in {0, 0.3, 1}."""
+    import torch
+    from oracle import nmrgnn_oracle as O
+    rng = np.random.default_rng(5)
+    ptr = [0, 40, 40, 97, 130]                                  # one empty graph
+    N = ptr[-1]
+    y = rng.standard_normal(N) * 3 + 120
+    pred = y + rng.standard_normal(N)
+    w = (rng.random(N) > 0.3) * rng.random(N)
+    w[97:] = 0.0                                                # last graph: sum w = 0
+    for s in (0.0, 0.3, 1.0):
+        loss, grad = O.batch_loss_name(y, w, pred, ptr, s)
+        x = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+        ty, tw = torch.tensor(y), torch.tensor(w)
+        tot = 0.0
+        for g in range(len(ptr) - 1):
+            a, b = ptr[g], ptr[g + 1]
+            xx, yy, ww = x[a:b], ty[a:b], tw[a:b]
+            m = ww.sum()
+            if m == 0:                                         # divide_no_nan: l2 = 0, r = 0
+                tot = tot + (1 - s) * 1.0
+                continue
+            l2 = (ww * (yy - xx) ** 2).sum() / m
+            xm, ym = (ww * xx).sum() / m, (ww * yy).sum() / m
+            xm2, ym2 = (ww * xx ** 2).sum() / m, (ww * yy ** 2).sum() / m
+            cov = (ww * (xx - xm) * (yy - ym)).sum()
+            r = cov / (m * torch.sqrt(torch.clamp((xm2 - xm ** 2) * (ym2 - ym ** 2), 0, 1e32)))
+            tot = tot + s * l2 + (1 - s) * (1 - r)
+        tot = tot / (len(ptr) - 1)
+        tot.backward()
+        assert loss == pytest.approx(tot.item(), rel=1e-12)
+        np.testing.assert_allclose(grad, x.grad.numpy(), rtol=1e-9, atol=1e-14)
+    l1, g1 = O.batch_loss_name(y, w, pred, ptr, 1.0)
+    l0, g0 = O.batch_loss_s1(y, w, pred, ptr)
+    assert l1 == pytest.approx(l0) and np.allclose(g1, g0)
+    from nmrgnn_amd.losses import NameLoss
+    single = NameLoss(label_idx=None, s=0.3)(np.stack([y[:40], np.zeros(40), w[:40]], 1), pred[:40])
+    assert single == pytest.approx(O.batch_loss_name(y[:40], w[:40], pred[:40], [0, 40], 0.3)[0])
