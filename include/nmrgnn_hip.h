@@ -117,6 +117,14 @@ int ng_mp_layer_bwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int a
                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out,
                     float* dh_in, float* de, int de_accum, float* dw);
 
+/* AMPLayer attention aggregation, nmrgnn/layers.py:89-96 (forward only; the layer is exported by the
+ * reference package but not used by its model):
+ *   b[i,:] = softmax_j( inv[i] * <e[i,j,:] @ wk, h[i,:] @ wq> ),  agg[i,:] = sum_j b[i,j] * h[nlist[i,j],:]
+ * The layer output is act(agg @ wv) = ng_dense_fwd(agg, wv, bias 0).  K <= 64, E <= 64. */
+int ng_amp_attend(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const float* h,
+                  const int32_t* nlist, const float* e, const float* inv_degree, const float* wq,
+                  const float* wk, float* agg);
+
 /* keras Dense (+ residual), nmrgnn/model.py:191-196:  Y = act(X@W + b) (+ X if residual)
  *   s_save [M,Nout] = act(X@W+b) written when non-NULL */
 int ng_dense_fwd(ng_ctx*, void* stream, int64_t M, int Kin, int Nout, int act, int residual,

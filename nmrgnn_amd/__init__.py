@@ -12,7 +12,7 @@ from .hypers import HyperParameters, declare_gnn_space  # noqa: F401
 
 _LAZY = {
     "Engine": "engine", "GraphBatch": "graph", "concat_graphs": "graph",
-    "MPLayer": "layers", "RBFExpansion": "layers", "EdgeFCBlock": "layers", "MPBlock": "layers",
+    "MPLayer": "layers", "AMPLayer": "layers", "RBFExpansion": "layers", "EdgeFCBlock": "layers", "MPBlock": "layers",
     "FCBlock": "layers", "GNNModel": "model", "build_GNNModel": "model",
     "load_model": "library", "universe2graph": "library", "check_peaks": "library",
     "save_model": "library", "NameLoss": "losses", "Trainer": "train",

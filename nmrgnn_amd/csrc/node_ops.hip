@@ -349,6 +349,64 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(int64_t N, int Fh, int
   }
 }
 
+// ------------------------------------------------------------------------------------ AMPLayer
+// nmrgnn/layers.py:81-100 (attention variant, forward only — the reference model never uses it):
+//   q_i = h_i wq ; key_ij = e_ij wk ; qdot_ij = v_i <key_ij, q_i> ; b_i: = softmax_j(qdot_i:)
+//   out_i = act( (sum_j b_ij h[nl_ij]) wv )            (values = h[nl] wv, sum pulled in front)
+// One wave per atom: q and u = wk q by wave reductions, qdot on lanes j < K, softmax by DPP/shuffle,
+// then the weighted gather.  The F x F product runs in the tall GEMM afterwards.
+__global__ __launch_bounds__(256) void amp_attend_kernel(int64_t N, int K, int F, int E,
+                                                         const float* __restrict__ h,
+                                                         const int32_t* __restrict__ nlist,
+                                                         const float* __restrict__ e,
+                                                         const float* __restrict__ inv,
+                                                         const float* __restrict__ wq,
+                                                         const float* __restrict__ wk,
+                                                         float* __restrict__ agg) {
+  __shared__ float sq[4][64], su[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  if (i >= N) return;
+  for (int n = 0; n < E; ++n) {                     // q[n] = sum_l h[i,l] wq[l,n]
+    float p = 0.f;
+    for (int l = lane; l < F; l += 64) p += h[i * F + l] * wq[l * E + n];
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    if (lane == 0) sq[wv][n] = p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < E) {                                   // u[n] = sum_k wk[n,k] q[k]
+    float p = 0.f;
+    for (int k = 0; k < E; ++k) p += wk[lane * E + k] * sq[wv][k];
+    su[wv][lane] = p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float qd = -INFINITY;
+  int nb = 0;
+  if (lane < K) {
+    const float* ep = e + (i * K + lane) * E;
+    float p = 0.f;
+    for (int n = 0; n < E; ++n) p += ep[n] * su[wv][n];
+    qd = inv[i] * p;
+    nb = nlist[i * K + lane];
+  }
+  float mx = qd;
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float ex = lane < K ? __expf(qd - mx) : 0.f;
+  float sm = ex;
+  for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
+  const float b = ex / sm;
+  for (int l0 = 0; l0 < F; l0 += 64) {
+    const int l = l0 + lane;
+    float acc = 0.f;
+    for (int j = 0; j < K; ++j) {
+      const float bj = __shfl(b, j, 64);
+      const int tj = __shfl(nb, j, 64);
+      if (l < F) acc += bj * h[(int64_t)tj * F + l];
+    }
+    if (l < F) agg[i * F + l] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------ loss
 // one wave per graph: lg = sum w (y-p)^2 / sum w ; dpred = -2 w (y-p) / (sum w * G)
 __global__ __launch_bounds__(256) void loss_graph_kernel(int G, const int32_t* __restrict__ gptr,
@@ -746,6 +804,22 @@ extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
   NG_HIP(ctx, hipMemcpyAsync(dWout, summed, (size_t)Fh * C * 4, hipMemcpyDeviceToDevice, st));
   NG_HIP(ctx, hipMemcpyAsync(dbout, summed + (size_t)Fh * C, (size_t)C * 4, hipMemcpyDeviceToDevice,
                              st));
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_amp_attend(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E,
+                             const float* h, const int32_t* nlist, const float* e,
+                             const float* inv_degree, const float* wq, const float* wk, float* agg) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, K >= 1 && K <= 64, "amp: neighbour count must be in [1,64]");
+  NG_REQUIRE(ctx, E >= 1 && E <= 64, "amp: edge feature size must be in [1,64]");
+  NG_REQUIRE(ctx, F >= 1, "amp: bad feature size");
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, st, "amp_attend");
+  hipLaunchKernelGGL(amp_attend_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, st, N, K, F, E, h,
+                     nlist, e, inv_degree, wq, wk, agg);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

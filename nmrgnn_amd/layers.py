@@ -224,3 +224,43 @@ class FCBlock(_DenseStack):
 
     def get_config(self):
         return {'hypers': self.hypers}
+
+
+class AMPLayer(_DenseStack):
+    """nmrgnn/layers.py:48-100: attention message passing.  ``b = softmax_j(inv_degree_i *
+    <edges_ij @ wk, nodes_i @ wq>)``, ``out = activation(sum_j b_ij * (nodes[nlist_ij] @ wv))``.
+    Forward only, like its use in the reference (a shape test; the model is built from MPLayer)."""
+
+    def __init__(self, activation=None, kernel_regularizer=None, name='AMPLayer', **kwargs):
+        super().__init__()
+        if activation not in ACT:
+            raise ValueError(f"unsupported activation {activation!r}")
+        self.activation, self.name = activation, name
+        self.mpl_regularizer = kernel_regularizer
+        self.wq = self.wk = self.wv = None
+
+    def get_config(self):
+        return {'activation': self.activation, 'name': self.name}
+
+    def build(self, F, E, dev):
+        self.wq = _glorot((F, E), dev, self._gen)
+        self.wk = _glorot((E, E), dev, self._gen)
+        self.wv = _glorot((F, F), dev, self._gen)
+        self.built = True
+
+    def __call__(self, inputs):
+        nodes, nlist, edges, inv_degree = inputs
+        dev = _device()
+        nodes, nlist = _f32(nodes, dev), _i32(nlist, dev)
+        edges, inv = _f32(edges, dev), _f32(inv_degree, dev).reshape(-1)
+        N, F = nodes.shape
+        K, E = nlist.shape[1], edges.shape[-1]
+        if not self.built:
+            self.build(F, E, dev)
+        agg = torch.empty(N, F, dtype=torch.float32, device=dev)
+        ctx = self._ctx(dev)
+        ctx.check(ctx.lib.ng_amp_attend(ctx.handle, self._st(dev), N, K, F, E, ptr(nodes), ptr(nlist),
+                                        ptr(edges), ptr(inv), ptr(self.wq.contiguous()),
+                                        ptr(self.wk.contiguous()), ptr(agg)), "ng_amp_attend")
+        zero = torch.zeros(F, dtype=torch.float32, device=dev)
+        return self._dense(agg, self.wv, zero, self.activation, False, dev)

@@ -278,6 +278,22 @@ def divide_no_nan(a, b):
     return out
 
 
+def amp_layer_forward(nodes, nlist, edges, inv_degree, wq, wk, wv, act=None):
+    """layers.py:81-100 (AMPLayer.call), literal: gather, query/keys/values, softmax over ALL K slots."""
+    nodes = np.asarray(nodes, np.float64)
+    edges = np.asarray(edges, np.float64)
+    sliced = nodes[np.asarray(nlist)]
+    query = nodes @ np.asarray(wq, np.float64)
+    keys = edges @ np.asarray(wk, np.float64)
+    values = sliced @ np.asarray(wv, np.float64)
+    qdot = np.einsum('i,ijk,ik->ij', np.asarray(inv_degree, np.float64), keys, query)
+    qdot = qdot - qdot.max(axis=-1, keepdims=True)
+    b = np.exp(qdot)
+    b /= b.sum(axis=-1, keepdims=True)
+    reduced = np.einsum('ij,ijk->ik', b, values)
+    return _act(act)(reduced)
+
+
 def corr_coeff(x, y, w=None):
     """nmrgnn/losses.py:4-15"""
     if w is None:

@@ -88,3 +88,24 @@ def test_aggregate_abi_matches_numpy(gpu_device, F, E):
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     ctx.check(ctx.lib.ng_mp_aggregate(ctx.handle, st, N, K, F, E, ptr(th), ptr(tn), ptr(te), ptr(A)), "agg")
     np.testing.assert_allclose(A.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("F,E,act", [(16, 2, None), (64, 3, "softplus"), (256, 8, "tanh")])
+def test_amplayer_matches_oracle(gpu_device, F, E, act):
+    """AMPLayer (nmrgnn/layers.py:48-100): reference shape test (tests:46-52) + literal fp64 oracle."""
+    import nmrgnn_amd
+    from oracle import nmrgnn_oracle as O
+    rng = np.random.default_rng(3)
+    N, K = 203, 16
+    nodes = rng.standard_normal((N, F)).astype(np.float32)
+    nlist = rng.integers(0, N, (N, K))
+    edges = rng.standard_normal((N, K, E)).astype(np.float32)
+    edges[:, K - 3:, :] = 0.0                                  # padded slots still take part in the softmax
+    nlist[:, K - 3:] = 0
+    inv = (1.0 / 13) * np.ones(N)
+    layer = nmrgnn_amd.AMPLayer(activation=act)
+    out = layer([nodes, nlist, edges, inv])
+    assert tuple(out.shape) == nodes.shape
+    ref = O.amp_layer_forward(nodes, nlist, edges, inv, layer.wq.cpu().numpy(), layer.wk.cpu().numpy(),
+                              layer.wv.cpu().numpy(), act)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
