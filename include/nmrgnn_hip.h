@@ -117,6 +117,15 @@ int ng_mp_layer_bwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int a
                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out,
                     float* dh_in, float* de, int de_accum, float* dw);
 
+/* ---- graph front end: K nearest neighbours per atom, per frame --------------------------------
+ * Replaces the neighbour search behind nmrgnn.universe2graph (nmrgnn/library.py:106-117, external
+ * nmrdata.parse_universe) and the per-frame graph construction of eval-struct (main.py:236-243).
+ *   pos [G][n][3] (Angstrom) -> nlist [G*n][K] batch-global indices (frame*n + j), self excluded,
+ *   ascending distance, ties -> lower index; edges [G*n][K] = distance*scale; unused slots (0, 0.0);
+ *   inv_degree [G*n] = 1/#(local neighbour index > 0), 0 when none (library.py:115-116).  K <= 64. */
+int ng_knn_graph(ng_ctx*, void* stream, int G, int n, int K, float scale, const float* pos,
+                 int32_t* nlist, float* edges, float* inv_degree);
+
 /* AMPLayer attention aggregation, nmrgnn/layers.py:89-96 (forward only; the layer is exported by the
  * reference package but not used by its model):
  *   b[i,:] = softmax_j( inv[i] * <e[i,j,:] @ wk, h[i,:] @ wq> ),  agg[i,:] = sum_j b[i,j] * h[nlist[i,j],:]

@@ -93,3 +93,33 @@ def concat_graphs(graphs, device=None):
         ptr.append(off)
     return GraphBatch(np.concatenate(atoms), np.concatenate(nlist).astype(np.int32),
                       np.concatenate(edges), np.concatenate(inv), graph_ptr=ptr, device=device)
+
+
+def frames_to_batch(atoms, frames, neighbor_number=16, scale=0.1, device=None):
+    """Build the graphs of ``G`` trajectory frames on the GPU (ng_knn_graph) and return them as one
+    device-resident GraphBatch: ``atoms`` [n,C] one-hot (shared by all frames), ``frames`` [G,n,3]
+    positions in Angstrom.  Same conventions as :func:`nmrgnn_amd.structure.knn_graph`."""
+    import ctypes as C
+    from . import _lib
+    from ._lib import ptr
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    pos = _to_dev(np.asarray(frames, dtype=np.float32) if not isinstance(frames, torch.Tensor) else frames,
+                  torch.float32, device)
+    if pos.dim() == 2:
+        pos = pos[None]
+    G, n, _ = pos.shape
+    K = int(neighbor_number)
+    at = _to_dev(atoms, torch.float32, device)
+    if at.shape[0] != n:
+        raise ValueError(f"atoms has {at.shape[0]} rows but frames have {n} atoms")
+    nlist = torch.empty(G * n, K, dtype=torch.int32, device=device)
+    edges = torch.empty(G * n, K, dtype=torch.float32, device=device)
+    inv = torch.empty(G * n, dtype=torch.float32, device=device)
+    ctx = _lib.get_context(device.index)
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    ctx.check(ctx.lib.ng_knn_graph(ctx.handle, st, G, n, K, float(scale), ptr(pos), ptr(nlist), ptr(edges),
+                                   ptr(inv)), "ng_knn_graph")
+    ptrs = np.arange(G + 1, dtype=np.int64) * n
+    return GraphBatch(at.repeat(G, 1), nlist, edges, inv, graph_ptr=ptrs, device=device, validate=False)

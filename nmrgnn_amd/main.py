@@ -2,8 +2,8 @@
 
 Same arguments, options, CSV columns and per-phase timing line as the reference command.  Frames
 of a trajectory are independent graphs, so they are concatenated ``--frames-per-batch`` at a time into
-one device batch (one launch sequence per batch instead of one per frame); the reference evaluates
-frame by frame.  The training / hyper-parameter-search commands of the reference are out of scope
+one device batch (one launch sequence per batch instead of one per frame) and their neighbour lists
+are built on the GPU (ng_knn_graph); the reference evaluates frame by frame with a CPU neighbour search.  The training / hyper-parameter-search commands of the reference are out of scope
 (control plane)."""
 from __future__ import annotations
 
@@ -39,9 +39,10 @@ def eval_structure(struct_files, output_csv, model_file=None, neighbor_number=16
     buckets in seconds."""
     if len(struct_files) == 0:
         raise ValueError('Must pass at least on structure file')
-    from .graph import concat_graphs
+    import torch
+    from .graph import frames_to_batch
     from .library import check_peaks, load_model
-    from .structure import atoms_onehot, inv_degree_of, knn_graph
+    from .structure import atoms_onehot
 
     model = load_model(model_file, device=device)
     u = _open_structure(struct_files)
@@ -53,17 +54,13 @@ def eval_structure(struct_files, output_csv, model_file=None, neighbor_number=16
     for b0 in range(0, len(frame_ids), max(1, frames_per_batch)):
         chunk = frame_ids[b0:b0 + max(1, frames_per_batch)]
         t = time.perf_counter()
-        graphs = []
-        for fr in chunk:
-            nlist, edges = knn_graph(u.frames[fr], neighbor_number)
-            graphs.append((atoms, nlist, edges, inv_degree_of(nlist)))
+        model.build(atoms.shape[1])
+        dev = model.engine.device
+        batch = frames_to_batch(atoms, np.stack([u.frames[fr] for fr in chunk]), neighbor_number, device=dev)
+        torch.cuda.synchronize(dev)
         timing['Structure'] += time.perf_counter() - t
         t = time.perf_counter()
-        if len(graphs) == 1:
-            peaks = np.asarray(model(graphs[0]))
-        else:
-            model.build(atoms.shape[1])
-            peaks = model(concat_graphs(graphs, device=model.engine.device)).cpu().numpy()
+        peaks = model(batch).cpu().numpy()
         peaks = peaks.reshape(len(chunk), n)
         conf = []
         for k in range(len(chunk)):

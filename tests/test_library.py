@@ -155,3 +155,40 @@ def test_eval_struct_trajectory_csv(gpu_device, tmp_path):
     got = np.array([float(r[4]) for r in rows[1 + 3 * 2770:]])
     assert np.max(np.abs(got - ref)) <= 0.011                     # rounding boundary only
     assert rows[1][1] == s.resnames[0] and rows[1][3] == s.names[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [16, 5, 24])
+def test_gpu_knn_matches_host_builder(gpu_device, K):
+    """ng_knn_graph vs the host cKDTree builder on the reference's PDB fixtures: same neighbours in the
+    same order (up to exact distance ties), distances to 1 ulp-ish, same inv_degree, frame offsets."""
+    from nmrgnn_amd.graph import frames_to_batch
+    from nmrgnn_amd.structure import atoms_onehot, inv_degree_of, knn_graph, read_pdb
+    s = read_pdb(PDB2)
+    frames = np.stack(s.frames[:3])
+    atoms = atoms_onehot(s.elements)
+    gb = frames_to_batch(atoms, frames, K, device=gpu_device)
+    n = atoms.shape[0]
+    assert gb.N == 3 * n and gb.G == 3 and gb.K == K
+    nl, ed, inv = gb.nlist.cpu().numpy(), gb.edges.cpu().numpy(), gb.inv_degree.cpu().numpy()
+    for f in range(3):
+        hn, he = knn_graph(frames[f], K)
+        sl = slice(f * n, (f + 1) * n)
+        np.testing.assert_allclose(ed[sl], he, rtol=2e-6, atol=1e-7)
+        same = (nl[sl] - f * n) == hn
+        tied = np.isclose(he, np.roll(he, 1, axis=1), rtol=1e-6) | np.isclose(he, np.roll(he, -1, axis=1), rtol=1e-6)
+        assert np.all(same | tied)
+        assert same.mean() > 0.999
+        np.testing.assert_allclose(inv[sl], inv_degree_of(nl[sl] - f * n), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_knn_tiny_and_ragged(gpu_device):
+    from nmrgnn_amd.graph import frames_to_batch
+    pos = np.array([[[0, 0, 0], [1, 0, 0], [0, 2, 0]]], np.float32)      # n-1 < K -> padded slots
+    atoms = np.eye(10, dtype=np.float32)[[4, 2, 3]]
+    gb = frames_to_batch(atoms, pos, 16, device=gpu_device)
+    nl, ed, inv = gb.nlist.cpu().numpy(), gb.edges.cpu().numpy(), gb.inv_degree.cpu().numpy()
+    assert nl[0, :2].tolist() == [1, 2] and np.allclose(ed[0, :2], [0.1, 0.2]) and not ed[0, 2:].any()
+    assert nl[1, :2].tolist() == [0, 2] and not nl[:, 2:].any()
+    np.testing.assert_allclose(inv, [0.5, 1.0, 1.0])                     # index 0 never counts (library.py:115)
