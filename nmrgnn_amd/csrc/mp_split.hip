@@ -30,7 +30,7 @@ constexpr int SAPB = 256 / SC4; // atoms per 256-thread block
 
 bool mp_split_enabled(int F, int E) {
   const char* v = getenv("NG_MP_PATH");
-  if (v && std::string(v) != "split") return false;
+  if (v && std::string(v) != "split" && std::string(v) != "win") return false;   // win: forward only so far
   return F == SF && E >= 1 && E <= 3;
 }
 

@@ -1,0 +1,573 @@
+// Window-resident fused MPLayer kernels for atom_feature_size == 64, edge_feature_size <= 3.
+// Reference: nmrgnn/layers.py:26-46 (MPLayer.call) + residual of nmrgnn/model.py:165-167.
+//
+//   h'[i,:] = act( v_i * sum_{n,l} A[i,n,l] W[l,:,n] ) + h[i,:],   A[i,n,l] = sum_j e[i,j,n] h[nlist[i,j], l]
+//
+// Molecule batches have index-local neighbour lists (a neighbour of atom i lies in i's own graph,
+// a few hundred rows around i).  One persistent 512-thread workgroup per CU walks a contiguous run of
+// 32-atom tiles and keeps a WINDOW of 288 consecutive h rows (72 KB) in LDS, so every gathered row is
+// read from HBM/L2 once per run instead of once per referencing edge, and the [N, E*64] aggregate never
+// touches HBM: it goes from the gather straight into an LDS tile that the matrix cores consume.
+//
+// Per tile, all eight waves run the same two phases, separated by barriers:
+//   gather   16 lanes per atom, 4 atoms per wave: list reads from LDS, one ds_read_b128 per neighbour
+//            from the window, v_pk_fma_f32 accumulation, aggregate written to the LDS tile;
+//            the lists of the NEXT tile go registers -> LDS here and the ones after that are requested
+//            from global memory (one full tile of latency cover).
+//   matrix   [32 x E*64] x [E*64 x 64] on v_mfma_f32_16x16x4_f32 — wave w owns output columns
+//            16(w&3).. of atoms 16(w>>2).., weight slab resident in registers — then the epilogue
+//            (inv_degree, activation, residual) from the accumulators.
+// Measured on gfx950 (tools/ubench): an fp32 MFMA stream and VALU work do NOT overlap on a SIMD, neither
+// across its two waves nor inside one wave — fp32 MFMA runs at the vector rate on shared issue — so there
+// is nothing to gain from giving waves different roles; what matters is the VALU instruction count
+// (packed FMAs, vector list traffic) and that the partner wave covers LDS latency.
+//
+// When a tile's lists leave the window it is restaged, centred on the referenced range; a tile whose
+// range is wider than the window (whole proteins with long-range contacts, or raw zero-padded lists)
+// gathers from global memory instead — same kernel, workgroup-uniform branch.  Hosts that want the
+// window path point padded slots at the atom itself (their edge features are exactly 0).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "mfma_gemm.cuh"
+#include "ng_internal.h"
+#include "edge_fused.h"   // NG_LDS_BARRIER
+
+namespace ng {
+
+constexpr int WF = 64;          // feature width
+constexpr int WTA = 32;         // atoms per tile
+constexpr int WROWS = 288;      // window rows
+constexpr int WC4 = WF / 4;     // float4 per row = lanes per atom
+constexpr int WTHREADS = 512;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- weight fragments for v_mfma_f32_16x16x4_f32 (A operand: row i = lane & 15, k = lane >> 4) ----
+// out[((ct*NT + T)*64 + lane)*4 + u] = Wsrc(k = 16T + 4(lane>>4) + u, o = 16ct + (lane&15))
+// mode 0 (forward):       Wsrc(k = n*64 + l, o = m) = w[l][m][n]
+// mode 1 (back to nodes): Wsrc(k = n*64 + m, o = l) = w[l][m][n]
+// mode 2 (dA = dP Wp^T):  Wsrc(k = m, o = n*64 + l) = w[l][m][n]
+__global__ void mpw_pack_kernel(int E, int mode, const float* __restrict__ w, float* __restrict__ out) {
+  const int KF = E * WF;
+  const int kdim = mode == 2 ? WF : KF;
+  const int odim = mode == 2 ? KF : WF;
+  const int NT = kdim / 16;
+  const int total = kdim * odim;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int u = r & 3; r >>= 2;
+    const int lane = r & 63; r >>= 6;
+    const int T = r % NT, ct = r / NT;
+    const int k = 16 * T + 4 * (lane >> 4) + u;
+    const int o = 16 * ct + (lane & 15);
+    float v;
+    if (mode == 0) {
+      v = w[((k % WF) * WF + o) * E + k / WF];
+    } else if (mode == 1) {
+      v = w[(o * WF + (k % WF)) * E + k / WF];
+    } else {
+      v = w[((o % WF) * WF + k) * E + o / WF];
+    }
+    out[idx] = v;
+  }
+}
+
+int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
+  hipLaunchKernelGGL(mpw_pack_kernel, dim3(24), dim3(256), 0, st, E, mode, w, out);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+// ---- shared device pieces ---------------------------------------------------------------------------
+
+// min over the 64 lanes, valid in lane 63: row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31
+__device__ __forceinline__ int wave_min_i32(int v) {
+  const int big = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// acc += w * h for one float4 of features, as two v_pk_fma_f32
+__device__ __forceinline__ void pk_axpy(f32x2& lo, f32x2& hi, float w, const float4& h) {
+  const f32x2 ww = {w, w};
+  lo = __builtin_elementwise_fma(ww, f32x2{h.x, h.y}, lo);
+  hi = __builtin_elementwise_fma(ww, f32x2{h.z, h.w}, hi);
+}
+
+// Neighbour lists of one 32-atom tile in flight between global memory and LDS.  K % 4 == 0: whole
+// 16-byte vectors (32K/4 int4 of indices, 32KE/4 float4 of edge features); otherwise scalars.
+template <int E, bool K4>
+struct WinLists {
+  int4 nl4;
+  float4 e4[2];
+  int nl1[2];
+  float e1[2][E];
+
+  // Every thread issues the same number of loads (indices clamped into the arrays, out-of-range slots
+  // zeroed afterwards): with no conditional VMEM in the tile loop the compiler's s_waitcnt counts stay
+  // exact and nothing waits on the output stores still in flight.
+  __device__ __forceinline__ void issue(const int32_t* __restrict__ nlist, const float* __restrict__ e,
+                                        int64_t t, int K, int64_t N, int tid) {
+    const int per_tile = WTA * K;
+    const int64_t base = t * per_tile, lim = N * K;
+    if (K4) {
+      const int64_t nb = base / 4, nlim = lim / 4;              // int4 units
+      const int64_t eb = base * E / 4, elim = lim * E / 4;      // float4 units
+      const int64_t qn = nb + tid;
+      const int4 z4 = make_int4(0, 0, 0, 0);
+      const int4 v = reinterpret_cast<const int4*>(nlist)[qn < nlim ? qn : nlim - 1];
+      nl4 = qn < nlim ? v : z4;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t qe = eb + tid + WTHREADS * u;
+        const float4 w = reinterpret_cast<const float4*>(e)[qe < elim ? qe : elim - 1];
+        e4[u] = qe < elim ? w : f4zero();
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t q = base + tid + WTHREADS * u;
+        const bool ok = q < lim;
+        const int64_t qc = ok ? q : lim - 1;
+        const int v = nlist[qc];
+        nl1[u] = ok ? v : 0;
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+          const float w = e[qc * E + n];
+          e1[u][n] = ok ? w : 0.f;
+        }
+      }
+    }
+  }
+
+  // registers -> LDS; the row range over ALL slots goes to ctl[wave] / ctl[8 + wave]
+  __device__ __forceinline__ void commit(int32_t* __restrict__ s_nl, float* __restrict__ s_e,
+                                         int* __restrict__ ctl, int K, int tid, int wave, int lane) {
+    const int per_tile = WTA * K;
+    int lo = 0x7fffffff, hi = -1;
+    if (K4) {
+      const int nv = per_tile / 4, ev = per_tile * E / 4;
+      if (tid < nv) {
+        reinterpret_cast<int4*>(s_nl)[tid] = nl4;
+        lo = min(min(nl4.x, nl4.y), min(nl4.z, nl4.w));
+        hi = max(max(nl4.x, nl4.y), max(nl4.z, nl4.w));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + WTHREADS * u < ev) reinterpret_cast<float4*>(s_e)[tid + WTHREADS * u] = e4[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = tid + WTHREADS * u;
+        if (q < per_tile) {
+          s_nl[q] = nl1[u];
+#pragma unroll
+          for (int n = 0; n < E; ++n) s_e[q * E + n] = e1[u][n];
+          lo = min(lo, nl1[u]); hi = max(hi, nl1[u]);
+        }
+      }
+    }
+    lo = wave_min_i32(lo);
+    hi = -wave_min_i32(-hi);
+    if (lane == 63) { ctl[wave] = lo; ctl[8 + wave] = hi; }
+  }
+};
+
+// every thread takes the same decision from the eight partial ranges; returns true when the window has
+// to be restaged at the (updated) wlo.  mode: 0 = gather from the window, 1 = gather from global memory
+__device__ __forceinline__ bool win_decide(const int* __restrict__ ctl, int& wlo, int& mode) {
+  int lo = ctl[0], hi = ctl[8];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) { lo = min(lo, ctl[i]); hi = max(hi, ctl[8 + i]); }
+  mode = 0;
+  if (hi < lo) return false;                                  // empty tile
+  if (lo >= wlo && hi < wlo + WROWS) return false;            // window hit
+  if (hi - lo + 1 > WROWS) { mode = 1; return false; }        // too wide
+  wlo = max(0, lo - (WROWS - (hi - lo + 1)) / 2);
+  return true;
+}
+
+__device__ __forceinline__ void win_stage(float4* __restrict__ win4, const float4* __restrict__ src4,
+                                          int wlo, int64_t N, int tid) {
+  float4 v[9];
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int idx = tid + WTHREADS * u;
+    const int64_t row = (int64_t)wlo + (idx >> 4);
+    v[u] = row < N ? src4[row * WC4 + (idx & 15)] : f4zero();
+  }
+#pragma unroll
+  for (int u = 0; u < 9; ++u) win4[tid + WTHREADS * u] = v[u];
+}
+static_assert(WROWS * WC4 == 9 * WTHREADS, "window staging assumes 9 float4 per thread");
+
+// ---- rotation gather (K <= 16, window mode) ------------------------------------------------------------
+// Lane c of an atom's 16-lane row owns neighbour slot c: ONE index and E weights per lane instead of
+// every lane reading the whole list (which cost as much LDS bandwidth as the row gather itself).  In
+// step s the lane uses the slot of lane (c + s) mod 16, fetched over the DPP network (row_ror:s) —
+// each lane walks the neighbours in its own rotated order, the sum is the same.  All sixteen lanes of
+// a row read the SAME bank group (4c..4c+3) of sixteen DIFFERENT window rows: still conflict-free.
+template <int S>
+__device__ __forceinline__ int ror_i(int v) {
+  if (S == 0) return v;
+  return __builtin_amdgcn_update_dpp(0, v, 0x120 + (S & 15), 0xf, 0xf, false);
+}
+template <int S>
+__device__ __forceinline__ float ror_f(float v) {
+  return __builtin_bit_cast(float, ror_i<S>(__builtin_bit_cast(int, v)));
+}
+
+template <int E, int S0>
+__device__ __forceinline__ void rot_steps4(const char* __restrict__ wbytes, int roff, const float (&w)[E],
+                                           f32x2 (&lo)[E], f32x2 (&hi)[E]) {
+  // four steps per call: the four row reads are issued before the first FMA needs its row
+  const float4 h0 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 0>(roff));
+  const float4 h1 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 1>(roff));
+  const float4 h2 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 2>(roff));
+  const float4 h3 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 3>(roff));
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 0>(w[n]), h0);
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 1>(w[n]), h1);
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 2>(w[n]), h2);
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 3>(w[n]), h3);
+}
+
+template <int E>
+__device__ __forceinline__ void win_gather_rot(int K, int wave, int lane, int wlo,
+                                               const int32_t* __restrict__ nl, const float* __restrict__ ee,
+                                               float* __restrict__ tb, int ld, const float4* __restrict__ win4) {
+  const int c = lane & 15;
+  const int al = wave * 4 + (lane >> 4);
+  const int slot = al * K + (c < K ? c : 0);
+  const int idx = nl[slot];
+  float w[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) w[n] = c < K ? ee[slot * E + n] : 0.f;
+  // byte offset of (this lane's neighbour row, column chunk 0); the chunk offset 16c is lane-local
+  const int roff = min(max(idx - wlo, 0), WROWS - 1) * (WF * 4);
+  const char* wbytes = reinterpret_cast<const char*>(win4) + 16 * c;
+  f32x2 lo[E], hi[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) { lo[n] = f32x2{0.f, 0.f}; hi[n] = f32x2{0.f, 0.f}; }
+  rot_steps4<E, 0>(wbytes, roff, w, lo, hi);
+  rot_steps4<E, 4>(wbytes, roff, w, lo, hi);
+  rot_steps4<E, 8>(wbytes, roff, w, lo, hi);
+  rot_steps4<E, 12>(wbytes, roff, w, lo, hi);
+#pragma unroll
+  for (int n = 0; n < E; ++n)
+    *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
+}
+
+// gather + edge-weighted sum of one 32-atom tile: 16 lanes per atom, 4 atoms per wave, 8 waves.
+// MODE 0 reads rows from the LDS window, MODE 1 from global memory; a compile-time constant because
+// the window instance must not contain global loads (the compiler's vmcnt(0) in front of their use
+// would also wait for the list prefetch that is deliberately left in flight).
+template <int E, bool K4, int MODE>
+__device__ __forceinline__ void win_gather(int K, int wave, int lane, int wlo,
+                                           const int32_t* __restrict__ nl, const float* __restrict__ ee,
+                                           float* __restrict__ tb, int ld, const float4* __restrict__ win4,
+                                           const float4* __restrict__ src4) {
+  const int c = lane & 15;
+  const int al = wave * 4 + (lane >> 4);
+  const float4* wbase = win4 + c;
+  f32x2 lo[E], hi[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) { lo[n] = f32x2{0.f, 0.f}; hi[n] = f32x2{0.f, 0.f}; }
+  if (K4) {
+    // 16 neighbours per round: all list reads, then all row reads, then the FMAs
+    const int4* nl4 = reinterpret_cast<const int4*>(nl + al * K);
+    const float4* e4 = reinterpret_cast<const float4*>(ee + al * K * E);
+    const int ng = K / 4;
+#pragma unroll 1
+    for (int g0 = 0; g0 < ng; g0 += 4) {
+      int4 r4[4];
+      float4 ev4[4][E];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gq = g0 + q < ng ? g0 + q : ng - 1;
+        r4[q] = nl4[gq];
+#pragma unroll
+        for (int n = 0; n < E; ++n) ev4[q][n] = e4[gq * E + n];
+      }
+      float4 hv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (MODE == 0) {
+            const int r = min(max(rr[u] - wlo, 0), WROWS - 1);   // padded slots stay inside the window
+            hv[4 * q + u] = wbase[r * WC4];
+          } else {
+            hv[4 * q + u] = src4[(int64_t)rr[u] * WC4 + c];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (g0 + q < ng) {
+          float ev[4 * E];
+#pragma unroll
+          for (int n = 0; n < E; ++n) {
+            ev[4 * n + 0] = ev4[q][n].x; ev[4 * n + 1] = ev4[q][n].y;
+            ev[4 * n + 2] = ev4[q][n].z; ev[4 * n + 3] = ev4[q][n].w;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ev[u * E + n], hv[4 * q + u]);
+        }
+      }
+    }
+  } else {
+    for (int j = 0; j < K; ++j) {
+      const int rj = nl[al * K + j];
+      float4 hv;
+      if (MODE == 0) {
+        const int r = min(max(rj - wlo, 0), WROWS - 1);
+        hv = wbase[r * WC4];
+      } else {
+        hv = src4[(int64_t)rj * WC4 + c];
+      }
+#pragma unroll
+      for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ee[(al * K + j) * E + n], hv);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < E; ++n) {
+    const float4 v = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
+    *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = v;
+  }
+}
+
+// The global-memory variant is kept out of line: inlined next to the window variant it makes the
+// compiler put vmcnt waits (for registers its loads may target) into the window gather, which then
+// stalls on the list prefetch in flight.
+template <int E, bool K4>
+__device__ __noinline__ void win_gather_global(int K, int wave, int lane, const int32_t* nl, const float* ee,
+                                               float* tb, int ld, const float4* src4) {
+  win_gather<E, K4, 1>(K, wave, lane, 0, nl, ee, tb, ld, nullptr, src4);
+}
+
+// ---- forward ------------------------------------------------------------------------------------------
+struct MpWinFwdArgs {
+  int64_t N;
+  int K;
+  int64_t ntiles;
+  int tiles_per_wg;
+  const float* h;          // [N][64]
+  const int32_t* nlist;    // [N][K]
+  const float* e;          // [N*K][E]
+  const float* Wfrag;      // mpw_pack mode 0
+  const float* rowscale;   // [N] or nullptr
+  int residual;
+  float* out;              // [N][64]
+  float* S_save;           // [N][64] or nullptr
+  int act;
+  float* dummy;            // 64 floats: where the lanes of rows >= N store
+  long long* trace;        // debug: per-tile cycle stamps of block 0 wave 0 (kept in LDS until the end)
+};
+
+template <int E, bool K4>
+__global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a) {
+  constexpr int KF = E * WF;
+  constexpr int LD = KF + 4;
+  constexpr int NT = KF / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* win = smem;                                                   // [WROWS][64]
+  float* tile = win + WROWS * WF;                                      // [32][LD]
+  int32_t* s_nl = reinterpret_cast<int32_t*>(tile + WTA * LD);         // [2][32*K]
+  float* s_e = reinterpret_cast<float*>(s_nl + 2 * WTA * a.K);         // [2][32*K*E]
+  int* ctl = reinterpret_cast<int*>(s_e + 2 * WTA * a.K * E);          // [2][16]
+  long long* s_tr = reinterpret_cast<long long*>(ctl + 32);            // [160] debug stamps
+  int tr_n = 0;
+#define WIN_STAMP()                                                                      \
+  do {                                                                                    \
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && tr_n < 160) s_tr[tr_n++] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K;
+  const int per_tile = WTA * K;
+
+  const int64_t T0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+  const int64_t T1 = std::min<int64_t>(T0 + a.tiles_per_wg, a.ntiles);
+  if (T0 >= T1) return;
+
+  const float4* src4 = reinterpret_cast<const float4*>(a.h);
+  float4* win4 = reinterpret_cast<float4*>(win);
+  // zero the window once: clamped reads of padded slots must hit finite values
+  for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
+
+  // this wave's weight slab (output columns 16ct..) resident in registers for the whole launch
+  const int ct = wave & 3, hh = wave >> 2;
+  float wf[KF / 4];
+  {
+    const float4* p = reinterpret_cast<const float4*>(a.Wfrag) + (ct * NT) * 64 + lane;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const float4 v = p[T * 64];
+      wf[4 * T + 0] = v.x; wf[4 * T + 1] = v.y; wf[4 * T + 2] = v.z; wf[4 * T + 3] = v.w;
+    }
+    // "use" the slab once here: otherwise the first MFMA of every tile carries a conservative vmcnt
+    // wait that also drains the previous tile's output stores
+#pragma unroll
+    for (int i = 0; i < KF / 4; ++i) asm volatile("" : "+v"(wf[i]));
+  }
+
+  WinLists<E, K4> lists;
+  int wlo = -(1 << 30);       // no window yet: the first tile stages one
+  int mode = 0;
+  lists.issue(a.nlist, a.e, T0, K, a.N, tid);
+  lists.commit(s_nl + (T0 & 1) * per_tile, s_e + (T0 & 1) * per_tile * E, ctl + (T0 & 1) * 16, K, tid, wave, lane);
+  lists.issue(a.nlist, a.e, T0 + 1 < T1 ? T0 + 1 : T0, K, a.N, tid);
+  NG_LDS_BARRIER();
+  if (win_decide(ctl + (T0 & 1) * 16, wlo, mode)) {
+    win_stage(win4, src4, wlo, a.N, tid);
+  }
+  NG_LDS_BARRIER();
+
+  const int a16 = lane & 15, g = lane >> 4;
+  const int col = 16 * ct + 4 * g;
+  const float resf = a.residual ? 1.f : 0.f;
+#pragma unroll 1
+  for (int64_t t = T0; t < T1; ++t) {
+    WIN_STAMP();
+    // ---- phase 1: lists of t+1 into LDS, request lists of t+2 and the epilogue operands, gather tile t
+    const int64_t row = t * WTA + 16 * hh + a16;          // this lane's atom in the matrix phase
+    const bool live = row < a.N;
+    const int64_t rowc = live ? row : a.N - 1;
+    if (t + 1 < T1)
+      lists.commit(s_nl + ((t + 1) & 1) * per_tile, s_e + ((t + 1) & 1) * per_tile * E,
+                   ctl + ((t + 1) & 1) * 16, K, tid, wave, lane);
+    lists.issue(a.nlist, a.e, t + 2 < T1 ? t + 2 : t, K, a.N, tid);
+    const float rs = a.rowscale[rowc];
+    const float4 re = *reinterpret_cast<const float4*>(a.h + rowc * WF + col);
+    WIN_STAMP();
+    {
+      const int32_t* nl = s_nl + (t & 1) * per_tile;
+      const float* ee = s_e + (t & 1) * per_tile * E;
+      if (mode == 0 && K <= 16) win_gather_rot<E>(K, wave, lane, wlo, nl, ee, tile, LD, win4);
+      else if (mode == 0) win_gather<E, K4, 0>(K, wave, lane, wlo, nl, ee, tile, LD, win4, src4);
+      else win_gather_global<E, K4>(K, wave, lane, nl, ee, tile, LD, src4);
+    }
+    WIN_STAMP();
+    NG_LDS_BARRIER();
+    WIN_STAMP();
+    // ---- phase 2: tile x weights on the matrix cores, epilogue
+    {
+      const float* xrow = tile + (16 * hh + a16) * LD + 4 * g;
+      // operand reads run two k-steps ahead of the MFMAs that consume them (pinned: left alone the
+      // scheduler hoists all of them to the top and the matrix pipe idles behind the LDS)
+      float4 x[NT];
+      x[0] = *reinterpret_cast<const float4*>(xrow);
+      x[1] = *reinterpret_cast<const float4*>(xrow + 16);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (T + 2 < NT) x[T + 2] = *reinterpret_cast<const float4*>(xrow + 16 * (T + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      WIN_STAMP();
+      float4 v = make_float4((acc0[0] + acc1[0]) * rs, (acc0[1] + acc1[1]) * rs, (acc0[2] + acc1[2]) * rs,
+                             (acc0[3] + acc1[3]) * rs);
+      if (a.act == NG_ACT_SOFTPLUS) {
+        v.x = softplus_f(v.x); v.y = softplus_f(v.y); v.z = softplus_f(v.z); v.w = softplus_f(v.w);
+      } else if (a.act != NG_ACT_NONE) {
+        v.x = act_apply(a.act, v.x); v.y = act_apply(a.act, v.y);
+        v.z = act_apply(a.act, v.z); v.w = act_apply(a.act, v.w);
+      }
+      // rows past the end store into a dummy row: the store count per tile stays fixed
+      const int64_t o = row * WF + col;
+      // both results first, then both stores: a wait on `re` between them would also wait for the
+      // first store to be acknowledged (vmcnt retires in order)
+      const float4 vo = make_float4(v.x + resf * re.x, v.y + resf * re.y, v.z + resf * re.z, v.w + resf * re.w);
+      asm volatile("" :: "v"(vo.x), "v"(vo.y), "v"(vo.z), "v"(vo.w));
+      if (a.S_save) *reinterpret_cast<float4*>(live ? a.S_save + o : a.dummy + col) = v;
+      *reinterpret_cast<float4*>(live ? a.out + o : a.dummy + col) = vo;
+    }
+    WIN_STAMP();
+    bool restage = false;
+    if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * 16, wlo, mode);
+    NG_LDS_BARRIER();
+    if (restage) {                       // uniform over the workgroup
+      win_stage(win4, src4, wlo, a.N, tid);
+      NG_LDS_BARRIER();
+    }
+  }
+  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+    s_tr[tr_n++] = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < tr_n; ++i) a.trace[i] = s_tr[i];
+  }
+}
+
+size_t mp_win_lds_bytes(int K, int E) {
+  const int LD = E * WF + 4;
+  return (size_t)(WROWS * WF + WTA * LD + 2 * WTA * K * (1 + E) + 32 + 320) * 4;
+}
+
+bool mp_win_supported(int F, int E, int K) {
+  return F == WF && E >= 1 && E <= 3 && K >= 1 && K <= 32 && mp_win_lds_bytes(K, E) <= 160 * 1024;
+}
+
+bool mp_win_enabled(int F, int E, int K) {
+  if (!mp_win_supported(F, E, K)) return false;
+  const char* s = getenv("NG_MP_PATH");
+  return s && !strcmp(s, "win");
+}
+
+int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
+               const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
+               float* s_save) {
+  if (N == 0) return NG_OK;
+  const int KF = E * WF;
+  float* Wfrag = (float*)workspace(ctx, (size_t)(KF * WF + 64) * 4);
+  if (!Wfrag) return NG_ERR_NOMEM;
+  int rc = mpw_pack(ctx, st, E, 0, w, Wfrag);
+  if (rc) return rc;
+  MpWinFwdArgs a{};
+  a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
+  // contiguous runs of tiles per workgroup, a multiple of 8 tiles (256 atoms) so that runs start on
+  // molecule boundaries for the common 256-atom padding
+  int64_t per = cdiv(a.ntiles, ctx->num_cu);
+  per = cdiv(per, 8) * 8;
+  a.tiles_per_wg = (int)per;
+  a.h = h; a.nlist = nlist; a.e = e; a.Wfrag = Wfrag; a.rowscale = inv_degree; a.residual = residual;
+  a.out = h_out; a.S_save = s_save; a.act = act; a.dummy = Wfrag + KF * WF;
+  { const char* d = getenv("NG_WIN_TRACE"); a.trace = d ? (long long*)strtoull(d, nullptr, 0) : nullptr; }
+  const int grid = (int)cdiv(a.ntiles, per);
+  const size_t lds = mp_win_lds_bytes(K, E);
+  ProfScope ps(ctx, st, "mp_win_fwd");
+#define CALL(EE)                                                                                          \
+  if (K % 4 == 0)                                                                                         \
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true>), dim3(grid), dim3(WTHREADS), lds, st, a);            \
+  else                                                                                                    \
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false>), dim3(grid), dim3(WTHREADS), lds, st, a);
+  switch (E) {
+    case 1: { CALL(1) } break;
+    case 2: { CALL(2) } break;
+    case 3: { CALL(3) } break;
+  }
+#undef CALL
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+}  // namespace ng

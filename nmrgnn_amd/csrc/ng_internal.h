@@ -76,6 +76,14 @@ int tall_tn(ng_ctx* ctx, hipStream_t st, int64_t N, const float* A, int lda, int
             int ldb, int kb_valid, const float* S_in, int act_in, float* dW, float* db, int w_map, int F,
             int E, float* scratch, const char* tag);
 
+// window-resident fused MPLayer kernels (mp_win.hip): atom_feature_size == 64, edge_feature_size <= 3
+bool mp_win_supported(int F, int E, int K);
+bool mp_win_enabled(int F, int E, int K);
+int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out);
+int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
+               const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
+               float* s_save);
+
 // split MPLayer path for atom_feature_size == 64 (mp_split.hip): XCD-aware gather kernels + tall GEMMs
 bool mp_split_enabled(int F, int E);
 int mp_split_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,

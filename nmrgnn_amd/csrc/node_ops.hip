@@ -670,6 +670,14 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, (E * F) % 8 == 0, "mp_layer: (E*F) % 8");
   // F == 64: NG_MP_PATH = split (default) | fused | layered  — see mp_split.hip for the comparison
+  if (N > 0 && mp_win_enabled(F, E, K)) {
+    // the window kernel never materialises the aggregate; a caller that asks for it gets a separate pass
+    if (A_save) {
+      const int rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, A_save);
+      if (rc) return rc;
+    }
+    return mp_win_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, s_save);
+  }
   if (N > 0 && mp_split_enabled(F, E))
     return mp_split_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, A_save,
                         s_save);

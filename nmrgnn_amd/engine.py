@@ -134,7 +134,7 @@ class Engine:
             A = self._new(N, E, F) if training else None
             S = self._new(N, F) if (training and self.mp_act != 0) else None
             self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
-                                         ptr(batch.nlist), ptr(e), ptr(batch.inv_degree),
+                                         ptr(batch.nlist_c), ptr(e), ptr(batch.inv_degree),
                                          ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A), ptr(S)),
                      "ng_mp_layer_fwd")
             hs.append(hn)
@@ -209,7 +209,7 @@ class Engine:
         dh = dx
         for l in reversed(range(self.L)):
             dhn = self._new(N, F)
-            self._ck(lib.ng_mp_layer_bwd(h, st, N, K, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.nlist),
+            self._ck(lib.ng_mp_layer_bwd(h, st, N, K, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.nlist_c),
                                          ptr(tp.e), ptr(b.inv_degree), ptr(P[f"mp/{l}/w"]),
                                          ptr(tp.A[l]), ptr(tp.S[l]), ptr(csc_ptr), ptr(csc_edge),
                                          ptr(dh), ptr(dhn), ptr(de), 0 if l == self.L - 1 else 1,

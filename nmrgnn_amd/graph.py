@@ -53,6 +53,11 @@ class GraphBatch:
         self.graph_ptr = torch.as_tensor(self.graph_ptr_host, device=self.device)
         self.G = len(self.graph_ptr_host) - 1
         self._csc = None
+        # compute-side copy of the lists: padded slots (edges == 0, weight exactly 0 after the edge mask)
+        # point at the atom itself instead of row 0, so that the row range a tile of atoms references
+        # stays local and the window-resident MP kernels (csrc/mp_win.hip) can keep it in LDS
+        own = torch.arange(self.N, dtype=torch.int32, device=self.device)[:, None]
+        self.nlist_c = torch.where(self.edges > 0, self.nlist, own).contiguous()
 
     @property
     def n_edges(self):

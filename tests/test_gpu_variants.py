@@ -9,7 +9,7 @@ from helpers import make_hp, small_batch, randomize_biases, rel_err
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [
-    {"NG_MP_PATH": "fused"}, {"NG_MP_PATH": "layered"}, {"NG_EDGE_BWD": "v2"}, {"NG_EDGE_FWD": "tm32"},
+    {"NG_MP_PATH": "win"}, {"NG_MP_PATH": "split"}, {"NG_MP_PATH": "fused"}, {"NG_MP_PATH": "layered"}, {"NG_EDGE_BWD": "v2"}, {"NG_EDGE_FWD": "tm32"},
     {"NG_EDGE_PATH": "layered"}, {"NG_DENSE_PATH": "generic"},
     {"NG_MP_PATH": "layered", "NG_AGG_PATH": "window"},
 ]
@@ -45,3 +45,47 @@ def test_variant_matches_default(gpu_device, monkeypatch, env):
     assert np.max(np.abs(var[1] - base[1])) < 5e-5
     for k in base[2]:
         assert rel_err(var[2][k], base[2][k]) < 2e-4, k
+
+
+@pytest.mark.parametrize("N,K,E,span", [(1000, 16, 3, 200), (1000, 16, 3, 0), (333, 5, 2, 100), (70, 24, 1, 0),
+                                        (4096, 16, 3, 256), (31, 16, 3, 0)])
+@pytest.mark.parametrize("path", ["win", "split"])
+def test_mp_layer_paths_vs_numpy(gpu_device, monkeypatch, path, N, K, E, span):
+    """ng_mp_layer_fwd on the F=64 fast paths: local neighbour windows (span > 0: neighbours within
+    +-span rows -> LDS window, incl. restaging as the run moves), unrestricted lists (span = 0 -> the
+    global-gather branch), padded slots, ragged tails, K % 4 != 0."""
+    import ctypes as C
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    monkeypatch.setenv("NG_MP_PATH", path)
+    rng = np.random.default_rng(N + K)
+    F = 64
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    if span:
+        base = np.arange(N)[:, None]
+        nl = np.clip(base + rng.integers(-span // 2, span // 2, (N, K)), 0, N - 1).astype(np.int32)
+    else:
+        nl = rng.integers(0, N, (N, K)).astype(np.int32)
+    e = rng.standard_normal((N, K, E)).astype(np.float32)
+    pad = rng.random((N, K)) < 0.1
+    e[pad] = 0.0
+    nl[pad] = 0                                        # padded slots point at row 0 (far outside any window)
+    inv = rng.random(N).astype(np.float32)
+    w = (rng.standard_normal((F, F, E)) * 0.1).astype(np.float32)
+    P = np.einsum("ijn,ijl,lmn,i->im", e.astype(np.float64), h.astype(np.float64)[nl], w.astype(np.float64),
+                  inv.astype(np.float64))
+    ref = np.log1p(np.exp(-np.abs(P))) + np.maximum(P, 0) + h
+    refA = np.einsum("ijn,ijl->inl", e.astype(np.float64), h.astype(np.float64)[nl])
+    dev = gpu_device
+    th, tn, te, ti, tw = (torch.from_numpy(x).to(dev) for x in (h, nl, e, inv, w))
+    out = torch.empty(N, F, device=dev)
+    A = torch.empty(N, E, F, device=dev)
+    S = torch.empty(N, F, device=dev)
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.check(ctx.lib.ng_mp_layer_fwd(ctx.handle, st, N, K, F, E, 1, 1, ptr(th), ptr(tn), ptr(te), ptr(ti),
+                                      ptr(tw), ptr(out), ptr(A), ptr(S)), "mp")
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(A.cpu().numpy(), refA, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(S.cpu().numpy(), ref - h, rtol=2e-5, atol=2e-5)
