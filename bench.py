@@ -64,6 +64,8 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C):
         "mp_aggregate": ("hbm", 2.0 * N * K * F * E, f4 * N * (F + K + K * E + F * E)),
         "mp_aggregate_csc": ("hbm", 2.0 * N * K * F * E, f4 * N * (F + 2 * K + K * E + F * E)),
         "mp_update_fwd": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + 3 * F + 1)),
+        # window-resident fused forward (mp_win.hip): gather + GEMM, the aggregate never leaves the CU
+        "mp_win_fwd": ("mfma", 2.0 * N * (K * F * E + KF * F), f4 * N * (3 * F + K + K * E + 1) + f4 * KF * F),
         "mp_fused_fwd": ("hbm", 2.0 * N * (K * F * E + KF * F), f4 * N * (3 * F + K + K * E + 1 + KF)),
         "mp_dw": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + F)),
         "mp_dA": ("mfma", 2.0 * N * KF * F, f4 * N * (3 * F + 1 + KF)),

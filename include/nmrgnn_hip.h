@@ -108,6 +108,12 @@ int ng_mp_aggregate(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const
 int ng_mp_layer_fwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act, int residual,
                     const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
                     const float* w, float* h_out, float* A_save, float* s_save);
+/* 1 when the backward pass of the kernel path selected for (F, E, K) reads the forward aggregate
+ * (pass a [N,E,F] buffer as A_save to ng_mp_layer_fwd and hand it to ng_mp_layer_bwd), 0 when it does
+ * not (pass NULL to both: the weight gradient is formed from h and the incoming-edge aggregate of dP).
+ * A_save == NULL is always accepted by ng_mp_layer_bwd; paths that need the aggregate rebuild it. */
+int ng_mp_layer_wants_aggregate(int F, int E, int K);
+
 /* backward of the above.  csc_ptr[N+1], csc_edge[nnz]: incoming-edge lists (edge id = i*K+j
  * grouped by target nlist[i,j]); dh_out [N,F] upstream; writes dh_in (overwrite),
  * de (accumulate if de_accum else overwrite), dw [F,F,E] (overwrite). */

@@ -1,0 +1,257 @@
+// Bandwidth-shaped versions of the small node-side kernels around the hot path: embedding weight
+// gradient, output head forward / backward.  Reference: nmrgnn/model.py:239-243,262,266-273.
+//
+// All of them stream [N, F] activations once (whole 16-byte vectors, a row's lanes side by side) and
+// keep the C-wide (number of elements <= 32) one-hot / standardisation arithmetic in registers:
+//   head   peaks_i = <x_i, u_i> + v_i,   u_i[f] = sum_c a_ic std_c Wout[f][c],  v_i = sum_c a_ic (std_c b_c + avg_c)
+//          dg_i[f] = mask * dpeaks_i * u_i[f]
+//          dWout[f][c] = sum_i x_i[f] dpeaks_i a_ic std_c,   dbout[c] = sum_i dpeaks_i a_ic std_c
+//   embed  dWemb[c][f] = sum_i a_ic dh0_i[f]
+// `a` is read as general floats (the reference feeds one-hot rows but does not require it).
+// Weight-gradient sums are two-stage and deterministic: per-workgroup partials, then reduce_z.
+#include <algorithm>
+
+#include "mfma_gemm.cuh"
+#include "ng_internal.h"
+#include "reduce.cuh"
+
+namespace ng {
+
+constexpr int HC_MAX = 32;     // one-hot width limit
+
+// quad / row reductions on the DPP network
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over aligned groups of 8 lanes (valid in every lane of the group)
+__device__ __forceinline__ float sum8(float v) {
+  v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);      // row_half_mirror: lane i <-> 7 - i within each half row
+  return v;
+}
+
+// ---- head forward: LPR lanes per row, one float4 of the Fh features each --------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, const float* __restrict__ g,
+                                                            const float* __restrict__ mask,
+                                                            const float* __restrict__ Wout,
+                                                            const float* __restrict__ bout,
+                                                            const float* __restrict__ atoms,
+                                                            const float* __restrict__ pstd,
+                                                            const float* __restrict__ pavg,
+                                                            float* __restrict__ peaks) {
+  constexpr int Fh = LPR * 4;
+  __shared__ float sWs[Fh * HC_MAX];     // std_c * Wout[f][c]
+  __shared__ float sV[HC_MAX];           // std_c * b_c + avg_c
+  for (int t = threadIdx.x; t < Fh * C; t += 256) sWs[t] = Wout[t] * pstd[t % C];
+  if (threadIdx.x < C) sV[threadIdx.x] = pstd[threadIdx.x] * bout[threadIdx.x] + pavg[threadIdx.x];
+  __syncthreads();
+  const int q = threadIdx.x % LPR;
+  const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / LPR);
+  for (int64_t i = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; i < N; i += rows_per_pass) {
+    float4 x = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
+    if (mask) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q);
+      x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+    }
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, v = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float a = atoms[i * C + c];
+      u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
+      u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
+      v += a * sV[c];
+    }
+    float p = x.x * u0 + x.y * u1 + x.z * u2 + x.w * u3;
+    p = sum8(p);
+    if (LPR == 16) p += __shfl_xor(p, 8, 64);
+    if (q == 0) peaks[i] = p + v;
+  }
+}
+
+// ---- head backward: dg + per-workgroup partials of [dWout ; dbout] ---------------------------------------
+// thread = (row lane r = tid / LPR, column lane q); accumulators acc[c][4] for its four f's, plus db[c] on q == 0
+template <int LPR, int CM>
+__global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t N, int C, int64_t rows_per_block,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ mask,
+                                                            const float* __restrict__ Wout,
+                                                            const float* __restrict__ atoms,
+                                                            const float* __restrict__ pstd,
+                                                            const float* __restrict__ dpeaks,
+                                                            float* __restrict__ dg, float* __restrict__ partial) {
+  constexpr int Fh = LPR * 4;
+  constexpr int RL = 256 / LPR;          // row lanes
+  __shared__ float sWs[Fh * HC_MAX];
+  __shared__ float sStd[HC_MAX];
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [RL][Fh*C + C] for the final sum
+  for (int t = threadIdx.x; t < Fh * C; t += 256) sWs[t] = Wout[t] * pstd[t % C];
+  if (threadIdx.x < C) sStd[threadIdx.x] = pstd[threadIdx.x];
+  __syncthreads();
+  const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+  float acc[CM][4];
+  float db[CM];
+#pragma unroll
+  for (int c = 0; c < CM; ++c) { acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f; db[c] = 0.f; }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
+  for (int64_t i = r0 + r; i < r1; i += RL) {
+    float4 x = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask) m = *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q);
+    x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+    const float dp = dpeaks[i];
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+      if (c < C) {
+        const float a = atoms[i * C + c];
+        u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
+        u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
+        const float d = dp * a * sStd[c];            // dfull[i][c]
+        acc[c][0] += x.x * d; acc[c][1] += x.y * d; acc[c][2] += x.z * d; acc[c][3] += x.w * d;
+        db[c] += d;
+      }
+    }
+    *reinterpret_cast<float4*>(dg + i * Fh + 4 * q) = make_float4(m.x * dp * u0, m.y * dp * u1, m.z * dp * u2,
+                                                                  m.w * dp * u3);
+  }
+  // sum over the row lanes through LDS, one partial per workgroup: layout [f*C + c] then [Fh*C + c]
+  const int items = Fh * C + C;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) {
+    if (c < C) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) red[r * items + (4 * q + s) * C + c] = acc[c][s];
+      if (q == 0) red[r * items + Fh * C + c] = db[c];
+    }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < items; it += 256) {
+    float s = 0.f;
+    for (int rr = 0; rr < RL; ++rr) s += red[rr * items + it];
+    partial[(int64_t)blockIdx.x * items + it] = s;
+  }
+}
+
+// ---- embedding weight gradient --------------------------------------------------------------------------
+// thread = (row lane, float4 column); acc[c] float4 per thread
+template <int CM>
+__global__ __launch_bounds__(256) void embed_bwd_fast_kernel(int64_t N, int C, int F, int64_t rows_per_block,
+                                                             const float* __restrict__ atoms,
+                                                             const float* __restrict__ dh0,
+                                                             float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [RL][C*F]
+  const int c4n = F / 4;
+  const int RL = 256 / c4n;
+  const int q = threadIdx.x % c4n, r = threadIdx.x / c4n;
+  float4 acc[CM];
+#pragma unroll
+  for (int c = 0; c < CM; ++c) acc[c] = f4zero();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
+  for (int64_t i = r0 + r; i < r1; i += RL) {
+    const float4 d = *reinterpret_cast<const float4*>(dh0 + i * F + 4 * q);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+      if (c < C) {
+        const float a = atoms[i * C + c];
+        acc[c].x += a * d.x; acc[c].y += a * d.y; acc[c].z += a * d.z; acc[c].w += a * d.w;
+      }
+    }
+  }
+  const int items = C * F;
+#pragma unroll
+  for (int c = 0; c < CM; ++c)
+    if (c < C) *reinterpret_cast<float4*>(red + r * items + c * F + 4 * q) = acc[c];
+  __syncthreads();
+  for (int it = threadIdx.x; it < items; it += 256) {
+    float s = 0.f;
+    for (int rr = 0; rr < RL; ++rr) s += red[rr * items + it];
+    partial[(int64_t)blockIdx.x * items + it] = s;
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+static bool fast_enabled() {
+  const char* v = getenv("NG_HEAD_PATH");
+  return !(v && std::string(v) == "generic");
+}
+
+bool head_fast_supported(int Fh, int C) {
+  if (!(fast_enabled() && (Fh == 32 || Fh == 64) && C >= 1 && C <= HC_MAX)) return false;
+  return (size_t)(256 / (Fh / 4)) * (Fh * C + C) * 4 <= 96 * 1024;     // LDS of the backward's final sum
+}
+
+int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
+                  const float* Wout, const float* bout, const float* atoms, const float* pstd,
+                  const float* pavg, float* peaks) {
+  const int lpr = Fh / 4;
+  const int64_t rpb = 256 / lpr;
+  const int grid = (int)std::min<int64_t>(cdiv(N, rpb), (int64_t)ctx->num_cu * 8);
+  ProfScope ps(ctx, st, "head_fwd");
+  if (lpr == 8)
+    hipLaunchKernelGGL((head_fwd_fast_kernel<8>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, atoms,
+                       pstd, pavg, peaks);
+  else
+    hipLaunchKernelGGL((head_fwd_fast_kernel<16>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout,
+                       atoms, pstd, pavg, peaks);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
+                  const float* Wout, const float* atoms, const float* pstd, const float* dpeaks, float* dg,
+                  float* dWout, float* dbout) {
+  const int lpr = Fh / 4, rl = 256 / lpr;
+  const int items = Fh * C + C;
+  const int grid = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 2);
+  const int64_t rows = cdiv(cdiv(N, grid), rl) * rl;
+  const int nb = (int)cdiv(N, rows);
+  float* ws = (float*)workspace(ctx, (size_t)(nb + 1) * items * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* partial = ws;
+  float* summed = ws + (size_t)nb * items;
+  const size_t lds = (size_t)rl * items * 4;
+  ProfScope ps(ctx, st, "head_bwd");
+#define NG_HB(L, CM)                                                                                      \
+  hipLaunchKernelGGL((head_bwd_fast_kernel<L, CM>), dim3(nb), dim3(256), lds, st, N, C, rows, g, mask, Wout, \
+                     atoms, pstd, dpeaks, dg, partial)
+  if (lpr == 8) { if (C <= 16) NG_HB(8, 16); else NG_HB(8, 32); }
+  else { if (C <= 16) NG_HB(16, 16); else NG_HB(16, 32); }
+#undef NG_HB
+  launch_reduce_z(st, partial, nb, items, summed);
+  NG_HIP(ctx, hipMemcpyAsync(dWout, summed, (size_t)Fh * C * 4, hipMemcpyDeviceToDevice, st));
+  NG_HIP(ctx, hipMemcpyAsync(dbout, summed + (size_t)Fh * C, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+bool embed_bwd_fast_supported(int F, int C) {
+  // LDS for the final sum: (256 / (F/4)) * C * F floats
+  return fast_enabled() && F % 4 == 0 && F >= 16 && F <= 256 && 256 % (F / 4) == 0 && C >= 1 && C <= HC_MAX &&
+         (size_t)(256 / (F / 4)) * C * F * 4 <= 64 * 1024;
+}
+
+int embed_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int C, int F, const float* atoms, const float* dh0,
+                   float* dWemb) {
+  const int rl = 256 / (F / 4);
+  const int items = C * F;
+  const int grid = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 2);
+  const int64_t rows = cdiv(cdiv(N, grid), rl) * rl;
+  const int nb = (int)cdiv(N, rows);
+  float* partial = (float*)workspace(ctx, (size_t)nb * items * 4);
+  if (!partial) return NG_ERR_NOMEM;
+  const size_t lds = (size_t)rl * items * 4;
+  ProfScope ps(ctx, st, "embed_bwd");
+  if (C <= 16)
+    hipLaunchKernelGGL((embed_bwd_fast_kernel<16>), dim3(nb), dim3(256), lds, st, N, C, F, rows, atoms, dh0, partial);
+  else
+    hipLaunchKernelGGL((embed_bwd_fast_kernel<32>), dim3(nb), dim3(256), lds, st, N, C, F, rows, atoms, dh0, partial);
+  launch_reduce_z(st, partial, nb, items, dWemb);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+}  // namespace ng

@@ -377,10 +377,6 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
 #undef CALL
     NG_HIP(ctx, hipGetLastError());
   }
-  // dw[l][m][n] = sum_i A[i][(n,l)] dP[i][m]
-  rc = tall_tn(ctx, st, N, A_save, KF, KF, dP, SF, SF, nullptr, NG_ACT_NONE, dw, nullptr, 1, SF, E, scr,
-               "mp_dw");
-  if (rc) return rc;
   if (N > 0) {   // B = aggregation of dP over the incoming edges
     ProfScope ps(ctx, st, "mp_aggregate_csc");
     const dim3 grid((unsigned)cdiv(N, SAPB));
@@ -391,6 +387,10 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
 #undef CALL
     NG_HIP(ctx, hipGetLastError());
   }
+  // dw[l][m][n] = sum_i v_i A[i][(n,l)] dP'[i][m] = sum_t h[t][l] B[t][(n,m)]  — the aggregate A of the
+  // forward pass is not needed: the incoming-edge aggregate B of dP carries the same sum
+  rc = tall_tn(ctx, st, N, dAB, KF, KF, h, SF, SF, nullptr, NG_ACT_NONE, dw, nullptr, 2, SF, E, scr, "mp_dw");
+  if (rc) return rc;
   TallArgs b{};
   b.N = N; b.X = dAB; b.ldx = KF; b.k_valid = KF; b.Wfrag = WfragN; b.act = NG_ACT_NONE;
   b.resid = dh_out; b.out = dh_in; b.ldo = SF; b.n_valid = SF;

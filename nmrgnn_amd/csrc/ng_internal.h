@@ -101,4 +101,16 @@ int aggregate_window(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
                      const int32_t* nlist, const float* e, float* A);
 int aggregate_window_csc(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* src,
                          const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, float* B);
+// bandwidth-shaped head / embedding kernels (head_ops.hip); NG_HEAD_PATH=generic selects the old ones
+bool head_fast_supported(int Fh, int C);
+int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
+                  const float* Wout, const float* bout, const float* atoms, const float* pstd,
+                  const float* pavg, float* peaks);
+int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
+                  const float* Wout, const float* atoms, const float* pstd, const float* dpeaks, float* dg,
+                  float* dWout, float* dbout);
+bool embed_bwd_fast_supported(int F, int C);
+int embed_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int C, int F, const float* atoms, const float* dh0,
+                   float* dWemb);
+
 }  // namespace ng

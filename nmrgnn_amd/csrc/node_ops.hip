@@ -640,6 +640,7 @@ extern "C" int ng_embed_bwd(ng_ctx* ctx, void* stream, int64_t N, int C, int F, 
     NG_HIP(ctx, hipMemsetAsync(dWemb, 0, items * 4, st));
     return NG_OK;
   }
+  if (embed_bwd_fast_supported(F, C)) return embed_bwd_fast(ctx, st, N, C, F, atoms, dh0, dWemb);
   // dWemb[c][f] = sum_i atoms[i][c] dh0[i][f]: small transposed product, rows staged through LDS
   const int64_t rows = 512;
   const int64_t nb = cdiv(N, rows);
@@ -701,6 +702,12 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
                    "mp_update_fwd");
 }
 
+extern "C" int ng_mp_layer_wants_aggregate(int F, int E, int K) {
+  (void)K;
+  if (mp_split_enabled(F, E)) return 0;      // dw comes from h^T B (incoming-edge aggregate of dP)
+  return 1;
+}
+
 extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
                                const float* h, const int32_t* nlist, const float* e,
                                const float* inv_degree, const float* w, const float* A_save,
@@ -709,7 +716,6 @@ extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
                                float* dw) {
   if (!ctx) return NG_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  NG_REQUIRE(ctx, A_save, "mp_layer_bwd: A_save required");
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
              "mp_layer_bwd: F in {16,32,64,128,256}");
@@ -717,19 +723,27 @@ extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   if (N > 0 && mp_split_enabled(F, E))
     return mp_split_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
                         csc_edge, dh_out, dh_in, de, de_accum, dw);
-  if (N > 0 && mp_fused_enabled(F, E))
+  if (N > 0 && mp_fused_enabled(F, E)) {
+    NG_REQUIRE(ctx, A_save, "mp_layer_bwd: the fused path needs the aggregate saved by the forward pass");
     return mp_fused_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
                         csc_edge, dh_out, dh_in, de, de_accum, dw);
+  }
   const int64_t KF = (int64_t)E * F;
   const float* S = s_save;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
-  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr) * 4);
+  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;
   float* Wp = ws;
   float* dA = ws + KF * F;
   float* scr = dA + N * KF;
   int rc = mp_repack_w(ctx, st, F, E, w, Wp);
   if (rc) return rc;
+  if (!A_save) {   // the caller did not keep the forward aggregate: rebuild it
+    float* Ar = scr + dw_scr;
+    rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, Ar);
+    if (rc) return rc;
+    A_save = Ar;
+  }
   // dw[l][m][n] = sum_i A[i][(n,l)] dP[i][m],   dP = dh_out * act'(P) * inv
   rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, S, inv_degree, dw, nullptr, 1, F, E, scr,
                 "mp_dw");
@@ -772,6 +786,9 @@ extern "C" int ng_head_fwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, C >= 1 && C <= MAX_C, "head: number of elements <= 32");
   if (N == 0) return NG_OK;
+  if (head_fast_supported(Fh, C))
+    return head_fwd_fast(ctx, (hipStream_t)stream, N, Fh, C, g, drop_mask, Wout, bout, atoms, peak_std,
+                         peak_avg, peaks);
   ProfScope ps(ctx, (hipStream_t)stream, "head_fwd");
   hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), (size_t)Fh * C * 4,
                      (hipStream_t)stream, N, Fh, C, g, drop_mask, Wout, bout, atoms, peak_std,
@@ -793,6 +810,8 @@ extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
     NG_HIP(ctx, hipMemsetAsync(dbout, 0, (size_t)C * 4, st));
     return NG_OK;
   }
+  if (head_fast_supported(Fh, C))
+    return head_bwd_fast(ctx, st, N, Fh, C, g, drop_mask, Wout, atoms, peak_std, dpeaks, dg, dWout, dbout);
   const int64_t rows = 512;
   const int64_t nb = cdiv(N, rows);
   float* ws = (float*)workspace(ctx, (size_t)(nb * items + items) * 4);

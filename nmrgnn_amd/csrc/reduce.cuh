@@ -32,6 +32,10 @@ static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __re
       const int k = (int)(idx / Nout), m = (int)(idx % Nout);
       const int ne = k / F, l = k % F;
       o = ((int64_t)l * F + m) * E + ne;
+    } else if (w_map == 2) {   // MPLayer weight from h^T B: idx = k*Nout + l with k = ne*F + m
+      const int k = (int)(idx / Nout), l = (int)(idx % Nout);
+      const int ne = k / F, m = k % F;
+      o = ((int64_t)l * F + m) * E + ne;
     }
     out[o] = t;
   }

@@ -182,9 +182,10 @@ int tall_tn(ng_ctx* ctx, hipStream_t st, int64_t N, const float* A, int lda, int
     NG_HIP(ctx, hipGetLastError());
   }
   ProfScope ps(ctx, st, "reduce_partials");
-  if (w_map == 1) {
-    // MPLayer: idx = k*64 + m with k = ne*F + l  ->  dw[(l*F + m)*E + ne]   (kb_valid == 64 == F)
-    launch_reduce_z(st, partial, grid, (int64_t)ka_valid * TN_KB, dW, 1, F, E, TN_KB, stride);
+  if (w_map == 1 || w_map == 2) {
+    // MPLayer: idx = k*64 + c;  w_map 1: k = ne*F + l, c = m;  w_map 2: k = ne*F + m, c = l
+    //          ->  dw[(l*F + m)*E + ne]   (kb_valid == 64 == F)
+    launch_reduce_z(st, partial, grid, (int64_t)ka_valid * TN_KB, dW, w_map, F, E, TN_KB, stride);
   } else if (kb_valid == TN_KB && ka_valid == kap) {
     launch_reduce_z(st, partial, grid, (int64_t)stride, dense, 0);
     NG_HIP(ctx, hipMemcpyAsync(dW, dense, (size_t)ka_valid * TN_KB * 4, hipMemcpyDeviceToDevice, st));

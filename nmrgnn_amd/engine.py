@@ -131,7 +131,7 @@ class Engine:
         hs, As, Ss = [h0], [], []
         for l in range(self.L):
             hn = self._new(N, F)
-            A = self._new(N, E, F) if training else None
+            A = self._new(N, E, F) if (training and lib.ng_mp_layer_wants_aggregate(F, E, K)) else None
             S = self._new(N, F) if (training and self.mp_act != 0) else None
             self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
                                          ptr(batch.nlist_c), ptr(e), ptr(batch.inv_degree),
