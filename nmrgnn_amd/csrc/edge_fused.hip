@@ -59,6 +59,7 @@ struct EdgeFwdArgs {
   const float* d_eff;
   const float* centers;
   float neg_inv_gap;
+  float neg_inv_gap_log2e;   // -log2(e)/gap
   const float* Wpk;       // [3][4][16][64][4]
   const float* bh[3];     // hidden biases
   const float* Wo;        // [128][E]
@@ -82,12 +83,26 @@ __device__ __forceinline__ void load_wfrag(float (&wf)[64], const float* __restr
 // 32-63 (an MFMA occupies the matrix pipe for 64 cycles after it issues, so the VALU work rides under
 // it), leaving only the second half's epilogue exposed.  After the MFMA chain the slab registers are
 // dead: the NEXT layer's slab is loaded into them, its L2 latency hiding under that last epilogue.
-__device__ __forceinline__ void epilogue_q(const f32x16& acc, int q, const float* __restrict__ bias,
-                                           float* __restrict__ dst) {
-  const float4 bv = *reinterpret_cast<const float4*>(bias + 8 * q);
+// fp32 MFMA and VALU share the SIMD's issue (tools/ubench: no overlap, not even across the two waves of a
+// SIMD), so every epilogue instruction is matrix time lost.  The bias therefore enters as the INITIAL
+// accumulator value (no add per element), and the non-transcendental half of the softplus runs on the
+// packed-fp32 ALU:  softplus(x) = max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e))
+//   per pair: 2 v_mul(|x|) + 2 v_exp + 1 v_pk_add + 2 v_log + 2 v_max + 1 v_pk_fma
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void softplus2(float x0, float x1, float& y0, float& y1) {
+  f32x2e t = {__builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x0)),
+              __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x1))};
+  t = t + f32x2e{1.0f, 1.0f};
+  const f32x2e l = {__builtin_amdgcn_logf(t[0]), __builtin_amdgcn_logf(t[1])};
+  const f32x2e m = {fmaxf(x0, 0.0f), fmaxf(x1, 0.0f)};
+  const f32x2e r = __builtin_elementwise_fma(l, f32x2e{0.6931471805599453f, 0.6931471805599453f}, m);
+  y0 = r[0]; y1 = r[1];
+}
+
+__device__ __forceinline__ void epilogue_q(const f32x16& acc, int q, float* __restrict__ dst) {
   float4 v;
-  v.x = softplus_fast(acc[4 * q + 0] + bv.x); v.y = softplus_fast(acc[4 * q + 1] + bv.y);
-  v.z = softplus_fast(acc[4 * q + 2] + bv.z); v.w = softplus_fast(acc[4 * q + 3] + bv.w);
+  softplus2(acc[4 * q + 0], acc[4 * q + 1], v.x, v.y);
+  softplus2(acc[4 * q + 2], acc[4 * q + 3], v.z, v.w);
   *reinterpret_cast<float4*>(dst + 8 * q) = v;
 }
 
@@ -96,16 +111,19 @@ __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __res
                                              const float* __restrict__ bias, int wave, int lane,
                                              const float* __restrict__ Wpk, int next_layer) {
   const int half = lane >> 5, l31 = lane & 31;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   const float* x0 = Xin + l31 * FLD + half * 4;
   const float* x1 = x0 + 32 * FLD;
   // lane holds, for rows l31 and 32+l31, columns 32*wave + 8q + 4*half + (0..3)
   const int ncol = 32 * wave + 4 * half;
-  const float* bcol = bias + ncol;
   float* o0 = Xout + l31 * FLD + ncol;
   float* o1 = o0 + 32 * FLD;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {          // accumulators start at the bias of their output column
+    const float4 bv = *reinterpret_cast<const float4*>(bias + ncol + 8 * q);
+    acc0[4 * q + 0] = bv.x; acc0[4 * q + 1] = bv.y; acc0[4 * q + 2] = bv.z; acc0[4 * q + 3] = bv.w;
+    acc1[4 * q + 0] = bv.x; acc1[4 * q + 1] = bv.y; acc1[4 * q + 2] = bv.z; acc1[4 * q + 3] = bv.w;
+  }
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const float4 a = *reinterpret_cast<const float4*>(x0 + 8 * t);
@@ -119,13 +137,13 @@ __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __res
     const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * t);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 0], b.x, acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 1], b.y, acc1, 0, 0, 0);
-    if ((t & 3) == 1) epilogue_q(acc0, t >> 2, bcol, o0);   // rides under the surrounding MFMAs
+    if ((t & 3) == 1) epilogue_q(acc0, t >> 2, o0);   // interleaved: its exp/log latency hides here
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 2], b.z, acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[4 * t + 3], b.w, acc1, 0, 0, 0);
   }
   load_wfrag(wf, Wpk, next_layer, wave, lane);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) epilogue_q(acc1, q, bcol, o1);
+  for (int q = 0; q < 4; ++q) epilogue_q(acc1, q, o1);
 }
 
 // copy a finished [64][128] LDS tile to global as whole rows (wave w: rows 16w .. 16w+15)
@@ -167,6 +185,13 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
   float wf[64];
   load_wfrag(wf, a.Wpk, 0, wave, lane);
 
+  // distances of the NEXT tile are requested one tile ahead (clamped index, no conditional VMEM): read at
+  // the point of use they exposed a full HBM latency at the head of every tile
+  float ds_n, de_n;
+  {
+    const int64_t g0 = std::min<int64_t>((int64_t)blockIdx.x * FTM + (tid & 63), a.n_edges - 1);
+    ds_n = a.d_src[g0]; de_n = a.d_eff[g0];
+  }
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * FTM;
@@ -174,26 +199,36 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
     {
       const int r = tid & 63;
       const int64_t gr = row0 + r;
-      float ds = 0.f, de = 0.f;
-      if (gr < a.n_edges) { ds = a.d_src[gr]; de = a.d_eff[gr]; }
+      const float ds = gr < a.n_edges ? ds_n : 0.f;
+      const float de = de_n;
       const float m = ds > 0.f ? 1.f : 0.f;
       if (wave == 0) sMask[r] = m;
+      // masked edges: a distance of 1e19 makes every (d - mu)^2 * c overflow to -inf and exp2 return an
+      // exact 0 — the mask costs nothing per element.  c2 = -log2(e)/gap folds __expf's scaling.
+      const float dm = ds > 0.f ? de : 1.0e19f;
+      const f32x2e d2 = {dm, dm};
+      const f32x2e c2 = {a.neg_inv_gap_log2e, a.neg_inv_gap_log2e};
       float* dst = X0 + r * FLD + 32 * wave;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * wave + 4 * i);
-        const float u0 = de - mu.x, u1 = de - mu.y, u2 = de - mu.z, u3 = de - mu.w;
+        f32x2e u0 = d2 - f32x2e{mu.x, mu.y};
+        f32x2e u1 = d2 - f32x2e{mu.z, mu.w};
+        u0 = (u0 * u0) * c2;
+        u1 = (u1 * u1) * c2;
         float4 v;
-        v.x = m * __expf(u0 * u0 * a.neg_inv_gap);
-        v.y = m * __expf(u1 * u1 * a.neg_inv_gap);
-        v.z = m * __expf(u2 * u2 * a.neg_inv_gap);
-        v.w = m * __expf(u3 * u3 * a.neg_inv_gap);
+        v.x = __builtin_amdgcn_exp2f(u0[0]); v.y = __builtin_amdgcn_exp2f(u0[1]);
+        v.z = __builtin_amdgcn_exp2f(u1[0]); v.w = __builtin_amdgcn_exp2f(u1[1]);
         *reinterpret_cast<float4*>(dst + 4 * i) = v;
       }
     }
     NG_LDS_BARRIER();
     // ---- hidden layer 0: X0 -> X1
     hidden_layer(wf, X0, X1, sBias, wave, lane, a.Wpk, 1);
+    {   // issued here they are younger than layer 1's weight slab and a full layer older than layer 2's
+      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * FTM + (tid & 63), a.n_edges - 1);
+      ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
+    }
     NG_LDS_BARRIER();
     if (SAVE) save_tile(X1, a.z_save, row0, a.n_edges, wave, lane);
     // ---- hidden layer 1: X1 -> X0
@@ -264,12 +299,14 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   EdgeFwdArgs a;
   a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
   a.neg_inv_gap = (float)(-1.0 / (double)gap);
+  a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
   a.Wpk = Wpk;
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.Wo = W[3]; a.bo = b[3];
   a.e_out = e_out; a.z_save = z_save;
   const int64_t ntiles = cdiv(n_edges, FTM);
-  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * 2);
+  const char* gm = getenv("NG_EDGE_FWD_WGS");
+  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * (gm ? atoi(gm) : 2));
   const size_t lds = (size_t)(2 * FTM * FLD + FH * FMAX_E + FTM + 4 * FH) * 4;
   ProfScope ps(ctx, st, "edge_fused_fwd");
 #define NG_FW(EE)                                                                                  \
