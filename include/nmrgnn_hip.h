@@ -140,6 +140,23 @@ int ng_amp_attend(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const f
                   const int32_t* nlist, const float* e, const float* inv_degree, const float* wq,
                   const float* wk, float* agg);
 
+/* FCBlock, nmrgnn/model.py:179-196, all layers in one call:
+ *   x_{l+1} = act(x_l @ W[l] + b[l]) + x_l   for l < L-1  (F -> F),   g = act(x_{L-1} @ W[L-1] + b[L-1])  (F -> F/2)
+ * y[l] receives x_{l+1} (l = 0 .. L-2; the tape of the backward pass), g the block output [N,F/2].
+ * W / b / y are host arrays of device pointers.  F == 64 runs one fused kernel; other sizes loop over the
+ * per-layer kernels. */
+int ng_fc_block_fwd(ng_ctx*, void* stream, int64_t N, int F, int L, int act, const float* x,
+                    const float* const* W, const float* const* b, float* const* y, float* g);
+
+/* backward of ng_fc_block_fwd.  x[l] = layer inputs (x[0] = block input, x[l+1] = y[l] of the forward call),
+ * g = block output, dg its gradient; writes dx (gradient w.r.t. x[0]) and dW[l], db[l] (overwrites).  The
+ * activation outputs are rebuilt as x[l+1] - x[l].  scratch: ng_fc_block_scratch_floats(N, F, L) floats. */
+/* floats of scratch ng_fc_block_bwd needs for this shape (0 when the fused kernel handles it) */
+int64_t ng_fc_block_scratch_floats(int64_t N, int F, int L);
+int ng_fc_block_bwd(ng_ctx*, void* stream, int64_t N, int F, int L, int act, const float* const* x,
+                    const float* g, const float* const* W, const float* dg, float* dx, float* const* dW,
+                    float* const* db, float* scratch);
+
 /* keras Dense (+ residual), nmrgnn/model.py:191-196:  Y = act(X@W + b) (+ X if residual)
  *   s_save [M,Nout] = act(X@W+b) written when non-NULL */
 int ng_dense_fwd(ng_ctx*, void* stream, int64_t M, int Kin, int Nout, int act, int residual,

@@ -53,6 +53,9 @@ SIGNATURES = {
     "ng_head_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_head_bwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_mp_layer_wants_aggregate": (_int, [_int, _int, _int]),
+    "ng_fc_block_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "ng_fc_block_scratch_floats": (_i64, [_i64, _int, _int]),
+    "ng_fc_block_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_knn_graph": (_int, [_vp, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _vp]),
     "ng_amp_attend": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_loss_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -347,18 +347,27 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
   const int KF = E * SF;
   const size_t dw_scr = tall_tn_scratch_floats(ctx, KF);
   // scratch: two packed weight copies | dP [N,64] | dA / B [N,KF] (shared) | dw partials
-  float* ws = (float*)workspace(ctx, (size_t)(2 * KF * SF + N * SF + N * KF + dw_scr) * 4);
+  float* ws = (float*)workspace(ctx, (size_t)(2 * KF * SF + N * SF + N * KF + dw_scr + 64) * 4);
   if (!ws) return NG_ERR_NOMEM;
   float* WfragT = ws;
   float* WfragN = WfragT + KF * SF;
   float* dP = WfragN + KF * SF;
   float* dAB = dP + N * SF;
   float* scr = dAB + N * KF;
-  int rc = mp_pack(ctx, st, E, 2, w, WfragT);
+  float* dummy = scr + dw_scr;
+  // NG_MP_BWD=split keeps the two-kernel edge gradient (dA to HBM, then the gather-dot); default is the
+  // window-resident fused kernel of mp_win_bwd.hip when the neighbour count allows it
+  const char* bsel = getenv("NG_MP_BWD");
+  const bool win_edge = mp_win_bwd_supported(SF, E, K) && !(bsel && std::string(bsel) == "split");
+  int rc = win_edge ? mpw_pack(ctx, st, E, 2, w, WfragT) : mp_pack(ctx, st, E, 2, w, WfragT);
   if (rc) return rc;
   rc = mp_pack(ctx, st, E, 1, w, WfragN);
   if (rc) return rc;
-  {   // dP = dH * act'(S) * v (kept) ;  dA = dP Wp^T
+  if (win_edge) {
+    rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum,
+                         dummy);
+    if (rc) return rc;
+  } else {   // dP = dH * act'(S) * v (kept) ;  dA = dP Wp^T
     TallArgs a{};
     a.N = N; a.X = dh_out; a.ldx = SF; a.k_valid = SF;
     a.S_in = act == NG_ACT_NONE ? nullptr : s_save; a.rs_in = inv_degree; a.act_in = act; a.dP_out = dP;
@@ -366,7 +375,7 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
     rc = tall_gemm(ctx, st, SF, KF, a, true, "mp_dA");
     if (rc) return rc;
   }
-  if (N > 0) {
+  if (N > 0 && !win_edge) {
     ProfScope ps(ctx, st, "mp_edge_grad");
     const dim3 grid((unsigned)cdiv(N, 64));
     const size_t lds = (size_t)64 * K * E * 4;

@@ -84,6 +84,12 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
                const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
                float* s_save);
 
+// window-resident backward kernels (mp_win_bwd.hip)
+bool mp_win_bwd_supported(int F, int E, int K);
+int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
+                    const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
+                    const float* dh_out, float* dP, float* de, int de_accum, float* dummy);
+
 // split MPLayer path for atom_feature_size == 64 (mp_split.hip): XCD-aware gather kernels + tall GEMMs
 bool mp_split_enabled(int F, int E);
 int mp_split_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,

@@ -140,21 +140,16 @@ class Engine:
             hs.append(hn)
             As.append(A)
             Ss.append(S)
+        # FC block: every layer in one call; the tape keeps the layer inputs only (nmrgnn/model.py:191-196)
         fx, fs = [hs[-1]], []
         for t in range(self.Lf - 1):
-            y = self._new(N, F)
-            s = self._new(N, F) if training else None
-            self._ck(lib.ng_dense_fwd(h, st, N, F, F, self.fc_act, 1, ptr(fx[-1]),
-                                      ptr(P[f"fc/{t}/kernel"]), ptr(P[f"fc/{t}/bias"]), ptr(y),
-                                      ptr(s)), "ng_dense_fwd")
-            fx.append(y)
-            fs.append(s)
+            fx.append(self._new(N, F))
         Fh = F // 2
         g = self._new(N, Fh)
-        t = self.Lf - 1
-        self._ck(lib.ng_dense_fwd(h, st, N, F, Fh, self.fc_act, 0, ptr(fx[-1]),
-                                  ptr(P[f"fc/{t}/kernel"]), ptr(P[f"fc/{t}/bias"]), ptr(g), None),
-                 "ng_dense_fwd")
+        Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
+        Bfc = [P[f"fc/{t}/bias"] for t in range(self.Lf)]
+        self._ck(lib.ng_fc_block_fwd(h, st, N, F, self.Lf, self.fc_act, ptr(fx[0]), ptr_array(Wfc),
+                                     ptr_array(Bfc), ptr_array(fx[1:]), ptr(g)), "ng_fc_block_fwd")
         mask = None
         if training and self.use_dropout:
             mask = dropout_mask
@@ -192,18 +187,15 @@ class Engine:
                                  ptr(P["out/kernel"]), ptr(b.atoms), ptr(self.peak_std),
                                  ptr(dpeaks), ptr(dg), ptr(P.g("out/kernel")), ptr(P.g("out/bias"))),
                  "ng_head_bwd")
-        t = self.Lf - 1
         dx = self._new(N, F)
-        self._ck(lib.ng_dense_bwd(h, st, N, F, Fh, self.fc_act, 0, ptr(tp.fx[t]),
-                                  ptr(P[f"fc/{t}/kernel"]), ptr(tp.g), ptr(dg), ptr(dx),
-                                  ptr(P.g(f"fc/{t}/kernel")), ptr(P.g(f"fc/{t}/bias"))), "ng_dense_bwd")
-        for t in reversed(range(self.Lf - 1)):
-            dxn = self._new(N, F)
-            self._ck(lib.ng_dense_bwd(h, st, N, F, F, self.fc_act, 1, ptr(tp.fx[t]),
-                                      ptr(P[f"fc/{t}/kernel"]), ptr(tp.fs[t]), ptr(dx), ptr(dxn),
-                                      ptr(P.g(f"fc/{t}/kernel")), ptr(P.g(f"fc/{t}/bias"))),
-                     "ng_dense_bwd")
-            dx = dxn
+        Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
+        ns = int(lib.ng_fc_block_scratch_floats(N, F, self.Lf))
+        scratch = self._new(ns) if ns else None
+        self._ck(lib.ng_fc_block_bwd(h, st, N, F, self.Lf, self.fc_act, ptr_array(tp.fx), ptr(tp.g),
+                                     ptr_array(Wfc), ptr(dg), ptr(dx),
+                                     ptr_array([P.g(f"fc/{t}/kernel") for t in range(self.Lf)]),
+                                     ptr_array([P.g(f"fc/{t}/bias") for t in range(self.Lf)]),
+                                     ptr(scratch)), "ng_fc_block_bwd")
         csc_ptr, csc_edge = b.csc()
         de = self._new(ne, E)
         dh = dx
