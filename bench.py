@@ -66,6 +66,12 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C):
         "mp_update_fwd": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + 3 * F + 1)),
         # window-resident fused forward (mp_win.hip): gather + GEMM, the aggregate never leaves the CU
         "mp_win_fwd": ("mfma", 2.0 * N * (K * F * E + KF * F), f4 * N * (3 * F + K + K * E + 1) + f4 * KF * F),
+        "mp_win_bwd_edge": ("mfma", 2.0 * N * (KF * F + K * F * E), f4 * N * (4 * F + K + 2 * K * E + 1) + f4 * KF * F),
+        "mp_win_bwd_node": ("mfma", 2.0 * N * (K * F * E + 2 * KF * F), f4 * N * (4 * F + 4 * K + 1) + f4 * KF * F),
+        "mp_records": ("hbm", 0.0, f4 * N * K * (1 + E + 4)),
+        # fused FC block (fc_fused.hip): Lf-1 residual layers F->F and the F->F/2 output layer
+        "fc_fused_fwd": ("mfma", 2.0 * N * ((Lf - 1) * F * F + F * Fh), f4 * N * (Lf * F + Fh)),
+        "fc_fused_bwd": ("mfma", 4.0 * N * ((Lf - 1) * F * F + F * Fh), f4 * N * ((Lf + 1) * F + 2 * Fh)),
         "mp_fused_fwd": ("hbm", 2.0 * N * (K * F * E + KF * F), f4 * N * (3 * F + K + K * E + 1 + KF)),
         "mp_dw": ("mfma", 2.0 * N * KF * F, f4 * N * (KF + F)),
         "mp_dA": ("mfma", 2.0 * N * KF * F, f4 * N * (3 * F + 1 + KF)),

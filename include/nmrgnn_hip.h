@@ -123,6 +123,18 @@ int ng_mp_layer_bwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int a
                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out,
                     float* dh_in, float* de, int de_accum, float* dw);
 
+/* Incoming-edge records for ng_mp_layer_bwd_rec: rec[p] = { source atom of CSC entry p (int bits),
+ * e[edge p][0..2] }, 16 bytes per entry, nnz = csc_ptr[N] entries (buffer: 4*N*K floats).  The edge
+ * features are the same for every MPLayer of a backward pass, so the records are built once and shared. */
+int ng_mp_edge_records(ng_ctx*, void* stream, int64_t N, int K, int E, const int32_t* csc_ptr,
+                       const int32_t* csc_edge, const float* e, float* rec);
+/* ng_mp_layer_bwd with the records supplied (csc_rec may be NULL: they are then rebuilt per call) */
+int ng_mp_layer_bwd_rec(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act,
+                    const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
+                    const float* w, const float* A_save, const float* s_save,
+                    const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out,
+                    float* dh_in, float* de, int de_accum, float* dw, const float* csc_rec);
+
 /* ---- graph front end: K nearest neighbours per atom, per frame --------------------------------
  * Replaces the neighbour search behind nmrgnn.universe2graph (nmrgnn/library.py:106-117, external
  * nmrdata.parse_universe) and the per-frame graph construction of eval-struct (main.py:236-243).

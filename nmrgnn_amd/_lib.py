@@ -47,6 +47,9 @@ SIGNATURES = {
                                _vp, _vp, _vp]),
     "ng_mp_layer_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "ng_mp_layer_bwd_rec": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp]),
+    "ng_mp_edge_records": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "ng_dense_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ng_dense_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp]),

@@ -343,7 +343,7 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
                  const int32_t* nlist, const float* e, const float* inv_degree, const float* w,
                  const float* A_save, const float* s_save, const int32_t* csc_ptr,
                  const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
-                 float* dw) {
+                 float* dw, const float* csc_rec) {
   const int KF = E * SF;
   const size_t dw_scr = tall_tn_scratch_floats(ctx, KF);
   // scratch: two packed weight copies | dP [N,64] | dA / B [N,KF] (shared) | dw partials
@@ -361,12 +361,22 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
   const bool win_edge = mp_win_bwd_supported(SF, E, K) && !(bsel && std::string(bsel) == "split");
   int rc = win_edge ? mpw_pack(ctx, st, E, 2, w, WfragT) : mp_pack(ctx, st, E, 2, w, WfragT);
   if (rc) return rc;
-  rc = mp_pack(ctx, st, E, 1, w, WfragN);
+  const bool win_node = win_edge && !(bsel && std::string(bsel) == "edge") && N * K * 4 <= N * KF &&
+                        mp_win_node_scratch_floats(ctx, E) <= dw_scr;
+  rc = win_node ? mpw_pack(ctx, st, E, 1, w, WfragN) : mp_pack(ctx, st, E, 1, w, WfragN);
   if (rc) return rc;
   if (win_edge) {
     rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum,
                          dummy);
     if (rc) return rc;
+    if (win_node) {   // incoming-edge aggregate, dh GEMM and dw in one kernel; dAB's space holds the records
+      if (!csc_rec) {
+        rc = mp_win_records(ctx, st, N, K, E, csc_ptr, csc_edge, e, dAB);
+        if (rc) return rc;
+        csc_rec = dAB;
+      }
+      return mp_win_bwd_node(ctx, st, N, E, h, dP, csc_ptr, csc_rec, WfragN, dh_out, dh_in, dw, scr, dummy);
+    }
   } else {   // dP = dH * act'(S) * v (kept) ;  dA = dP Wp^T
     TallArgs a{};
     a.N = N; a.X = dh_out; a.ldx = SF; a.k_valid = SF;

@@ -312,11 +312,336 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
   }
 }
 
+// ---- node kernel ---------------------------------------------------------------------------------------
+// Incoming-edge records in CSC order, 16 bytes each: { source atom (int bits), e[p][0..2] } — built once
+// per backward pass (the edge features are the same for every layer).
+constexpr int NREC_CAP = 1024;          // records staged per 32-atom tile (mean 16 * 32 = 512)
+
+struct MpWinNodeArgs {
+  int64_t N;
+  int64_t ntiles;
+  int tiles_per_wg;
+  const float* dP;          // [N][64]  (gathered)
+  const float* dH;          // [N][64]  residual term of dh
+  const float* h;           // [N][64]  layer input (for dw)
+  const int32_t* csc_ptr;   // [N+1]
+  const float4* rec;        // [nnz] records
+  const float* WfragN;      // mpw_pack mode 1
+  float* dh;                // [N][64] out
+  float* partial;           // [grid][64*E*64] dw partials, layout [(n,m)][l]
+  float* dummy;
+};
+
+__device__ __forceinline__ void pk_axpy(f32x2& lo, f32x2& hi, float w, const float4& h) {
+  const f32x2 ww = {w, w};
+  lo = __builtin_elementwise_fma(ww, f32x2{h.x, h.y}, lo);
+  hi = __builtin_elementwise_fma(ww, f32x2{h.z, h.w}, hi);
+}
+
+template <int E, int S0, int MODE>
+__device__ __forceinline__ void node_steps4(const char* __restrict__ wbytes, const float4* __restrict__ src4,
+                                            int c, int roff, int gidx, const float (&w)[E], f32x2 (&lo)[E],
+                                            f32x2 (&hi)[E]) {
+  float4 h0, h1, h2, h3;
+  if (MODE == 0) {
+    h0 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 0>(roff));
+    h1 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 1>(roff));
+    h2 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 2>(roff));
+    h3 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 3>(roff));
+  } else {
+    h0 = src4[(int64_t)ror_i<S0 + 0>(gidx) * WC4 + c];
+    h1 = src4[(int64_t)ror_i<S0 + 1>(gidx) * WC4 + c];
+    h2 = src4[(int64_t)ror_i<S0 + 2>(gidx) * WC4 + c];
+    h3 = src4[(int64_t)ror_i<S0 + 3>(gidx) * WC4 + c];
+  }
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 0>(w[n]), h0);
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 1>(w[n]), h1);
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 2>(w[n]), h2);
+#pragma unroll
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 3>(w[n]), h3);
+}
+
+// B[t][(n,m)] for the tile's 32 target atoms: 16 lanes per atom, the atom's incoming records taken 16 at a
+// time (lane c owns record 16*round + c), rotation walk as in the forward gather
+template <int E, int MODE>
+__device__ __forceinline__ void node_gather(int wave, int lane, int wlo, const int* __restrict__ s_ptr,
+                                            const float4* __restrict__ recs, int rec_base,
+                                            float* __restrict__ tb, int ld, const float4* __restrict__ win4,
+                                            const float4* __restrict__ src4) {
+  const int c = lane & 15;
+  const int al = wave * 4 + (lane >> 4);
+  const int p0 = s_ptr[al], cnt = s_ptr[al + 1] - p0;
+  // wave-uniform number of rounds: the largest record count among this wave's four atoms
+  int mx = cnt;
+  mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, false));   // row_bcast15 (rows 1,3)
+  mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, false));   // row_bcast31 (rows 2,3)
+  const int rounds = (__builtin_amdgcn_readlane(mx, 63) + 15) >> 4;
+  const char* wbytes = reinterpret_cast<const char*>(win4) + 16 * c;
+  f32x2 lo[E], hi[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) { lo[n] = f32x2{0.f, 0.f}; hi[n] = f32x2{0.f, 0.f}; }
+#pragma unroll 1
+  for (int r = 0; r < rounds; ++r) {
+    const int q = 16 * r + c;
+    float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < cnt) rc = recs[p0 - rec_base + q];
+    const int src = q < cnt ? __builtin_bit_cast(int, rc.x) : wlo;
+    float w[E];
+    w[0] = rc.y;
+    if (E > 1) w[1] = rc.z;
+    if (E > 2) w[2] = rc.w;
+    const int roff = min(max(src - wlo, 0), WROWS - 1) * (WF * 4);
+    node_steps4<E, 0, MODE>(wbytes, src4, c, roff, src, w, lo, hi);
+    node_steps4<E, 4, MODE>(wbytes, src4, c, roff, src, w, lo, hi);
+    node_steps4<E, 8, MODE>(wbytes, src4, c, roff, src, w, lo, hi);
+    node_steps4<E, 12, MODE>(wbytes, src4, c, roff, src, w, lo, hi);
+  }
+#pragma unroll
+  for (int n = 0; n < E; ++n)
+    *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
+}
+
+template <int E>
+__device__ __noinline__ void node_gather_global(int wave, int lane, const int* s_ptr, const float4* recs,
+                                                int rec_base, float* tb, int ld, const float4* src4) {
+  node_gather<E, 1>(wave, lane, 0, s_ptr, recs, rec_base, tb, ld, nullptr, src4);
+}
+
+template <int E>
+__global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeArgs a) {
+  constexpr int KF = E * WF;
+  constexpr int LD = KF + 4;
+  constexpr int NT = KF / 16;
+  constexpr int NCT = NT / 2;              // dw column tiles per wave: (lt = w & 3) x (NT/2 tiles of half w >> 2)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* win = smem;                                                   // [WROWS][64]   dP rows
+  float* tile = win + WROWS * WF;                                      // [32][LD]      B
+  float* htile = tile + WTA * LD;                                      // [32][SDP_LD]  h rows of the tile
+  float4* s_rec = reinterpret_cast<float4*>(htile + WTA * SDP_LD);     // [2][NREC_CAP]
+  int* s_ptr = reinterpret_cast<int*>(s_rec + 2 * NREC_CAP);           // [2][36]
+  int* ctl = s_ptr + 2 * 36;                                           // [2][16]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t T0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+  const int64_t T1 = std::min<int64_t>(T0 + a.tiles_per_wg, a.ntiles);
+  float* part = a.partial + (int64_t)blockIdx.x * (KF * WF);
+
+  const float4* src4 = reinterpret_cast<const float4*>(a.dP);
+  float4* win4 = reinterpret_cast<float4*>(win);
+  for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
+
+  const int ct = wave & 3, hh = wave >> 2;      // dh: column tile, atom half;  dw: l-tile ct, column half hh
+  float wf[KF / 4];
+  {
+    const float4* p = reinterpret_cast<const float4*>(a.WfragN) + (ct * NT) * 64 + lane;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const float4 v = p[T * 64];
+      wf[4 * T + 0] = v.x; wf[4 * T + 1] = v.y; wf[4 * T + 2] = v.z; wf[4 * T + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < KF / 4; ++i) asm volatile("" : "+v"(wf[i]));
+  }
+  f32x4 accW[NCT];
+#pragma unroll
+  for (int u = 0; u < NCT; ++u) accW[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (T0 < T1) {
+    // per-tile inputs in flight
+    float4 p_rec0, p_rec1, p_h, p_dH;
+    int p_ptr;
+    const int a16 = lane & 15, g4 = lane >> 4;
+    const int col = 16 * ct + 4 * g4;
+    const int64_t nnz = a.csc_ptr[a.N];
+    // The record range of a tile starts at csc_ptr[32 t]; that offset is itself a global load, so it is
+    // fetched one issue ahead (base_next) — a dependent load inside issue() would expose its latency.
+    int p_base, p_end;
+    int base_next = a.csc_ptr[std::min<int64_t>(T0 * WTA, a.N)];
+    auto issue = [&](int64_t t) {          // records + pointers of tile t (calls walk consecutive tiles)
+      const int64_t r0 = t * WTA;
+      const int64_t rp = std::min<int64_t>(r0 + tid, a.N);
+      p_ptr = a.csc_ptr[tid <= WTA ? rp : a.N];
+      p_end = a.csc_ptr[std::min<int64_t>(r0 + WTA, a.N)];
+      p_base = base_next;
+      const int64_t q0 = (int64_t)p_base + tid, q1 = q0 + WTHREADS;
+      p_rec0 = a.rec[q0 < nnz ? q0 : (nnz > 0 ? nnz - 1 : 0)];
+      p_rec1 = a.rec[q1 < nnz ? q1 : (nnz > 0 ? nnz - 1 : 0)];
+      base_next = a.csc_ptr[std::min<int64_t>(r0 + WTA, a.N)];
+    };
+    auto commit = [&](int64_t t) {
+      float4* rc = s_rec + (t & 1) * NREC_CAP;
+      int* pp = s_ptr + (t & 1) * 36;
+      rc[tid] = p_rec0;
+      rc[tid + WTHREADS] = p_rec1;
+      if (tid <= WTA) pp[tid] = p_ptr;
+      // row range over the tile's OWN records only (the staging area also holds the head of later tiles)
+      int lo = 0x7fffffff, hi = -1;
+      const int s0 = __builtin_bit_cast(int, p_rec0.x), s1 = __builtin_bit_cast(int, p_rec1.x);
+      if (p_base + tid < p_end) { lo = s0; hi = s0; }
+      if (p_base + tid + WTHREADS < p_end) { lo = min(lo, s1); hi = max(hi, s1); }
+      lo = wave_min_i32(lo);
+      hi = -wave_min_i32(-hi);
+      if (lane == 63) { ctl[(t & 1) * 16 + wave] = lo; ctl[(t & 1) * 16 + 8 + wave] = hi; }
+    };
+    auto issue_rows = [&](int64_t t) {     // h rows of tile t (dw operand) and this lane's dH chunk (epilogue)
+      const int64_t rh = t * WTA + (tid >> 4);
+      p_h = rh < a.N ? reinterpret_cast<const float4*>(a.h)[rh * WC4 + (tid & 15)] : f4zero();
+      const int64_t rd = t * WTA + 16 * hh + a16;
+      p_dH = *reinterpret_cast<const float4*>(a.dH + (rd < a.N ? rd : a.N - 1) * WF + col);
+    };
+
+    int wlo = -(1 << 30), mode = 0;
+    issue(T0);
+    issue_rows(T0);
+    commit(T0);
+    issue(T0 + 1 < T1 ? T0 + 1 : T0);
+    NG_LDS_BARRIER();
+    if (win_decide(ctl + (T0 & 1) * 16, wlo, mode)) win_stage(win4, src4, wlo, a.N, tid);
+    NG_LDS_BARRIER();
+
+#pragma unroll 1
+    for (int64_t t = T0; t < T1; ++t) {
+      // ---- vector interval: B tile of t; records of t+1 into LDS; h rows of t into LDS; requests for t+2
+      {
+        const int* pp = s_ptr + (t & 1) * 36;
+        const float4* rc = s_rec + (t & 1) * NREC_CAP;
+        const int rec_base = pp[0];
+        const bool fits = pp[WTA] - rec_base <= NREC_CAP;
+        // a tile with more records than the staging area reads them from global memory instead (separate
+        // call sites: the fast path must see an LDS pointer, not a generic one)
+        if (mode == 0 && fits) node_gather<E, 0>(wave, lane, wlo, pp, rc, rec_base, tile, LD, win4, src4);
+        else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4);
+        else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4);
+      }
+      *reinterpret_cast<float4*>(htile + (tid >> 4) * SDP_LD + 4 * (tid & 15)) = p_h;
+      const float4 dHc = p_dH;
+      if (t + 1 < T1) commit(t + 1);
+      issue(t + 2 < T1 ? t + 2 : t);
+      issue_rows(t + 1 < T1 ? t + 1 : t);
+      NG_LDS_BARRIER();
+      // ---- matrix interval: dh = dH + B Wn ;  dw += h^T B
+      {
+        const float* xrow = tile + (16 * hh + a16) * LD + 4 * g4;
+        float4 x[NT];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) x[T] = *reinterpret_cast<const float4*>(xrow + 16 * T);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
+        }
+        const int64_t row = t * WTA + 16 * hh + a16;
+        const float4 v = make_float4(acc0[0] + acc1[0] + dHc.x, acc0[1] + acc1[1] + dHc.y,
+                                     acc0[2] + acc1[2] + dHc.z, acc0[3] + acc1[3] + dHc.w);
+        *reinterpret_cast<float4*>(row < a.N ? a.dh + row * WF + col : a.dummy + col) = v;
+      }
+      {
+        // D[i = l][j = (n,m)] += sum_atoms h[atom][l] B[atom][(n,m)]: l-tile ct, column tiles NCT*hh + u
+        const float* ha = htile + 16 * ct + a16;
+        const float* bb = tile + 16 * (NCT * hh) + a16;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+          const int ro = (T & 3) + 4 * g4 + 16 * (T >> 2);
+          const float av = ha[ro * SDP_LD];
+#pragma unroll
+          for (int u = 0; u < NCT; ++u)
+            accW[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb[ro * LD + 16 * u], accW[u], 0, 0, 0);
+        }
+      }
+      bool restage = false;
+      if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * 16, wlo, mode);
+      NG_LDS_BARRIER();
+      if (restage) {
+        win_stage(win4, src4, wlo, a.N, tid);
+        NG_LDS_BARRIER();
+      }
+    }
+  }
+  // ---- dw partial of this workgroup, layout [(n,m)][l]: lane holds l = 16ct + 4(lane>>4) + r, column = 16(NCT*hh+u) + (lane&15)
+  {
+    const int a16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < NCT; ++u) {
+      const int cidx = 16 * (NCT * hh + u) + a16;
+      *reinterpret_cast<float4*>(part + cidx * WF + 16 * ct + 4 * g4) =
+          make_float4(accW[u][0], accW[u][1], accW[u][2], accW[u][3]);
+    }
+  }
+}
+
+__global__ void mp_records_kernel(int64_t N, int K, int E, const int32_t* __restrict__ csc_ptr,
+                                  const int32_t* __restrict__ csc_edge, const float* __restrict__ e,
+                                  float4* __restrict__ rec) {
+  const int64_t nnz = csc_ptr[N];
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+    const int eid = csc_edge[p];
+    float4 r;
+    r.x = __builtin_bit_cast(float, eid / K);
+    r.y = e[(int64_t)eid * E];
+    r.z = E > 1 ? e[(int64_t)eid * E + 1] : 0.f;
+    r.w = E > 2 ? e[(int64_t)eid * E + 2] : 0.f;
+    rec[p] = r;
+  }
+}
+
+size_t node_lds_bytes(int E) {
+  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + WTA * SDP_LD) * 4 + (size_t)2 * NREC_CAP * 16 + (2 * 36 + 32) * 4;
+}
+
 size_t edge_lds_bytes(int K, int E) {
   return (size_t)(WROWS * WF + WTA * (E * WF + 4) + 2 * WTA * SDP_LD + 2 * WTA * K + 32) * 4;
 }
 
 }  // namespace
+
+int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
+                   const int32_t* csc_edge, const float* e, float* rec) {
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, st, "mp_records");
+  const int grid = (int)std::min<int64_t>(cdiv(N * K, 256), (int64_t)ctx->num_cu * 8);
+  hipLaunchKernelGGL(mp_records_kernel, dim3(grid), dim3(256), 0, st, N, K, E, csc_ptr, csc_edge, e,
+                     reinterpret_cast<float4*>(rec));
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E) { return (size_t)(ctx->num_cu + 1) * E * WF * WF; }
+
+// dh_in = dh_out + B Wn,  dw = h^T B  with B the incoming-edge aggregate of dP (never materialised)
+int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
+                    const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
+                    float* dh_in, float* dw, float* scratch, float* dummy) {
+  MpWinNodeArgs a{};
+  a.N = N; a.ntiles = cdiv(N, WTA);
+  int64_t per = cdiv(a.ntiles, ctx->num_cu);
+  per = cdiv(per, 8) * 8;
+  a.tiles_per_wg = (int)per;
+  a.dP = dP; a.dH = dh_out; a.h = h; a.csc_ptr = csc_ptr; a.rec = reinterpret_cast<const float4*>(rec);
+  a.WfragN = WfragN; a.dh = dh_in; a.partial = scratch; a.dummy = dummy;
+  const int grid = (int)cdiv(a.ntiles, per);
+  const size_t lds = node_lds_bytes(E);
+  {
+    ProfScope ps(ctx, st, "mp_win_bwd_node");
+    switch (E) {
+      case 1: hipLaunchKernelGGL((mp_win_bwd_node_kernel<1>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 2: hipLaunchKernelGGL((mp_win_bwd_node_kernel<2>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 3: hipLaunchKernelGGL((mp_win_bwd_node_kernel<3>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    }
+    NG_HIP(ctx, hipGetLastError());
+  }
+  ProfScope ps(ctx, st, "reduce_partials");
+  // partial idx = (n*64 + m)*64 + l  ->  dw[(l*64 + m)*E + n]
+  launch_reduce_z(st, scratch, grid, (int64_t)E * WF * WF, dw, 2, WF, E, WF, (int64_t)E * WF * WF);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
 
 bool mp_win_bwd_supported(int F, int E, int K) {
   return F == WF && E >= 1 && E <= 3 && K % 4 == 0 && K >= 4 && K <= 16;

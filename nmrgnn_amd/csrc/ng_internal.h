@@ -90,6 +90,13 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
                     const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
                     const float* dh_out, float* dP, float* de, int de_accum, float* dummy);
 
+int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
+                   const int32_t* csc_edge, const float* e, float* rec);
+size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E);
+int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
+                    const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
+                    float* dh_in, float* dw, float* scratch, float* dummy);
+
 // split MPLayer path for atom_feature_size == 64 (mp_split.hip): XCD-aware gather kernels + tall GEMMs
 bool mp_split_enabled(int F, int E);
 int mp_split_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,
@@ -99,7 +106,7 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
                  const int32_t* nlist, const float* e, const float* inv_degree, const float* w,
                  const float* A_save, const float* s_save, const int32_t* csc_ptr,
                  const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
-                 float* dw);
+                 float* dw, const float* csc_rec = nullptr);
 
 // LDS-window neighbour aggregation (mp_window.hip)
 bool aggregate_window_supported(int F, int E);

@@ -708,12 +708,36 @@ extern "C" int ng_mp_layer_wants_aggregate(int F, int E, int K) {
   return 1;
 }
 
+extern "C" int ng_mp_edge_records(ng_ctx* ctx, void* stream, int64_t N, int K, int E, const int32_t* csc_ptr,
+                                  const int32_t* csc_edge, const float* e, float* rec) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, E >= 1 && E <= 3, "edge records hold at most 3 edge features");
+  return mp_win_records(ctx, (hipStream_t)stream, N, K, E, csc_ptr, csc_edge, e, rec);
+}
+
+extern "C" int ng_mp_layer_bwd_rec(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
+                                   const float* h, const int32_t* nlist, const float* e,
+                                   const float* inv_degree, const float* w, const float* A_save,
+                                   const float* s_save, const int32_t* csc_ptr, const int32_t* csc_edge,
+                                   const float* dh_out, float* dh_in, float* de, int de_accum,
+                                   float* dw, const float* csc_rec);
+
 extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
                                const float* h, const int32_t* nlist, const float* e,
                                const float* inv_degree, const float* w, const float* A_save,
                                const float* s_save, const int32_t* csc_ptr, const int32_t* csc_edge,
                                const float* dh_out, float* dh_in, float* de, int de_accum,
                                float* dw) {
+  return ng_mp_layer_bwd_rec(ctx, stream, N, K, F, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
+                             csc_edge, dh_out, dh_in, de, de_accum, dw, nullptr);
+}
+
+extern "C" int ng_mp_layer_bwd_rec(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act,
+                                   const float* h, const int32_t* nlist, const float* e,
+                                   const float* inv_degree, const float* w, const float* A_save,
+                                   const float* s_save, const int32_t* csc_ptr, const int32_t* csc_edge,
+                                   const float* dh_out, float* dh_in, float* de, int de_accum,
+                                   float* dw, const float* csc_rec) {
   if (!ctx) return NG_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
@@ -722,7 +746,7 @@ extern "C" int ng_mp_layer_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "mp_layer_bwd: edge_feature_size <= 8");
   if (N > 0 && mp_split_enabled(F, E))
     return mp_split_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
-                        csc_edge, dh_out, dh_in, de, de_accum, dw);
+                        csc_edge, dh_out, dh_in, de, de_accum, dw, csc_rec);
   if (N > 0 && mp_fused_enabled(F, E)) {
     NG_REQUIRE(ctx, A_save, "mp_layer_bwd: the fused path needs the aggregate saved by the forward pass");
     return mp_fused_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,

@@ -198,14 +198,20 @@ class Engine:
                                      ptr(scratch)), "ng_fc_block_bwd")
         csc_ptr, csc_edge = b.csc()
         de = self._new(ne, E)
+        # incoming-edge records (source atom + edge features in CSC order): shared by all MP layers
+        rec = None
+        if E <= 3:
+            rec = self._new(ne, 4)
+            self._ck(lib.ng_mp_edge_records(h, st, N, K, E, ptr(csc_ptr), ptr(csc_edge), ptr(tp.e), ptr(rec)),
+                     "ng_mp_edge_records")
         dh = dx
         for l in reversed(range(self.L)):
             dhn = self._new(N, F)
-            self._ck(lib.ng_mp_layer_bwd(h, st, N, K, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.nlist_c),
+            self._ck(lib.ng_mp_layer_bwd_rec(h, st, N, K, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.nlist_c),
                                          ptr(tp.e), ptr(b.inv_degree), ptr(P[f"mp/{l}/w"]),
                                          ptr(tp.A[l]), ptr(tp.S[l]), ptr(csc_ptr), ptr(csc_edge),
                                          ptr(dh), ptr(dhn), ptr(de), 0 if l == self.L - 1 else 1,
-                                         ptr(P.g(f"mp/{l}/w"))), "ng_mp_layer_bwd")
+                                         ptr(P.g(f"mp/{l}/w")), ptr(rec)), "ng_mp_layer_bwd")
             dh = dhn
         self._ck(lib.ng_embed_bwd(h, st, N, self.C, F, ptr(b.atoms), ptr(dh),
                                   ptr(P.g("embed/kernel"))), "ng_embed_bwd")
