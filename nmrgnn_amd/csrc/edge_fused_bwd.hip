@@ -180,18 +180,21 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   // per-tile inputs are fetched one tile ahead (during phase D of the previous tile) so that phase A
   // never waits on HBM: Z3, Z2 tiles (32 VGPRs) and this thread's d / de scalars
   float4 pzA[4], pzB[4];
-  float pf_ds = 0.f, pf_dn = 0.f, pf_de = 0.f;
+  float pf_ds = 0.f, pf_dn = 0.f, pf_de = 0.f, pf_dm = 0.f;
   auto prefetch = [&](int64_t row0) {
     tile_to_regs(pzA, Z3g, row0, a.n_edges, tid);
     tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
-    pf_ds = 0.f; pf_dn = 0.f; pf_de = 0.f;
+    pf_ds = 0.f; pf_dn = 0.f; pf_de = 0.f; pf_dm = 0.f;
     if (tid < FTM) {
       const int64_t gr = row0 + tid;
       if (gr < a.n_edges) { pf_ds = a.d_src[gr]; pf_dn = a.d_eff[gr]; }
     }
     if (tid < FTM * E) {
-      const int64_t gr = row0 + tid / E;
-      if (gr < a.n_edges && a.d_src[gr] > 0.f) pf_de = a.de[row0 * E + tid];
+      // mask source and gradient are requested TOGETHER (clamped index, masked at use): reading de only
+      // after d_src had arrived put a full HBM latency (5-8k cycles per tile) into this prefetch
+      const int64_t gr = std::min<int64_t>(row0 + tid / E, a.n_edges - 1);
+      pf_dm = row0 + tid / E < a.n_edges ? a.d_src[gr] : 0.f;
+      pf_de = a.de[std::min<int64_t>(row0 * E + tid, a.n_edges * E - 1)];
     }
   };
   if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
       sD[tid] = pf_dn;
       sM[tid] = pf_ds > 0.f ? 1.f : 0.f;
     }
-    if (tid < FTM * E) sdE[tid] = pf_de;
+    if (tid < FTM * E) sdE[tid] = pf_dm > 0.f ? pf_de : 0.f;
     regs_to_lds(pzA, bufA, tid);
     regs_to_lds(pzB, bufB, tid);
     NG_LDS_BARRIER();
