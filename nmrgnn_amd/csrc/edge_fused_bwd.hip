@@ -183,7 +183,6 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   float pf_ds = 0.f, pf_dn = 0.f, pf_de = 0.f, pf_dm = 0.f;
   auto prefetch = [&](int64_t row0) {
     tile_to_regs(pzA, Z3g, row0, a.n_edges, tid);
-    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
     pf_ds = 0.f; pf_dn = 0.f; pf_de = 0.f; pf_dm = 0.f;
     if (tid < FTM) {
       const int64_t gr = row0 + tid;
@@ -209,7 +208,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
     }
     if (tid < FTM * E) sdE[tid] = pf_dm > 0.f ? pf_de : 0.f;
     regs_to_lds(pzA, bufA, tid);
-    regs_to_lds(pzB, bufB, tid);
+    // Z2 is requested here and lands in bufB at the end of this phase (~6k cycles of cover): holding it in
+    // registers across the previous tile's last GEMM cost 16 VGPRs at the kernel's pressure peak
+    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
     NG_LDS_BARRIER();
     tile_to_regs(pzA, Z1g, row0, a.n_edges, tid);   // lands in bufC at the end of phase B
     // G3 = (dE Wo^T) * s'(Z3) -> bufC
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
       for (int n = 0; n < E; ++n) accWo[n] += z * sdE[r * E + n];
       if (cn < E) accbo += sdE[r * E + cn];
     }
+    regs_to_lds(pzB, bufB, tid);    // Z2
     NG_LDS_BARRIER();
     // ------------------------------------------------------------------ phase B (layer 3)
     dw_gemm(accW[2], bufB, bufC, kslab, nsl0, lane);
