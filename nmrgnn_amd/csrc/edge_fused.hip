@@ -155,7 +155,8 @@ __device__ __forceinline__ void save_tile(const float* __restrict__ X, float* __
     const int r = 16 * wave + 2 * i + (lane >> 5);
     if (row0 + r < n_rows) {
       const float4 v = *reinterpret_cast<const float4*>(X + r * FLD + col);
-      *reinterpret_cast<float4*>(dst + (row0 + r) * FH + col) = v;
+      typedef float nt4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4*>(dst + (row0 + r) * FH + col));
     }
   }
 }

@@ -49,9 +49,15 @@ __device__ __forceinline__ void tile_to_regs(float4 (&pz)[4], const float* __res
   for (int i = 0; i < 4; ++i) {
     const int lin = tid + i * BW_THREADS;
     const int row = lin >> 5, c4 = lin & 31;
-    pz[i] = (row0 + row < n_rows)
-                ? *reinterpret_cast<const float4*>(src + (row0 + row) * FH + c4 * 4)
-                : f4zero();
+    // streamed once: non-temporal, so the 3.2 GB of saved activations do not evict the weight fragments
+    // that every tile re-reads from L2
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    if (row0 + row < n_rows) {
+      const nt4 v = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(src + (row0 + row) * FH + c4 * 4));
+      pz[i] = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      pz[i] = f4zero();
+    }
   }
 }
 __device__ __forceinline__ void regs_to_lds(const float4 (&pz)[4], float* __restrict__ buf, int tid) {

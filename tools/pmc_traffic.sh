@@ -14,7 +14,9 @@ names = {"edge_fused_bwd_kernel": "edge_fused_bwd", "edge_fused_bwd2_kernel": "e
          "edge_fused_fwd_kernel": "edge_fused_fwd", "split_agg_kernel": "mp_aggregate",
          "split_agg_csc2_kernel": "mp_aggregate_csc", "split_edge_grad2_kernel": "mp_edge_grad",
          "tall_tn_kernel<192": "mp_dw", "tall_gemm_kernel<192, 64, false>": "mp_update_fwd|mp_dh",
-         "tall_gemm_kernel<64, 192, true>": "mp_dA"}
+         "tall_gemm_kernel<64, 192, true>": "mp_dA", "mp_win_fwd_kernel": "mp_win_fwd",
+         "mp_win_bwd_edge_kernel": "mp_win_bwd_edge", "mp_win_bwd_node_kernel": "mp_win_bwd_node",
+         "fc_fwd_kernel": "fc_fused_fwd", "fc_bwd_kernel": "fc_fused_bwd"}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmc_{C}/**/*counter_collection.csv", recursive=True)
     if not f:
