@@ -106,16 +106,29 @@ __device__ __forceinline__ void dz_gemm_epilogue(const float* __restrict__ G,
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float4* wp = reinterpret_cast<const float4*>(WpkT) + ((layer * 4 + zk) * 16) * 64 + lane;
+  // W^T fragments stream from L2 through BUFFER loads: scalar resource + scalar chunk offset + one VGPR lane
+  // offset.  With flat/global addressing the compiler kept a 64-bit per-lane pointer per chunk, hoisted all
+  // of them out of the tile loop, spilled them, and every reload carried a vmcnt(0) that serialised the
+  // fragment stream behind its own latency.
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WpkT), 0, 3 * FH * FH * 4, 0x00020000);
+  const int wvo = lane * 16;
+  const int wso = ((layer * 4 + zk) * 16) * 64 * 16;
+  auto wload = [&](int i) {
+    typedef float f32x4w __attribute__((ext_vector_type(4)));
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + i * 1024, 0);
+    const f32x4w v = __builtin_bit_cast(f32x4w, raw);
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
   const float* g = G + (zrt * 32 + l31) * FLD + 4 * half;
   float4 wc[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wc[0][i] = wp[i * 64];
+  for (int i = 0; i < 4; ++i) wc[0][i] = wload(i);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c < 3) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wc[(c + 1) & 1][i] = wp[(4 * (c + 1) + i) * 64];
+      for (int i = 0; i < 4; ++i) wc[(c + 1) & 1][i] = wload(4 * (c + 1) + i);
     }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
