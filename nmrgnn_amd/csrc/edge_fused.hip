@@ -66,6 +66,7 @@ struct EdgeFwdArgs {
   const float* bo;        // [E]
   float* e_out;           // [n_edges][E]
   float* z_save;          // [3][n_edges][128] or nullptr
+  float* dummy;           // 128 floats: where rows past the end store
 };
 
 __device__ __forceinline__ void load_wfrag(float (&wf)[64], const float* __restrict__ Wpk, int layer,
@@ -147,17 +148,20 @@ __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __res
 }
 
 // copy a finished [64][128] LDS tile to global as whole rows (wave w: rows 16w .. 16w+15)
+// Rows past the end go to a dummy row instead of being skipped: with a fixed number of stores per tile the
+// compiler's vmcnt counts for the next layer's weight slab stay exact (otherwise the last waits of the
+// MFMA chain also wait for these stores to be acknowledged).
 __device__ __forceinline__ void save_tile(const float* __restrict__ X, float* __restrict__ dst,
-                                          int64_t row0, int64_t n_rows, int wave, int lane) {
+                                          float* __restrict__ dummy, int64_t row0, int64_t n_rows, int wave,
+                                          int lane) {
   const int col = (lane & 31) * 4;
+  typedef float nt4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = 16 * wave + 2 * i + (lane >> 5);
-    if (row0 + r < n_rows) {
-      const float4 v = *reinterpret_cast<const float4*>(X + r * FLD + col);
-      typedef float nt4 __attribute__((ext_vector_type(4)));
-      __builtin_nontemporal_store(nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4*>(dst + (row0 + r) * FH + col));
-    }
+    const float4 v = *reinterpret_cast<const float4*>(X + r * FLD + col);
+    float* d = row0 + r < n_rows ? dst + (row0 + r) * FH + col : dummy + col;
+    __builtin_nontemporal_store(nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4*>(d));
   }
 }
 
@@ -231,15 +235,15 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
       ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
     }
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X1, a.z_save, row0, a.n_edges, wave, lane);
+    if (SAVE) save_tile(X1, a.z_save, a.dummy, row0, a.n_edges, wave, lane);
     // ---- hidden layer 1: X1 -> X0
     hidden_layer(wf, X1, X0, sBias + FH, wave, lane, a.Wpk, 2);
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, row0, a.n_edges, wave, lane);
+    if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane);
     // ---- hidden layer 2: X0 -> X1   (reloads layer 0's slab for the next tile)
     hidden_layer(wf, X0, X1, sBias + 2 * FH, wave, lane, a.Wpk, 0);
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, row0, a.n_edges, wave, lane);
+    if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane);
     // ---- output layer: wave w -> rows 16w..16w+15, 4 lanes per row (k = 16i + 4*(lane&3) + s)
     {
       const int r = 16 * wave + (lane >> 2), qq = lane & 3;
@@ -293,7 +297,7 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   }
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
-  float* Wpk = (float*)workspace(ctx, pk_floats * 4);
+  float* Wpk = (float*)workspace(ctx, (pk_floats + FH) * 4);
   if (!Wpk) return NG_ERR_NOMEM;
   int rc = edge_fused_pack(ctx, st, W, Wpk, nullptr);
   if (rc) return rc;
@@ -304,7 +308,7 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.Wpk = Wpk;
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.Wo = W[3]; a.bo = b[3];
-  a.e_out = e_out; a.z_save = z_save;
+  a.e_out = e_out; a.z_save = z_save; a.dummy = Wpk + pk_floats;
   const int64_t ntiles = cdiv(n_edges, FTM);
   const char* gm = getenv("NG_EDGE_FWD_WGS");
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * (gm ? atoi(gm) : 2));
