@@ -107,14 +107,15 @@ __device__ __forceinline__ void epilogue_q(const f32x16& acc, int q, float* __re
 
 __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __restrict__ Xin,
                                              float* __restrict__ Xout,
-                                             const float* __restrict__ bias, int wave, int lane,
+                                             const float* __restrict__ bias, int wave, int rbase, int lane,
                                              const float* __restrict__ Wpk, int next_layer) {
+  // wave = column slab (0..3); rbase = first of this wave's 64 rows in the tile
   const int half = lane >> 5, l31 = lane & 31;
-  const float* x0 = Xin + l31 * FLD + half * 4;
+  const float* x0 = Xin + (rbase + l31) * FLD + half * 4;
   const float* x1 = x0 + 32 * FLD;
   // lane holds, for rows l31 and 32+l31, columns 32*wave + 8q + 4*half + (0..3)
   const int ncol = 32 * wave + 4 * half;
-  float* o0 = Xout + l31 * FLD + ncol;
+  float* o0 = Xout + (rbase + l31) * FLD + ncol;
   float* o1 = o0 + 32 * FLD;
   f32x16 acc0, acc1;
 #pragma unroll
@@ -166,19 +167,25 @@ __device__ __forceinline__ void save_tile(const float* __restrict__ X, float* __
   }
 }
 
-template <int E, bool SAVE>
-__global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
+// TM = rows per tile = 16 per wave.  TM = 64: 256 threads, two workgroups per CU (their phases drift apart,
+// which hides latency but not VALU work: beside an fp32-MFMA stream the partner wave issues nothing).
+// TM = 128: 512 threads, ONE workgroup per CU whose two waves per SIMD run the SAME phase: in the VALU
+// phases (softplus, RBF, output layer, z_save copies) two waves issue twice as fast as one.
+template <int E, bool SAVE, int TM>
+__global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
+  constexpr int NTHR = TM * 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* X0 = smem;                         // [64][132]
-  float* X1 = smem + FTM * FLD;             // [64][132]
-  float* sWo = X1 + FTM * FLD;              // [128*E]
-  float* sMask = sWo + FH * FMAX_E;         // [64]
-  float* sCen = sMask + FTM;                // [128] RBF centres
+  float* X0 = smem;                         // [TM][132]
+  float* X1 = smem + TM * FLD;              // [TM][132]
+  float* sWo = X1 + TM * FLD;               // [128*E]
+  float* sMask = sWo + FH * FMAX_E;         // [TM]
+  float* sCen = sMask + TM;                 // [128] RBF centres
   float* sBias = sCen + FH;                 // [3][128] hidden biases (LDS: keeps them out of VGPRs)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int t = tid; t < FH * E; t += 256) sWo[t] = a.Wo[t];
+  const int slab = wave & 3, rbase = 64 * (wave >> 2);
+  for (int t = tid; t < FH * E; t += NTHR) sWo[t] = a.Wo[t];
   if (tid < FH) {
     sCen[tid] = a.centers[tid];
     sBias[tid] = a.bh[0][tid];
@@ -187,37 +194,37 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
   }
   __syncthreads();
 
-  const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
+  const int64_t ntiles = (a.n_edges + TM - 1) / TM;
   float wf[64];
-  load_wfrag(wf, a.Wpk, 0, wave, lane);
+  load_wfrag(wf, a.Wpk, 0, slab, lane);
 
   // distances of the NEXT tile are requested one tile ahead (clamped index, no conditional VMEM): read at
   // the point of use they exposed a full HBM latency at the head of every tile
   float ds_n, de_n;
   {
-    const int64_t g0 = std::min<int64_t>((int64_t)blockIdx.x * FTM + (tid & 63), a.n_edges - 1);
+    const int64_t g0 = std::min<int64_t>((int64_t)blockIdx.x * TM + (tid & (TM - 1)), a.n_edges - 1);
     ds_n = a.d_src[g0]; de_n = a.d_eff[g0];
   }
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * FTM;
-    // ---- RBF tile: thread -> (row = tid & 63, quarter = wave): 32 centres each
+    const int64_t row0 = tile * TM;
+    // ---- RBF tile: thread -> (row = tid % TM, quarter = tid / TM): 32 centres each
     {
-      const int r = tid & 63;
+      const int r = tid & (TM - 1), qt = tid / TM;
       const int64_t gr = row0 + r;
       const float ds = gr < a.n_edges ? ds_n : 0.f;
       const float de = de_n;
       const float m = ds > 0.f ? 1.f : 0.f;
-      if (wave == 0) sMask[r] = m;
+      if (qt == 0) sMask[r] = m;
       // masked edges: a distance of 1e19 makes every (d - mu)^2 * c overflow to -inf and exp2 return an
       // exact 0 — the mask costs nothing per element.  c2 = -log2(e)/gap folds __expf's scaling.
       const float dm = ds > 0.f ? de : 1.0e19f;
       const f32x2e d2 = {dm, dm};
       const f32x2e c2 = {a.neg_inv_gap_log2e, a.neg_inv_gap_log2e};
-      float* dst = X0 + r * FLD + 32 * wave;
+      float* dst = X0 + r * FLD + 32 * qt;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * wave + 4 * i);
+        const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * qt + 4 * i);
         f32x2e u0 = d2 - f32x2e{mu.x, mu.y};
         f32x2e u1 = d2 - f32x2e{mu.z, mu.w};
         u0 = (u0 * u0) * c2;
@@ -230,19 +237,19 @@ __global__ __launch_bounds__(256, 2) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
     }
     NG_LDS_BARRIER();
     // ---- hidden layer 0: X0 -> X1
-    hidden_layer(wf, X0, X1, sBias, wave, lane, a.Wpk, 1);
+    hidden_layer(wf, X0, X1, sBias, slab, rbase, lane, a.Wpk, 1);
     {   // issued here they are younger than layer 1's weight slab and a full layer older than layer 2's
-      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * FTM + (tid & 63), a.n_edges - 1);
+      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * TM + (tid & (TM - 1)), a.n_edges - 1);
       ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
     }
     NG_LDS_BARRIER();
     if (SAVE) save_tile(X1, a.z_save, a.dummy, row0, a.n_edges, wave, lane);
     // ---- hidden layer 1: X1 -> X0
-    hidden_layer(wf, X1, X0, sBias + FH, wave, lane, a.Wpk, 2);
+    hidden_layer(wf, X1, X0, sBias + FH, slab, rbase, lane, a.Wpk, 2);
     NG_LDS_BARRIER();
     if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane);
     // ---- hidden layer 2: X0 -> X1   (reloads layer 0's slab for the next tile)
-    hidden_layer(wf, X0, X1, sBias + 2 * FH, wave, lane, a.Wpk, 0);
+    hidden_layer(wf, X0, X1, sBias + 2 * FH, slab, rbase, lane, a.Wpk, 0);
     NG_LDS_BARRIER();
     if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane);
     // ---- output layer: wave w -> rows 16w..16w+15, 4 lanes per row (k = 16i + 4*(lane&3) + s)
@@ -291,11 +298,9 @@ bool edge_fused_supported(int H, int E, int Le) { return H == FH && Le == 4 && E
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* const* b, float* e_out, float* z_save) {
-  {
-    const char* v = getenv("NG_EDGE_FWD");   // "tm32": 32-edge tiles, 4 workgroups / CU (edge_fused_fwd32.hip)
-    if (v && std::string(v) == "tm32")
-      return edge_fused_fwd32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
-  }
+  const char* v0 = getenv("NG_EDGE_FWD");   // "tm32": 32-edge tiles, 4 workgroups / CU (edge_fused_fwd32.hip)
+  if (v0 && std::string(v0) == "tm32")
+    return edge_fused_fwd32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
   float* Wpk = (float*)workspace(ctx, (pk_floats + FH) * 4);
@@ -310,20 +315,24 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.Wo = W[3]; a.bo = b[3];
   a.e_out = e_out; a.z_save = z_save; a.dummy = Wpk + pk_floats;
-  const int64_t ntiles = cdiv(n_edges, FTM);
-  const char* gm = getenv("NG_EDGE_FWD_WGS");
-  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * (gm ? atoi(gm) : 2));
-  const size_t lds = (size_t)(2 * FTM * FLD + FH * FMAX_E + FTM + 4 * FH) * 4;
+  // default: 64-edge tiles, two 256-thread workgroups per CU (1.83 ms).  NG_EDGE_FWD=tm128: 128-edge tiles, one
+  // 512-thread workgroup per CU with both waves of a SIMD in the same phase (1.85 ms: no gain measured)
+  const bool tm64 = !(v0 && std::string(v0) == "tm128");
+  const int TMr = tm64 ? 64 : 128;
+  const int64_t ntiles = cdiv(n_edges, TMr);
+  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * (tm64 ? 2 : 1));
+  const size_t lds = (size_t)(2 * TMr * FLD + FH * FMAX_E + TMr + 4 * FH) * 4;
   ProfScope ps(ctx, st, "edge_fused_fwd");
+#define NG_FW1(EE, SV)                                                                              \
+  if (tm64) hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, SV, 64>), dim3(grid), dim3(256), lds, st, a); \
+  else hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, SV, 128>), dim3(grid), dim3(512), lds, st, a);
 #define NG_FW(EE)                                                                                  \
   case EE:                                                                                         \
-    if (z_save)                                                                                    \
-      hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, true>), dim3(grid), dim3(256), lds, st, a);    \
-    else                                                                                           \
-      hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, false>), dim3(grid), dim3(256), lds, st, a);   \
+    if (z_save) { NG_FW1(EE, true) } else { NG_FW1(EE, false) }                                    \
     break;
   switch (E) { NG_FW(1) NG_FW(2) NG_FW(3) NG_FW(4) NG_FW(5) NG_FW(6) NG_FW(7) NG_FW(8) }
 #undef NG_FW
+#undef NG_FW1
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

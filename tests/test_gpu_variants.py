@@ -9,7 +9,7 @@ from helpers import make_hp, small_batch, randomize_biases, rel_err
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [
-    {"NG_MP_PATH": "win"}, {"NG_MP_PATH": "split"}, {"NG_MP_PATH": "fused"}, {"NG_MP_PATH": "layered"}, {"NG_EDGE_BWD": "v2"}, {"NG_EDGE_FWD": "tm32"},
+    {"NG_MP_PATH": "win"}, {"NG_MP_PATH": "split"}, {"NG_MP_PATH": "fused"}, {"NG_MP_PATH": "layered"}, {"NG_EDGE_BWD": "v2"}, {"NG_EDGE_FWD": "tm32"}, {"NG_EDGE_FWD": "tm128"},
     {"NG_EDGE_PATH": "layered"}, {"NG_DENSE_PATH": "generic"}, {"NG_FC_PATH": "layered"}, {"NG_HEAD_PATH": "generic"},
     {"NG_MP_BWD": "split"}, {"NG_MP_BWD": "edge"},
     {"NG_MP_PATH": "layered", "NG_AGG_PATH": "window"},
