@@ -505,7 +505,13 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
 
 #pragma unroll 1
     for (int64_t t = T0; t < T1; ++t) {
-      // ---- vector interval: B tile of t; records of t+1 into LDS; h rows of t into LDS; requests for t+2
+      // ---- vector interval: records of t+1 and h rows of t into LDS FIRST, then the B tile of t, then the
+      // requests for t+2.  Nothing freshly requested may be live across the gather: its out-of-line
+      // global-memory variant is a call, and registers live across a call are saved to scratch — with a
+      // vmcnt wait on the loads that fill them (measured: the prefetch latency came back every tile).
+      *reinterpret_cast<float4*>(htile + (tid >> 4) * SDP_LD + 4 * (tid & 15)) = p_h;
+      const float4 dHc = p_dH;
+      if (t + 1 < T1) commit(t + 1);
       {
         const int* pp = s_ptr + (t & 1) * 36;
         const float4* rc = s_rec + (t & 1) * NREC_CAP;
@@ -517,25 +523,27 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
         else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4);
         else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4);
       }
-      *reinterpret_cast<float4*>(htile + (tid >> 4) * SDP_LD + 4 * (tid & 15)) = p_h;
-      const float4 dHc = p_dH;
-      if (t + 1 < T1) commit(t + 1);
       issue(t + 2 < T1 ? t + 2 : t);
       issue_rows(t + 1 < T1 ? t + 1 : t);
       NG_LDS_BARRIER();
       // ---- matrix interval: dh = dH + B Wn ;  dw += h^T B
       {
+        // operand reads run two k-steps ahead of their MFMAs (pinned): holding all NT of them kept 48 VGPRs
+        // live and pushed freshly requested prefetch registers into scratch — behind a vmcnt wait
         const float* xrow = tile + (16 * hh + a16) * LD + 4 * g4;
         float4 x[NT];
-#pragma unroll
-        for (int T = 0; T < NT; ++T) x[T] = *reinterpret_cast<const float4*>(xrow + 16 * T);
+        x[0] = *reinterpret_cast<const float4*>(xrow);
+        x[1] = *reinterpret_cast<const float4*>(xrow + 16);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
+          if (T + 2 < NT) x[T + 2] = *reinterpret_cast<const float4*>(xrow + 16 * (T + 2));
+          __builtin_amdgcn_sched_barrier(0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
         const int64_t row = t * WTA + 16 * hh + a16;
         const float4 v = make_float4(acc0[0] + acc1[0] + dHc.x, acc0[1] + acc1[1] + dHc.y,
