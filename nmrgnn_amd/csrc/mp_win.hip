@@ -225,22 +225,26 @@ __device__ __forceinline__ float ror_f(float v) {
   return __builtin_bit_cast(float, ror_i<S>(__builtin_bit_cast(int, v)));
 }
 
+// four rotation steps: row reads and FMAs are separate so that the reads of the NEXT four steps can be
+// issued before the FMAs of the current four (the LDS latency is otherwise exposed: both waves of a SIMD
+// run this phase in lockstep and wait at the same time)
+template <int S0>
+__device__ __forceinline__ void rot_load4(const char* __restrict__ wbytes, int roff, float4 (&h)[4]) {
+  h[0] = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 0>(roff));
+  h[1] = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 1>(roff));
+  h[2] = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 2>(roff));
+  h[3] = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 3>(roff));
+}
 template <int E, int S0>
-__device__ __forceinline__ void rot_steps4(const char* __restrict__ wbytes, int roff, const float (&w)[E],
-                                           f32x2 (&lo)[E], f32x2 (&hi)[E]) {
-  // four steps per call: the four row reads are issued before the first FMA needs its row
-  const float4 h0 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 0>(roff));
-  const float4 h1 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 1>(roff));
-  const float4 h2 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 2>(roff));
-  const float4 h3 = *reinterpret_cast<const float4*>(wbytes + ror_i<S0 + 3>(roff));
+__device__ __forceinline__ void rot_fma4(const float4 (&h)[4], const float (&w)[E], f32x2 (&lo)[E], f32x2 (&hi)[E]) {
 #pragma unroll
-  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 0>(w[n]), h0);
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 0>(w[n]), h[0]);
 #pragma unroll
-  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 1>(w[n]), h1);
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 1>(w[n]), h[1]);
 #pragma unroll
-  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 2>(w[n]), h2);
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 2>(w[n]), h[2]);
 #pragma unroll
-  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 3>(w[n]), h3);
+  for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 3>(w[n]), h[3]);
 }
 
 template <int E>
@@ -260,10 +264,18 @@ __device__ __forceinline__ void win_gather_rot(int K, int wave, int lane, int wl
   f32x2 lo[E], hi[E];
 #pragma unroll
   for (int n = 0; n < E; ++n) { lo[n] = f32x2{0.f, 0.f}; hi[n] = f32x2{0.f, 0.f}; }
-  rot_steps4<E, 0>(wbytes, roff, w, lo, hi);
-  rot_steps4<E, 4>(wbytes, roff, w, lo, hi);
-  rot_steps4<E, 8>(wbytes, roff, w, lo, hi);
-  rot_steps4<E, 12>(wbytes, roff, w, lo, hi);
+  float4 ha[4], hb[4];
+  rot_load4<0>(wbytes, roff, ha);
+  rot_load4<4>(wbytes, roff, hb);
+  __builtin_amdgcn_sched_barrier(0);
+  rot_fma4<E, 0>(ha, w, lo, hi);
+  rot_load4<8>(wbytes, roff, ha);
+  __builtin_amdgcn_sched_barrier(0);
+  rot_fma4<E, 4>(hb, w, lo, hi);
+  rot_load4<12>(wbytes, roff, hb);
+  __builtin_amdgcn_sched_barrier(0);
+  rot_fma4<E, 8>(ha, w, lo, hi);
+  rot_fma4<E, 12>(hb, w, lo, hi);
 #pragma unroll
   for (int n = 0; n < E; ++n)
     *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
