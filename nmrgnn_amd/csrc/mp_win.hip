@@ -388,7 +388,6 @@ struct MpWinFwdArgs {
   float* S_save;           // [N][64] or nullptr
   int act;
   float* dummy;            // 64 floats: where the lanes of rows >= N store
-  long long* trace;        // debug: per-tile cycle stamps of block 0 wave 0 (kept in LDS until the end)
 };
 
 template <int E, bool K4>
@@ -402,12 +401,6 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
   int32_t* s_nl = reinterpret_cast<int32_t*>(tile + WTA * LD);         // [2][32*K]
   float* s_e = reinterpret_cast<float*>(s_nl + 2 * WTA * a.K);         // [2][32*K*E]
   int* ctl = reinterpret_cast<int*>(s_e + 2 * WTA * a.K * E);          // [2][16]
-  long long* s_tr = reinterpret_cast<long long*>(ctl + 32);            // [160] debug stamps
-  int tr_n = 0;
-#define WIN_STAMP()                                                                      \
-  do {                                                                                    \
-    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && tr_n < 160) s_tr[tr_n++] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -456,7 +449,6 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
   const float resf = a.residual ? 1.f : 0.f;
 #pragma unroll 1
   for (int64_t t = T0; t < T1; ++t) {
-    WIN_STAMP();
     // ---- phase 1: lists of t+1 into LDS, request lists of t+2 and the epilogue operands, gather tile t
     const int64_t row = t * WTA + 16 * hh + a16;          // this lane's atom in the matrix phase
     const bool live = row < a.N;
@@ -467,7 +459,6 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
     lists.issue(a.nlist, a.e, t + 2 < T1 ? t + 2 : t, K, a.N, tid);
     const float rs = a.rowscale[rowc];
     const float4 re = *reinterpret_cast<const float4*>(a.h + rowc * WF + col);
-    WIN_STAMP();
     {
       const int32_t* nl = s_nl + (t & 1) * per_tile;
       const float* ee = s_e + (t & 1) * per_tile * E;
@@ -475,9 +466,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
       else if (mode == 0) win_gather<E, K4, 0>(K, wave, lane, wlo, nl, ee, tile, LD, win4, src4);
       else win_gather_global<E, K4>(K, wave, lane, nl, ee, tile, LD, src4);
     }
-    WIN_STAMP();
     NG_LDS_BARRIER();
-    WIN_STAMP();
     // ---- phase 2: tile x weights on the matrix cores, epilogue
     {
       const float* xrow = tile + (16 * hh + a16) * LD + 4 * g;
@@ -497,7 +486,6 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      WIN_STAMP();
       float4 v = make_float4((acc0[0] + acc1[0]) * rs, (acc0[1] + acc1[1]) * rs, (acc0[2] + acc1[2]) * rs,
                              (acc0[3] + acc1[3]) * rs);
       if (a.act == NG_ACT_SOFTPLUS) {
@@ -515,7 +503,6 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
       if (a.S_save) *reinterpret_cast<float4*>(live ? a.S_save + o : a.dummy + col) = v;
       *reinterpret_cast<float4*>(live ? a.out + o : a.dummy + col) = vo;
     }
-    WIN_STAMP();
     bool restage = false;
     if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * 16, wlo, mode);
     NG_LDS_BARRIER();
@@ -524,15 +511,11 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
       NG_LDS_BARRIER();
     }
   }
-  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
-    s_tr[tr_n++] = __builtin_amdgcn_s_memtime();
-    for (int i = 0; i < tr_n; ++i) a.trace[i] = s_tr[i];
-  }
 }
 
 size_t mp_win_lds_bytes(int K, int E) {
   const int LD = E * WF + 4;
-  return (size_t)(WROWS * WF + WTA * LD + 2 * WTA * K * (1 + E) + 32 + 320) * 4;
+  return (size_t)(WROWS * WF + WTA * LD + 2 * WTA * K * (1 + E) + 32) * 4;
 }
 
 bool mp_win_supported(int F, int E, int K) {
@@ -563,7 +546,6 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   a.tiles_per_wg = (int)per;
   a.h = h; a.nlist = nlist; a.e = e; a.Wfrag = Wfrag; a.rowscale = inv_degree; a.residual = residual;
   a.out = h_out; a.S_save = s_save; a.act = act; a.dummy = Wfrag + KF * WF;
-  { const char* d = getenv("NG_WIN_TRACE"); a.trace = d ? (long long*)strtoull(d, nullptr, 0) : nullptr; }
   const int grid = (int)cdiv(a.ntiles, per);
   const size_t lds = mp_win_lds_bytes(K, E);
   ProfScope ps(ctx, st, "mp_win_fwd");

@@ -29,13 +29,3 @@ def timeit(f, n=20):
     t1.record(); torch.cuda.synchronize()
     return t0.elapsed_time(t1) / n * 1e3
 print("%s dbg=%s fwd %.1f us" % (os.environ.get("NG_MP_PATH"), os.environ.get("NG_WIN_DBG"), timeit(fwd)))
-if os.environ.get("WIN_TRACE"):
-    tr = torch.zeros(512, dtype=torch.int64, device=dev)
-    os.environ["NG_WIN_TRACE"] = str(tr.data_ptr())
-    fwd(); torch.cuda.synchronize()
-    t = tr.cpu().numpy()
-    t = t[t > 0]
-    d = np.diff(t)
-    print("per tile [commit+issue, gather, barrierA, mfma, epilogue, decide+barrierB]:")
-    for i in range(0, min(len(d), 60), 6): print("  ", d[i:i+6].tolist())
-    print("total cycles", t[-1] - t[0])
