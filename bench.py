@@ -287,6 +287,20 @@ def main():
                                "avg_launch_ms": dom["avg_ms"]}
         out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
 
+    # ---- configs[1]: the same batch, inference only (no noise / dropout / tape), reported beside the headline
+    if rank == 0 and world == 1:
+        for _ in range(2):
+            eng.forward(gb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        isteps = max(5, args.steps // 2)
+        for _ in range(isteps):
+            eng.forward(gb)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / isteps
+        out["inference"] = {"workload": "configs[1]: forward only on the same batch", "value": gb.N / dt,
+                            "unit": "atoms/s", "ms_per_step": dt * 1e3, "steps": isteps}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(ARCH, sample_graphs=8, seed=42)
