@@ -518,14 +518,16 @@ int fc_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const f
     NG_HIP(ctx, hipGetLastError());
   }
   ProfScope ps(ctx, st, "reduce_partials");
-  launch_reduce_z(st, partial, grid, fc_part_floats(L), summed, 0, 0, 0, 1, part);
+  ReduceSegs sg{};
+  sg.n = 2 * L;
   for (int l = 0; l < L; ++l) {
     const int nout = l == L - 1 ? FC_H : FC_F;
-    NG_HIP(ctx, hipMemcpyAsync(dW[l], summed + (size_t)l * FC_F * FC_F, (size_t)FC_F * nout * 4,
-                               hipMemcpyDeviceToDevice, st));
-    NG_HIP(ctx, hipMemcpyAsync(db[l], summed + (size_t)L * FC_F * FC_F + l * FC_F, (size_t)nout * 4,
-                               hipMemcpyDeviceToDevice, st));
+    sg.begin[l] = l * FC_F * FC_F; sg.len[l] = FC_F * nout; sg.dst[l] = dW[l];
+    sg.begin[L + l] = L * FC_F * FC_F + l * FC_F; sg.len[L + l] = nout; sg.dst[L + l] = db[l];
   }
+  launch_reduce_z_seg(st, partial, grid, fc_part_floats(L), part, sg);
+  NG_HIP(ctx, hipGetLastError());
+  (void)summed;
   return NG_OK;
 }
 

@@ -221,9 +221,12 @@ int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   if (lpr == 8) { if (C <= 16) NG_HB(8, 16); else NG_HB(8, 32); }
   else { if (C <= 16) NG_HB(16, 16); else NG_HB(16, 32); }
 #undef NG_HB
-  launch_reduce_z(st, partial, nb, items, summed);
-  NG_HIP(ctx, hipMemcpyAsync(dWout, summed, (size_t)Fh * C * 4, hipMemcpyDeviceToDevice, st));
-  NG_HIP(ctx, hipMemcpyAsync(dbout, summed + (size_t)Fh * C, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+  ReduceSegs sg{};
+  sg.n = 2;
+  sg.begin[0] = 0; sg.len[0] = Fh * C; sg.dst[0] = dWout;
+  sg.begin[1] = Fh * C; sg.len[1] = C; sg.dst[1] = dbout;
+  launch_reduce_z_seg(st, partial, nb, items, items, sg);
+  (void)summed;
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

@@ -47,6 +47,42 @@ static inline void launch_reduce_z(hipStream_t st, const float* partial, int nz,
                      nz, n_elem, out, w_map, F, E, Nout, z_stride ? z_stride : n_elem);
 }
 
+// Same reduction, but the summed vector is cut into segments that land in different tensors (weight and
+// bias gradients of several layers): one launch instead of a reduction plus one device copy per tensor.
+constexpr int REDUCE_MAX_SEG = 16;
+struct ReduceSegs {
+  int n;
+  int begin[REDUCE_MAX_SEG];     // first index of the segment in the summed vector
+  int len[REDUCE_MAX_SEG];
+  float* dst[REDUCE_MAX_SEG];
+};
+
+static __global__ __launch_bounds__(1024) void reduce_z_seg_kernel(const float* __restrict__ partial, int nz,
+                                                                   int64_t n_elem, int64_t z_stride, ReduceSegs sg) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (idx < n_elem)
+    for (int z = w; z < nz; z += 16) s += partial[(int64_t)z * z_stride + idx];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && idx < n_elem) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) t += red[j][lane];
+#pragma unroll
+    for (int k = 0; k < REDUCE_MAX_SEG; ++k)
+      if (k < sg.n && idx >= sg.begin[k] && idx < sg.begin[k] + sg.len[k]) sg.dst[k][idx - sg.begin[k]] = t;
+  }
+}
+
+static inline void launch_reduce_z_seg(hipStream_t st, const float* partial, int nz, int64_t n_elem,
+                                       int64_t z_stride, const ReduceSegs& sg) {
+  hipLaunchKernelGGL(reduce_z_seg_kernel, dim3((unsigned)cdiv(n_elem, 64)), dim3(1024), 0, st, partial, nz,
+                     n_elem, z_stride, sg);
+}
+
 // partial[blk][a*B + b] = sum_{rows of blk} X(row, a) * Y(row, b)      (A <= 32, any B)
 // rows are staged 64 at a time in LDS; thread t owns items t, t+256, ... (<= SMALL_TN_ITEMS each);
 // blockIdx.y selects a batch of 256*SMALL_TN_ITEMS items.
