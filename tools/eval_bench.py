@@ -28,3 +28,15 @@ for fpb in (1, 10, 50):
     n = 100 * atoms.shape[0]
     print(f"frames/batch {fpb:3d}: {dt*1e3:8.1f} ms for 100 frames x {atoms.shape[0]} atoms = {n/dt/1e6:.2f} M atoms/s "
           f"(graph build {tg*1e3:.1f} ms)")
+
+# per-kernel breakdown of one 50-frame batch
+eng = model.engine
+gb = frames_to_batch(atoms, frames[:50], 16, device=dev)
+eng.ctx.prof_reset(); eng.ctx.prof_enable(True)
+for _ in range(3):
+    model(gb)
+torch.cuda.synchronize()
+prof = eng.ctx.prof_read(); eng.ctx.prof_enable(False)
+print("per-kernel, 50 frames x %d atoms (F=256):" % atoms.shape[0])
+for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+    print("  %-18s %8.3f ms/call-set  x%d" % (k, ms / 3, cnt // 3))
