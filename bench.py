@@ -186,6 +186,7 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    local = local % torch.cuda.device_count()      # (ranks may share a GPU only in the gloo smoke test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -235,18 +236,23 @@ def main():
         "loss": final_loss,
     }
 
-    # ---- per-kernel hipEvent pass (same step, events bracketed inside the C library)
-    if rank == 0 and not args.no_profile:
+    # ---- per-kernel hipEvent pass (same step, events bracketed inside the C library).  EVERY rank runs the
+    # steps — they contain the gradient all-reduce, a collective — only rank 0 reads the events.
+    prof = None
+    psteps = min(args.steps, 5)
+    if not args.no_profile:
         torch.cuda.synchronize()
-        eng.ctx.prof_reset()
-        eng.ctx.prof_enable(True)
-        psteps = min(args.steps, 5)
+        if rank == 0:
+            eng.ctx.prof_reset()
+            eng.ctx.prof_enable(True)
         for _ in range(psteps):
             tr.step(gb, y, w)
         torch.cuda.synchronize()
-        prof = eng.ctx.prof_read()
-        eng.ctx.prof_enable(False)
-        eng.ctx.prof_reset()
+        if rank == 0:
+            prof = eng.ctx.prof_read()
+            eng.ctx.prof_enable(False)
+            eng.ctx.prof_reset()
+    if rank == 0 and prof is not None:
         work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM)
         rows = []
         for name, (tot_ms, cnt) in prof.items():

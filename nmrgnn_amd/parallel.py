@@ -29,9 +29,10 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # "nccl" IS RCCL on ROCm; NMRGNN_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+            backend = os.environ.get("NMRGNN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 
