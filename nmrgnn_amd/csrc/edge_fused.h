@@ -45,3 +45,11 @@ int edge_fused_fwd32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const 
                      const float* d_eff, const float* centers, float gap, const float* const* W,
                      const float* const* b, float* e_out, float* z_save);
 }  // namespace ng
+
+namespace ng {
+// forward on the bf16 matrix pipe with three-way operand splitting (edge_fwd_x3.hip); NG_EDGE_MATH=bf16x3
+bool edge_x3_enabled();
+int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
+                float* z_save);
+}  // namespace ng

@@ -298,6 +298,7 @@ bool edge_fused_supported(int H, int E, int Le) { return H == FH && Le == 4 && E
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* const* b, float* e_out, float* z_save) {
+  if (edge_x3_enabled()) return edge_x3_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
   const char* v0 = getenv("NG_EDGE_FWD");   // "tm32": 32-edge tiles, 4 workgroups / CU (edge_fused_fwd32.hip)
   if (v0 && std::string(v0) == "tm32")
     return edge_fused_fwd32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);

@@ -1,0 +1,78 @@
+"""Edge forward on the bf16 matrix pipe (edge_fwd_x3.hip: every fp32 operand split exactly into three bf16
+pieces, six piece products per multiply, fp32 accumulate) against a float64 numpy statement of
+nmrgnn/model.py:251-261 + layers.py:137-140 + model.py:132-138 — and against the f32-input MFMA kernel
+(NG_EDGE_MATH=fp32): the split path must be as close to float64 as the fp32 path is."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+H = 128
+
+
+def softplus(x):
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def ref_edge(d_src, d_eff, centers, gap, Ws, bs):
+    m = (d_src > 0).astype(np.float64)
+    x = np.exp(-(d_eff[:, None] - centers[None, :]) ** 2 / gap) * m[:, None]
+    zs = []
+    for W, b in zip(Ws[:-1], bs[:-1]):
+        x = softplus(x @ W + b)
+        zs.append(x)
+    return m[:, None] * (x @ Ws[-1] + bs[-1]), zs
+
+
+def run_gpu(dev, d_src, d_eff, centers, gap, Ws, bs, E, save):
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr, ptr_array
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    n = len(d_src)
+    td, te, tc = t(d_src), t(d_eff), t(centers)
+    tW, tb = [t(w) for w in Ws], [t(b) for b in bs]
+    e = torch.full((n, E), 7.0, device=dev)
+    z = torch.full((3, n, H), 7.0, device=dev) if save else None
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.check(ctx.lib.ng_edge_mlp_fwd(ctx.handle, st, n, H, E, 4, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
+                                      ptr_array(tb), ptr(e), ptr(z)), "ng_edge_mlp_fwd")
+    torch.cuda.synchronize()
+    return e.cpu().numpy().astype(np.float64), (z.cpu().numpy().astype(np.float64) if save else None)
+
+
+@pytest.mark.parametrize("n,E,save", [(1, 3, True), (255, 3, True), (257, 1, True), (70001, 3, True), (5000, 8, False),
+                                      (4096, 3, False), (33, 2, True)])
+def test_edge_forward_split_vs_float64(gpu_device, monkeypatch, n, E, save):
+    rng = np.random.default_rng(n + E)
+    d_src = rng.uniform(0.05, 1.2, n)
+    d_src[rng.random(n) < 0.15] = 0.0                       # padded slots
+    d_eff = np.where(d_src > 0, d_src + 0.025 * rng.standard_normal(n), d_src)
+    centers = np.linspace(0.0, 1.2, H)
+    gap = centers[1] - centers[0]
+    Ws = [rng.standard_normal((H, H)) * 0.15 for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2]
+    bs = [rng.standard_normal(H) * 0.1 for _ in range(3)] + [rng.standard_normal(E) * 0.1]
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)     # what the GPU is given
+    e_ref, z_ref = ref_edge(f32(d_src), f32(d_eff), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws],
+                            [f32(b) for b in bs])
+    out = {}
+    for math in ("bf16x3", "fp32"):
+        monkeypatch.setenv("NG_EDGE_MATH", math)
+        out[math] = run_gpu(gpu_device, d_src, d_eff, centers, gap, Ws, bs, E, save)
+    # the output layer is a 128-term dot product: its rounding error scales with sum |z||W|, not with the result
+    mag = (np.abs(z_ref[2]) @ np.abs(f32(Ws[3])) + np.abs(f32(bs[3]))).max()
+    err = {k: np.abs(v[0] - e_ref) for k, v in out.items()}
+    assert err["bf16x3"].max() < 1e-6 * mag, (err["bf16x3"].max(), err["fp32"].max(), mag)
+    assert np.sqrt((err["bf16x3"] ** 2).mean()) < 2e-7 * mag
+    if save:
+        # hidden activations: the split products carry no more error than the f32-input MFMA chain (measured: less)
+        for l in range(3):
+            dz = {k: v[1][l] - z_ref[l] for k, v in out.items()}
+            assert np.abs(dz["bf16x3"]).max() < 1e-5, l
+            if n >= 255:
+                rms = {k: np.sqrt((v ** 2).mean()) for k, v in dz.items()}
+                assert rms["bf16x3"] < 1.2 * rms["fp32"] + 1e-8, (l, rms)
+    # masked edges give exact zeros, rows past the end are never written
+    assert np.all(out["bf16x3"][0][d_src == 0] == 0.0)

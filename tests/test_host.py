@@ -93,3 +93,21 @@ def test_shard_range_partitions_everything():
             seen += list(range(lo, hi))
         assert seen == list(range(n))
     assert shard_range(4096, 3, 8) == (1536, 2048)
+
+
+def test_three_piece_split_is_exact():
+    """host restatement of the split used on the device: x == h + m + l exactly, every piece has <= 8 significant bits"""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(4096), rng.standard_normal(4096) * 1e-20, rng.standard_normal(4096) * 1e20]
+                       ).astype(np.float32)
+
+    def rne_bf16(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+    h = rne_bf16(x)
+    r1 = x - h
+    m = rne_bf16(r1)
+    r2 = r1 - m
+    l = rne_bf16(r2)
+    assert np.all(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64) == x.astype(np.float64))
