@@ -1,0 +1,383 @@
+// Fused persistent backward of the edge path on the bf16 matrix pipe with exactly split fp32 operands
+// (x3_common.cuh).  Same math, phases, workgroup partials and reduction kernel as edge_fused_bwd.hip (backward of
+// nmrgnn/model.py:251-261); opt-out with NG_EDGE_MATH=fp32.
+//
+//   A:  dE = m*de ;  G3 = (dE Wo^T) * s'(Z3)   [VALU]      dWo += Z3^T dE, dbo += sum dE   [VALU, fp32]
+//   B:  dW3 += Z2^T G3 ; db3 += colsum G3 ; dZ2 = G3 W3^T ; G2 = dZ2 * s'(Z2)
+//   C:  dW2 += Z1^T G2 ; db2 += colsum G2 ; dZ1 = G2 W2^T ; G1 = dZ1 * s'(Z1)
+//   D:  R = m*rbf(d) recomputed ; dW1 += R^T G1 ; db1 += colsum G1
+//
+// Mapping.  512 threads = 8 waves (2 per SIMD), one persistent workgroup per CU, 64-edge tiles.
+// Every GEMM operand that comes from activations lives in LDS as a bf16-piece IMAGE [3 pieces][64 edges][136]:
+// three images (Z-type, G ping, G pong) = 153 KB.  Elementwise work is done ONCE per element in the accumulator
+// layout of the dZ GEMM (lane = edge row, 16 columns of the wave's 32-column slab): the lane that loads Z_l from
+// HBM in that layout splits it into the image AND keeps the fp32 values for s'(Z_l) in its own epilogue.
+//   dZ GEMM (wave: k-slab zk = w&3, edge half zrt = w>>2): A = W^T pieces streamed from a fragment-ordered image
+//     in L2 (buffer loads), B = G pieces read as rows of the image (ds_read_b128), 48 MFMAs.
+//   dW GEMM (wave: k-slab w>>1, n-slabs 2(w&1)+{0,1}; contraction over the tile's 64 edges): both operands are
+//     COLUMNS of an image; ds_read_b64_tr_b16 delivers a lane 4 consecutive edges of its column (two reads = one
+//     8-edge MFMA operand), 48 MFMAs per layer.  The three 128x128 accumulators stay in registers (96 VGPRs).
+//   Bias gradients: the 16 per-lane values are summed over the 32 rows of a lane half with 5 DPP adds and
+//     accumulated in LDS by one owner lane per column (fixed order, no atomics).
+#include <algorithm>
+#include <string>
+
+#include "edge_fused.h"
+#include "x3_common.cuh"
+
+namespace ng {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define BX_LDS(T) __attribute__((address_space(3))) T
+
+constexpr int BX_THREADS = 512;
+constexpr int BX_ROWB = 272;                 // image row stride in bytes: 136 bf16 (odd multiple of 16 B)
+constexpr int BX_PIECE = FTM * BX_ROWB;      // 17,408 B
+constexpr int BX_IMG = 3 * BX_PIECE;         // 52,224 B
+constexpr int BX_STG = 132;                  // fp32 staging row stride (floats)
+constexpr int BX_MISC_FLOATS = FH * 4 + FTM * 4 + 2 * 3 * FH + FH;   // sWo4 | sdE | sDb | sCen
+constexpr int BX_LDS_BYTES = 3 * BX_IMG + BX_MISC_FLOATS * 4;          // 163,328 of 163,840
+
+struct EdgeBwdX3Args {
+  int64_t n_edges;
+  const float* d_src;
+  const float* d_eff;
+  const float* centers;
+  float neg_inv_gap_log2e;
+  const char* wt_img;   // [2 layers (W2, W3)][4 k-slabs][8 k-steps][3 pieces][1 KB]
+  const float* Wo;      // [128][E]
+  const float* z_save;  // [3][n_edges][128]
+  const float* de;      // [n_edges][E]
+  float* partial;       // [grid][part_stride], layout of edge_fused_bwd.hip
+  int part_stride;
+  int E;
+};
+
+// W^T fragments of the dZ GEMMs: lane (row k = 32 zk + (l&31), k-slot t) = piece_p( W[k][n = 16 ks + 8 (l>>5) + t] )
+__global__ void x3_pack_wt_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
+                                  unsigned* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (L, zk, ks, lane)
+  if (idx >= 2 * 4 * 8 * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) & 7, zk = (idx >> 9) & 3, L = idx >> 11;
+  const float* W = L == 0 ? W2 : W3;
+  const int k = 32 * zk + (lane & 31), n0 = 16 * ks + 8 * (lane >> 5);
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split3_pair(W[k * FH + n0 + 2 * j], W[k * FH + n0 + 2 * j + 1], h[j], m[j], l[j]);
+  unsigned* dst = img + (size_t)(((L * 4 + zk) * 8 + ks) * 3) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = m[j]; dst[512 + j] = l[j]; }
+}
+
+// 16 values of one row (columns col0 + 8q + j, v[4q + j]) -> the three piece planes of an image
+__device__ __forceinline__ void bx_img_write(char* __restrict__ img, int row, int col0, const float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(v[4 * q + 0], v[4 * q + 1], h0, m0, l0);
+    split3_pair(v[4 * q + 2], v[4 * q + 3], h1, m1, l1);
+    char* p = img + row * BX_ROWB + (col0 + 8 * q) * 2;
+    *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(p + BX_PIECE) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(p + 2 * BX_PIECE) = u32x2{l0, l1};
+  }
+}
+
+// one MFMA operand (8 consecutive edges of this lane's column) = two transposing reads of 4 edges each
+__device__ __forceinline__ u32x4 bx_tr_frag(const char* p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((BX_LDS(s16x4)*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((BX_LDS(s16x4)*)(p + 4 * BX_ROWB));
+  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+  return u32x4{a[0], a[1], b[0], b[1]};
+}
+
+// acc[j][n][k] += sum_edges G[e][n] Zin[e][k]   (D rows n = G columns of slab nsl0 + j, D cols k = Zin columns of kslab)
+__device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], const char* __restrict__ imgZ,
+                                           const char* __restrict__ imgG, int kslab, int nsl0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2), columns 4(i&3)..+3
+  const int lane_off = (8 * (g >> 1) + (i >> 2)) * BX_ROWB + (16 * (g & 1) + 4 * (i & 3)) * 2;
+  const char* zb = imgZ + lane_off + 64 * kslab;
+  const char* g0 = imgG + lane_off + 64 * nsl0;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 b[3], a0[3], a1[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      b[p] = bx_tr_frag(zb + p * BX_PIECE + 16 * ks * BX_ROWB);
+      a0[p] = bx_tr_frag(g0 + p * BX_PIECE + 16 * ks * BX_ROWB);
+      a1[p] = bx_tr_frag(g0 + 64 + p * BX_PIECE + 16 * ks * BX_ROWB);
+    }
+    acc[0] = mfma_bf16(a0[2], b[0], acc[0]); acc[1] = mfma_bf16(a1[2], b[0], acc[1]);
+    acc[0] = mfma_bf16(a0[0], b[2], acc[0]); acc[1] = mfma_bf16(a1[0], b[2], acc[1]);
+    acc[0] = mfma_bf16(a0[1], b[1], acc[0]); acc[1] = mfma_bf16(a1[1], b[1], acc[1]);
+    acc[0] = mfma_bf16(a0[1], b[0], acc[0]); acc[1] = mfma_bf16(a1[1], b[0], acc[1]);
+    acc[0] = mfma_bf16(a0[0], b[1], acc[0]); acc[1] = mfma_bf16(a1[0], b[1], acc[1]);
+    acc[0] = mfma_bf16(a0[0], b[0], acc[0]); acc[1] = mfma_bf16(a1[0], b[0], acc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void bx_wload(u32x4 (&w)[3], __amdgpu_buffer_rsrc_t wrs, int wvo, int wso, int ks) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + (ks * 3 + p) * 1024, 0);
+    w[p] = __builtin_bit_cast(u32x4, raw);
+  }
+}
+
+// dZ[e][k] = sum_n G[e][n] W[k][n]  for k-slab zk, edge rows 32 zrt..; D rows = k, D cols = edges.
+// Returned lane layout: edge 32 zrt + (l&31), columns 32 zk + 8q + 4 (l>>5) + j  in register 4q + j.
+__device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restrict__ imgG, __amdgpu_buffer_rsrc_t wrs,
+                                           int L, int zk, int zrt, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const char* gb = imgG + (32 * zrt + l31) * BX_ROWB + 16 * half;
+  const int wvo = lane * 16, wso = ((L * 4 + zk) * 8) * 3 * 1024;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  u32x4 wa[2][3];
+  bx_wload(wa[0], wrs, wvo, wso, 0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks < 7) bx_wload(wa[(ks + 1) & 1], wrs, wvo, wso, ks + 1);
+    u32x4 b[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const u32x4*>(gb + 32 * ks + p * BX_PIECE);
+    if (ks & 1) acc1 = mma6(wa[ks & 1], b, acc1);
+    else acc0 = mma6(wa[ks & 1], b, acc0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[r] = acc0[r] + acc1[r];
+}
+
+// sum over the 32 lanes of this lane's half; valid in lanes 31 and 63
+__device__ __forceinline__ float bx_half_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast15 -> rows 1, 3
+  return v;
+}
+
+// db[col] += sum_rows g[.]: lane 31 / 63 own columns sdb[8q + j] (sdb already offset by 32 zk + 4 half)
+__device__ __forceinline__ void bx_bias_accum(const float (&g)[16], float* __restrict__ sdb, int l31) {
+  float s[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = bx_half_sum(g[r]);
+  if (l31 == 31) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 c = *reinterpret_cast<float4*>(sdb + 8 * q);
+      c.x += s[4 * q + 0]; c.y += s[4 * q + 1]; c.z += s[4 * q + 2]; c.w += s[4 * q + 3];
+      *reinterpret_cast<float4*>(sdb + 8 * q) = c;
+    }
+  }
+}
+
+// this lane's 16 values of a saved activation row (clamped row: rows past the end multiply a zero gradient)
+__device__ __forceinline__ void bx_load_z(float (&z)[16], const float* __restrict__ Zg, int64_t grow, int col0) {
+  typedef float nt4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const nt4 v = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(Zg + grow * FH + col0 + 8 * q));
+    z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+  }
+}
+
+__global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_bx[];
+  char* IZ = smem_bx;                 // Z2 -> Z1 -> R
+  char* GA = smem_bx + BX_IMG;        // G3 -> G1
+  char* GB = smem_bx + 2 * BX_IMG;    // fp32 Z3 staging -> G2
+  float* stg = reinterpret_cast<float*>(GB);
+  float* sWo4 = reinterpret_cast<float*>(smem_bx + 3 * BX_IMG);   // [128][4]
+  float* sdE = sWo4 + FH * 4;         // [64][4]
+  float* sDb = sdE + FTM * 4;         // [2 zrt][3 layers][128]
+  float* sCen = sDb + 2 * 3 * FH;     // [128]
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kslab = wave >> 1, nsl0 = 2 * (wave & 1);   // dW blocks
+  const int zk = wave & 3, zrt = wave >> 2;             // dZ block / elementwise ownership
+  const int cn = tid & 127, rq = tid >> 7;              // dWo ownership
+  const int row = 32 * zrt + l31;                       // this lane's edge row in the tile
+  const int col0 = 32 * zk + 4 * half;                  // its columns: col0 + 8q + j
+  const int E = a.E;
+
+  for (int t = tid; t < FH * 4; t += BX_THREADS) sWo4[t] = (t & 3) < E ? a.Wo[(t >> 2) * E + (t & 3)] : 0.f;
+  for (int t = tid; t < 2 * 3 * FH; t += BX_THREADS) sDb[t] = 0.f;
+  if (tid < FH) sCen[tid] = a.centers[tid];
+
+  f32x16 accW[3][2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW[l][j][r] = 0.f;
+  float accWo[4] = {0.f, 0.f, 0.f, 0.f};
+  float accbo = 0.f;
+
+  const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
+  const float* Z1g = a.z_save;
+  const float* Z2g = a.z_save + a.n_edges * FH;
+  const float* Z3g = a.z_save + 2 * a.n_edges * FH;
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wt_img), 0, 2 * 4 * 8 * 3 * 1024, 0x00020000);
+  __syncthreads();
+
+  // per-tile inputs of this lane's row, requested one tile ahead
+  float z3r[16], pf_ds, pf_dn, pf_de[4];
+  auto prefetch = [&](int64_t row0) {
+    const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
+    bx_load_z(z3r, Z3g, gr, col0);
+    pf_ds = row0 + row < a.n_edges ? a.d_src[gr] : 0.f;
+    pf_dn = a.d_eff[gr];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const float v = a.de[gr * E + std::min(n, E - 1)];
+      pf_de[n] = n < E ? v : 0.f;
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
+
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * FTM;
+    const int64_t grow = std::min<int64_t>(row0 + row, a.n_edges - 1);
+    const bool on = pf_ds > 0.f;
+    const float dn = pf_dn;
+    float dEm[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dEm[n] = on ? pf_de[n] : 0.f;
+    float z2r[16], z1r[16];
+    bx_load_z(z2r, Z2g, grow, col0);
+    // ------------------------------------------------------------------ phase A
+    if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(dEm[0], dEm[1], dEm[2], dEm[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(stg + row * BX_STG + col0 + 8 * q) =
+          make_float4(z3r[4 * q + 0], z3r[4 * q + 1], z3r[4 * q + 2], z3r[4 * q + 3]);
+    NG_LDS_BARRIER();
+    // dWo[k][n] += sum_rows Z3[row][k] dE[row][n]   (thread: k = cn, rows 16rq..16rq+15), fp32 on the VALU
+#pragma unroll 4
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) {
+      const float z = stg[r * BX_STG + cn];
+      const float4 d = *reinterpret_cast<const float4*>(sdE + 4 * r);
+      accWo[0] += z * d.x; accWo[1] += z * d.y; accWo[2] += z * d.z; accWo[3] += z * d.w;
+      if (cn < 4) accbo += sdE[4 * r + cn];
+    }
+    {   // G3 = (dE Wo^T) * s'(Z3)  ->  GA ;  db3
+      float g[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 w = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));
+          const float pre = dEm[0] * w.x + dEm[1] * w.y + dEm[2] * w.z + dEm[3] * w.w;
+          g[4 * q + j] = pre * (1.0f - __expf(-z3r[4 * q + j]));
+        }
+      bx_bias_accum(g, sDb + (zrt * 3 + 2) * FH + col0, l31);
+      bx_img_write(GA, row, col0, g);
+    }
+    bx_img_write(IZ, row, col0, z2r);       // Z2 pieces
+    bx_load_z(z1r, Z1g, grow, col0);        // lands during phase B
+    NG_LDS_BARRIER();
+    // ------------------------------------------------------------------ phase B (layer 3)
+    bx_dw_gemm(accW[2], IZ, GA, kslab, nsl0, lane);
+    {
+      float g[16];
+      bx_dz_gemm(g, GA, wrs, 1, zk, zrt, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z2r[r]);
+      bx_bias_accum(g, sDb + (zrt * 3 + 1) * FH + col0, l31);
+      bx_img_write(GB, row, col0, g);       // G2
+    }
+    NG_LDS_BARRIER();
+    bx_img_write(IZ, row, col0, z1r);       // Z1 pieces
+    NG_LDS_BARRIER();
+    // ------------------------------------------------------------------ phase C (layer 2)
+    bx_dw_gemm(accW[1], IZ, GB, kslab, nsl0, lane);
+    {
+      float g[16];
+      bx_dz_gemm(g, GB, wrs, 0, zk, zrt, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z1r[r]);
+      bx_bias_accum(g, sDb + (zrt * 3 + 0) * FH + col0, l31);
+      bx_img_write(GA, row, col0, g);       // G1
+    }
+    NG_LDS_BARRIER();
+    {   // R = m * rbf(d_eff)  ->  IZ   (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
+      float rr[16];
+      const float dm = on ? dn : 1.0e19f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 mu = *reinterpret_cast<const float4*>(sCen + col0 + 8 * q);
+        const float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
+        rr[4 * q + 0] = __builtin_amdgcn_exp2f(u0 * u0 * a.neg_inv_gap_log2e);
+        rr[4 * q + 1] = __builtin_amdgcn_exp2f(u1 * u1 * a.neg_inv_gap_log2e);
+        rr[4 * q + 2] = __builtin_amdgcn_exp2f(u2 * u2 * a.neg_inv_gap_log2e);
+        rr[4 * q + 3] = __builtin_amdgcn_exp2f(u3 * u3 * a.neg_inv_gap_log2e);
+      }
+      bx_img_write(IZ, row, col0, rr);
+    }
+    NG_LDS_BARRIER();
+    // ------------------------------------------------------------------ phase D (layer 1)
+    if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * FTM);
+    bx_dw_gemm(accW[0], IZ, GA, kslab, nsl0, lane);
+    NG_LDS_BARRIER();
+  }
+
+  // ---------------------------------------------------------------------- write this workgroup's partial
+  float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
+  {
+    const int k = kslab * 32 + l31;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = (nsl0 + j) * 32 + 8 * q + 4 * half;
+          *reinterpret_cast<float4*>(part + l * FH * FH + k * FH + n) =
+              make_float4(accW[l][j][4 * q + 0], accW[l][j][4 * q + 1], accW[l][j][4 * q + 2],
+                          accW[l][j][4 * q + 3]);
+        }
+  }
+  // bias sums of the two edge halves, dWo / dbo of the four row quarters: summed through LDS (IZ is free now)
+  float* red = reinterpret_cast<float*>(IZ);
+  const int red_stride = 3 * FH + FH * E + E;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = rq < 2 ? sDb[(rq * 3 + l) * FH + cn] : 0.f;
+  for (int n = 0; n < E; ++n) red[rq * red_stride + 3 * FH + cn * E + n] = accWo[n];
+  if (cn < E) red[rq * red_stride + 3 * FH + FH * E + cn] = accbo;
+  __syncthreads();
+  for (int t = tid; t < red_stride; t += BX_THREADS)
+    part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
+}
+
+bool edge_bwd_x3_supported(int E) { return E >= 1 && E <= 4; }
+
+size_t edge_bwd_x3_ws_bytes() { return (size_t)2 * 4 * 8 * 3 * 1024; }
+
+// wt_img: edge_bwd_x3_ws_bytes() of scratch; partial / stride / grid as in edge_fused_bwd()
+int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                       const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
+                       char* wt_img, float* partial, int part_stride, int grid) {
+  hipLaunchKernelGGL(x3_pack_wt_kernel, dim3(16), dim3(256), 0, st, W[1], W[2], (unsigned*)wt_img);
+  NG_HIP(ctx, hipGetLastError());
+  EdgeBwdX3Args a;
+  a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
+  a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
+  a.wt_img = wt_img; a.Wo = W[3]; a.z_save = z_save; a.de = de;
+  a.partial = partial; a.part_stride = part_stride; a.E = E;
+  ProfScope ps(ctx, st, "edge_bwd_x3");
+  hipLaunchKernelGGL(edge_bwd_x3_kernel, dim3(grid), dim3(BX_THREADS), BX_LDS_BYTES, st, a);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+}  // namespace ng

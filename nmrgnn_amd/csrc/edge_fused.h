@@ -53,3 +53,12 @@ int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
                 float* z_save);
 }  // namespace ng
+
+namespace ng {
+// backward on the bf16 matrix pipe with split operands (edge_bwd_x3.hip); partial layout of edge_fused_bwd.hip
+bool edge_bwd_x3_supported(int E);
+size_t edge_bwd_x3_ws_bytes();
+int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                       const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
+                       char* wt_img, float* partial, int part_stride, int grid);
+}  // namespace ng

@@ -371,7 +371,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
   const size_t pk_floats = (size_t)3 * FH * FH;
-  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)grid * stride) * 4);
+  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)grid * stride) * 4 + edge_bwd_x3_ws_bytes());
   if (!ws) return NG_ERR_NOMEM;
   float* Wpk = ws;
   float* WpkT = ws + pk_floats;
@@ -387,7 +387,12 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   // NG_EDGE_BWD=v2 selects the one-wave-per-SIMD variant (edge_fused_bwd2.hip: no spills, 4 barriers per
   // tile, but 56 % vs 62 % of the MFMA peak at the bench shape); default is the 8-wave kernel in this file
   const char* ver = getenv("NG_EDGE_BWD");
-  if (ver && std::string(ver) == "v2") {
+  const char* xm = getenv("NG_EDGE_BWD_MATH");   // "bf16x3": split-operand kernel (edge_bwd_x3.hip)
+  if (xm && std::string(xm) == "bf16x3" && edge_bwd_x3_supported(E)) {
+    int rc3 = edge_bwd_x3_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
+                                 (char*)(partial + (size_t)grid * stride), partial, stride, grid);
+    if (rc3) return rc3;
+  } else if (ver && std::string(ver) == "v2") {
     int rc2 = edge_fused_bwd2_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, WpkT, W[3], z_save,
                                      de, partial, stride, grid);
     if (rc2) return rc2;

@@ -30,12 +30,9 @@
 #include <string>
 
 #include "edge_fused.h"
+#include "x3_common.cuh"
 
 namespace ng {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_TM = 256;
 constexpr int X3_CHUNK = 48 * 1024;
@@ -43,21 +40,6 @@ constexpr int X3_NCHUNK = 7;
 constexpr int X3_RING = 2 * X3_CHUNK;
 constexpr int X3_TLD = 36;                 // row stride (floats) of a wave's 32 x 32 transposition tile
 constexpr int X3_TBYTES = 8 * 32 * X3_TLD * 4;
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// (x0, x1) -> packed bf16 pieces; piece p of x0 in the low half, of x1 in the high half
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  m = cvt_pk_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-  l = cvt_pk_bf16(s0, s1);
-}
 
 // feature (within a 32-block) held in k-slot t (0..7) of k-step s by lane half hf  ==  accumulator register 8s+t
 __host__ __device__ inline int x3_feat(int t, int s, int hf) { return (t & 3) + 16 * s + 8 * (t >> 2) + 4 * hf; }
@@ -116,10 +98,6 @@ __device__ __forceinline__ void x3_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, int ci
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(slot + kb * 1024), 16,
                                          lane * 16, cid * X3_CHUNK + kb * 1024, 0, 0);
   }
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ f32x16 x3_bias(const float* __restrict__ sb, int bo, int hf);
