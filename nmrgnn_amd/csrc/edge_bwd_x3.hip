@@ -9,7 +9,7 @@
 //
 // Mapping.  512 threads = 8 waves (2 per SIMD), one persistent workgroup per CU, 64-edge tiles.
 // Every GEMM operand that comes from activations lives in LDS as a bf16-piece IMAGE [3 pieces][64 edges][136]:
-// three images (Z-type, G ping, G pong) = 153 KB.  Elementwise work is done ONCE per element in the accumulator
+// three images (Z-type, G ping, G pong) = 152 KB.  Elementwise work is done ONCE per element in the accumulator
 // layout of the dZ GEMM (lane = edge row, 16 columns of the wave's 32-column slab): the lane that loads Z_l from
 // HBM in that layout splits it into the image AND keeps the fp32 values for s'(Z_l) in its own epilogue.
 //   dZ GEMM (wave: k-slab zk = w&3, edge half zrt = w>>2): A = W^T pieces streamed from a fragment-ordered image
@@ -21,6 +21,7 @@
 //     accumulated in LDS by one owner lane per column (fixed order, no atomics).
 #include <algorithm>
 #include <string>
+#include <cstdio>
 
 #include "edge_fused.h"
 #include "x3_common.cuh"
@@ -31,12 +32,33 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define BX_LDS(T) __attribute__((address_space(3))) T
 
 constexpr int BX_THREADS = 512;
-constexpr int BX_ROWB = 272;                 // image row stride in bytes: 136 bf16 (odd multiple of 16 B)
-constexpr int BX_PIECE = FTM * BX_ROWB;      // 17,408 B
-constexpr int BX_IMG = 3 * BX_PIECE;         // 52,224 B
+// Image geometry.  G images are read as rows (ds_read_b128: stride must be a multiple of 16 B; 272 B = 68 dwords
+// puts 16 consecutive rows on disjoint 4-bank slots) and as columns (transposing reads); the Z image only as
+// columns (stride 264 B: the 8-B piece writes of 32 rows then cost the minimum of 2 LDS cycles).  A transposing
+// read fetches 4 consecutive edges x 32 B per 16-lane group, so the ROWS are stored permuted: the 4 edges of a
+// quad sit 8 banks apart (bx_prow_*), without which every such read is a 2-way bank conflict.
+constexpr int BX_ROWG = 272, BX_ROWZ = 264;
+constexpr int BX_PIECE_G = FTM * BX_ROWG, BX_PIECE_Z = FTM * BX_ROWZ;
+constexpr int BX_IMG_G = 3 * BX_PIECE_G;     // 52,224 B
+constexpr int BX_IMG_Z = 3 * BX_PIECE_Z;     // 50,688 B
 constexpr int BX_STG = 132;                  // fp32 staging row stride (floats)
 constexpr int BX_MISC_FLOATS = FH * 4 + FTM * 4 + 2 * 3 * FH + FH;   // sWo4 | sdE | sDb | sCen
-constexpr int BX_LDS_BYTES = 3 * BX_IMG + BX_MISC_FLOATS * 4;          // 163,328 of 163,840
+constexpr int BX_IMGS = BX_IMG_Z + 2 * BX_IMG_G;
+#ifdef BX_STAMP
+constexpr int BX_LDS_BYTES = BX_IMGS + BX_MISC_FLOATS * 4 + 1024;
+#else
+constexpr int BX_LDS_BYTES = BX_IMGS + BX_MISC_FLOATS * 4;
+#endif             // 161,792 of 163,840
+
+// physical row of edge e (0..63) in the Z image / in a G image
+__device__ __forceinline__ int bx_prow_z(int e) {
+  const int hi = e >> 4, a = (e >> 2) & 3, b = e & 3;
+  return 2 * (a + 4 * b) + (hi & 1) + 32 * (hi >> 1);
+}
+__device__ __forceinline__ int bx_prow_g(int e) {
+  const int hi = e >> 4, a = (e >> 2) & 3, b = e & 3;
+  return 16 * hi + 2 * b + (a & 1) + 8 * (a >> 1);
+}
 
 struct EdgeBwdX3Args {
   int64_t n_edges;
@@ -51,6 +73,7 @@ struct EdgeBwdX3Args {
   float* partial;       // [grid][part_stride], layout of edge_fused_bwd.hip
   int part_stride;
   int E;
+  unsigned long long* stamps;
 };
 
 // W^T fragments of the dZ GEMMs: lane (row k = 32 zk + (l&31), k-slot t) = piece_p( W[k][n = 16 ks + 8 (l>>5) + t] )
@@ -70,7 +93,9 @@ __global__ void x3_pack_wt_kernel(const float* __restrict__ W2, const float* __r
 }
 
 // 16 values of one row (columns col0 + 8q + j, v[4q + j]) -> the three piece planes of an image
+template <int ROWB>
 __device__ __forceinline__ void bx_img_write(char* __restrict__ img, int row, int col0, const float (&v)[16]) {
+  constexpr int BX_ROWB = ROWB, BX_PIECE = FTM * ROWB;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     unsigned h0, m0, l0, h1, m1, l1;
@@ -83,37 +108,47 @@ __device__ __forceinline__ void bx_img_write(char* __restrict__ img, int row, in
   }
 }
 
-// one MFMA operand (8 consecutive edges of this lane's column) = two transposing reads of 4 edges each
-__device__ __forceinline__ u32x4 bx_tr_frag(const char* p) {
+// one MFMA operand (8 consecutive edges of this lane's column) = two transposing reads of 4 edges each; `step` is
+// the byte distance between the two quads' first rows
+__device__ __forceinline__ u32x4 bx_tr_frag(const char* p, int step) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((BX_LDS(s16x4)*)p);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((BX_LDS(s16x4)*)(p + 4 * BX_ROWB));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((BX_LDS(s16x4)*)(p + step));
   const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
   return u32x4{a[0], a[1], b[0], b[1]};
 }
 
+struct BxDwFrags { u32x4 b[3], a0[3], a1[3]; };
+
+// operands of k-step ks (edges 16 ks .. 16 ks + 15): physical rows per bx_prow_z / bx_prow_g
+__device__ __forceinline__ void bx_dw_load(BxDwFrags& f, const char* zb, const char* g0, int ks) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    f.b[p] = bx_tr_frag(zb + p * BX_PIECE_Z + ((ks & 1) + 32 * (ks >> 1)) * BX_ROWZ, 2 * BX_ROWZ);
+    f.a0[p] = bx_tr_frag(g0 + p * BX_PIECE_G + 16 * ks * BX_ROWG, BX_ROWG);
+    f.a1[p] = bx_tr_frag(g0 + 64 + p * BX_PIECE_G + 16 * ks * BX_ROWG, BX_ROWG);
+  }
+}
+
 // acc[j][n][k] += sum_edges G[e][n] Zin[e][k]   (D rows n = G columns of slab nsl0 + j, D cols k = Zin columns of kslab)
+// the operands of step ks+1 are requested before the 12 MFMAs of step ks
 __device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], const char* __restrict__ imgZ,
                                            const char* __restrict__ imgG, int kslab, int nsl0, int lane) {
   const int g = lane >> 4, i = lane & 15;
-  // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2), columns 4(i&3)..+3
-  const int lane_off = (8 * (g >> 1) + (i >> 2)) * BX_ROWB + (16 * (g & 1) + 4 * (i & 3)) * 2;
-  const char* zb = imgZ + lane_off + 64 * kslab;
-  const char* g0 = imgG + lane_off + 64 * nsl0;
+  // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2) of the quad, columns 4(i&3)..+3
+  const char* zb = imgZ + (4 * (g >> 1) + 8 * (i >> 2)) * BX_ROWZ + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * kslab;
+  const char* g0 = imgG + (2 * (i >> 2) + 8 * (g >> 1)) * BX_ROWG + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * nsl0;
+  BxDwFrags f[2];
+  bx_dw_load(f[0], zb, g0, 0);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    u32x4 b[3], a0[3], a1[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      b[p] = bx_tr_frag(zb + p * BX_PIECE + 16 * ks * BX_ROWB);
-      a0[p] = bx_tr_frag(g0 + p * BX_PIECE + 16 * ks * BX_ROWB);
-      a1[p] = bx_tr_frag(g0 + 64 + p * BX_PIECE + 16 * ks * BX_ROWB);
-    }
-    acc[0] = mfma_bf16(a0[2], b[0], acc[0]); acc[1] = mfma_bf16(a1[2], b[0], acc[1]);
-    acc[0] = mfma_bf16(a0[0], b[2], acc[0]); acc[1] = mfma_bf16(a1[0], b[2], acc[1]);
-    acc[0] = mfma_bf16(a0[1], b[1], acc[0]); acc[1] = mfma_bf16(a1[1], b[1], acc[1]);
-    acc[0] = mfma_bf16(a0[1], b[0], acc[0]); acc[1] = mfma_bf16(a1[1], b[0], acc[1]);
-    acc[0] = mfma_bf16(a0[0], b[1], acc[0]); acc[1] = mfma_bf16(a1[0], b[1], acc[1]);
-    acc[0] = mfma_bf16(a0[0], b[0], acc[0]); acc[1] = mfma_bf16(a1[0], b[0], acc[1]);
+    if (ks < 3) bx_dw_load(f[(ks + 1) & 1], zb, g0, ks + 1);
+    const BxDwFrags& c = f[ks & 1];
+    acc[0] = mfma_bf16(c.a0[2], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[2], c.b[0], acc[1]);
+    acc[0] = mfma_bf16(c.a0[0], c.b[2], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[2], acc[1]);
+    acc[0] = mfma_bf16(c.a0[1], c.b[1], acc[0]); acc[1] = mfma_bf16(c.a1[1], c.b[1], acc[1]);
+    acc[0] = mfma_bf16(c.a0[1], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[1], c.b[0], acc[1]);
+    acc[0] = mfma_bf16(c.a0[0], c.b[1], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[1], acc[1]);
+    acc[0] = mfma_bf16(c.a0[0], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[0], acc[1]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -128,28 +163,32 @@ __device__ __forceinline__ void bx_wload(u32x4 (&w)[3], __amdgpu_buffer_rsrc_t w
 
 // dZ[e][k] = sum_n G[e][n] W[k][n]  for k-slab zk, edge rows 32 zrt..; D rows = k, D cols = edges.
 // Returned lane layout: edge 32 zrt + (l&31), columns 32 zk + 8q + 4 (l>>5) + j  in register 4q + j.
-__device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restrict__ imgG, __amdgpu_buffer_rsrc_t wrs,
-                                           int L, int zk, int zrt, int lane) {
-  const int half = lane >> 5, l31 = lane & 31;
-  const char* gb = imgG + (32 * zrt + l31) * BX_ROWB + 16 * half;
+// w0 holds the W^T fragments of step 0 (requested by the caller before the preceding GEMM); steps ks+1, ks+2 are
+// in flight while step ks multiplies (L2 latency is ~3 steps of 6 MFMAs).
+__device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restrict__ imgG, int prow_g,
+                                           __amdgpu_buffer_rsrc_t wrs, const u32x4 (&w0)[3], int L, int zk, int lane) {
+  const int half = lane >> 5;
+  const char* gb = imgG + prow_g * BX_ROWG + 16 * half;
   const int wvo = lane * 16, wso = ((L * 4 + zk) * 8) * 3 * 1024;
-  f32x16 acc0, acc1;
+  f32x16 acc0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  u32x4 wa[2][3];
-  bx_wload(wa[0], wrs, wvo, wso, 0);
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+  u32x4 wa[3][3], b[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { wa[0][p] = w0[p]; b[0][p] = *reinterpret_cast<const u32x4*>(gb + p * BX_PIECE_G); }
+  bx_wload(wa[1], wrs, wvo, wso, 1);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    if (ks < 7) bx_wload(wa[(ks + 1) & 1], wrs, wvo, wso, ks + 1);
-    u32x4 b[3];
+    if (ks < 6) bx_wload(wa[(ks + 2) % 3], wrs, wvo, wso, ks + 2);
+    if (ks < 7) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const u32x4*>(gb + 32 * ks + p * BX_PIECE);
-    if (ks & 1) acc1 = mma6(wa[ks & 1], b, acc1);
-    else acc0 = mma6(wa[ks & 1], b, acc0);
+      for (int p = 0; p < 3; ++p) b[(ks + 1) & 1][p] = *reinterpret_cast<const u32x4*>(gb + 32 * (ks + 1) + p * BX_PIECE_G);
+    }
+    acc0 = mma6(wa[ks % 3], b[ks & 1], acc0);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) out[r] = acc0[r] + acc1[r];
+  for (int r = 0; r < 16; ++r) out[r] = acc0[r];
 }
 
 // sum over the 32 lanes of this lane's half; valid in lanes 31 and 63
@@ -182,21 +221,35 @@ __device__ __forceinline__ void bx_load_z(float (&z)[16], const float* __restric
   typedef float nt4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const nt4 v = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(Zg + grow * FH + col0 + 8 * q));
+    const nt4 v = *reinterpret_cast<const nt4*>(Zg + grow * FH + col0 + 8 * q);
     z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
   }
 }
 
+#ifdef BX_STAMP
+#define BX_T(k)                                                                              \
+  do {                                                                                       \
+    if (lane == 0 && (wave & 3) == 0 && titer >= 2 && titer < 6)                             \
+      sStamp[((wave >> 2) * 4 + (titer - 2)) * 16 + (k)] = __builtin_readcyclecounter();     \
+  } while (0)
+#else
+#define BX_T(k)
+#endif
+
 __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_bx[];
-  char* IZ = smem_bx;                 // Z2 -> Z1 -> R
-  char* GA = smem_bx + BX_IMG;        // G3 -> G1
-  char* GB = smem_bx + 2 * BX_IMG;    // fp32 Z3 staging -> G2
+  char* IZ = smem_bx;                           // Z2 -> Z1 -> R
+  char* GA = smem_bx + BX_IMG_Z;                // G3 -> G1
+  char* GB = smem_bx + BX_IMG_Z + BX_IMG_G;     // fp32 Z3 staging -> G2
   float* stg = reinterpret_cast<float*>(GB);
-  float* sWo4 = reinterpret_cast<float*>(smem_bx + 3 * BX_IMG);   // [128][4]
+  float* sWo4 = reinterpret_cast<float*>(smem_bx + BX_IMGS);      // [128][4]
   float* sdE = sWo4 + FH * 4;         // [64][4]
   float* sDb = sdE + FTM * 4;         // [2 zrt][3 layers][128]
   float* sCen = sDb + 2 * 3 * FH;     // [128]
+#ifdef BX_STAMP
+  unsigned long long* sStamp = reinterpret_cast<unsigned long long*>(sCen + FH);   // [2][4][16]
+  int titer = -1;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,6 +258,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   const int cn = tid & 127, rq = tid >> 7;              // dWo ownership
   const int row = 32 * zrt + l31;                       // this lane's edge row in the tile
   const int col0 = 32 * zk + 4 * half;                  // its columns: col0 + 8q + j
+  const int prz = bx_prow_z(row), prg = bx_prow_g(row); // where that row lives in the images
   const int E = a.E;
 
   for (int t = tid; t < FH * 4; t += BX_THREADS) sWo4[t] = (t & 3) < E ? a.Wo[(t >> 2) * E + (t & 3)] : 0.f;
@@ -230,38 +284,45 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   __syncthreads();
 
   // per-tile inputs of this lane's row, requested one tile ahead
-  float z3r[16], pf_ds, pf_dn, pf_de[4];
+  float z3r[16], z2r[16], pf_ds, pf_dn, pf_de[4];
+  // Nothing here may USE a loaded value (no select, no conversion): a use inside this block makes the compiler
+  // wait for the HBM loads right behind their issue, in front of the GEMM they are meant to hide under.  Indices are
+  // clamped, the masks are applied at the point of use in the next iteration.
   auto prefetch = [&](int64_t row0) {
     const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
     bx_load_z(z3r, Z3g, gr, col0);
-    pf_ds = row0 + row < a.n_edges ? a.d_src[gr] : 0.f;
+    bx_load_z(z2r, Z2g, gr, col0);
+    pf_ds = a.d_src[gr];
     pf_dn = a.d_eff[gr];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const float v = a.de[gr * E + std::min(n, E - 1)];
-      pf_de[n] = n < E ? v : 0.f;
-    }
+    for (int n = 0; n < 4; ++n) pf_de[n] = a.de[gr * E + std::min(n, E - 1)];
   };
   if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
 
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef BX_STAMP
+    ++titer;
+#endif
+    BX_T(0);
     const int64_t row0 = tile * FTM;
     const int64_t grow = std::min<int64_t>(row0 + row, a.n_edges - 1);
-    const bool on = pf_ds > 0.f;
+    const bool on = pf_ds > 0.f && row0 + row < a.n_edges;
     const float dn = pf_dn;
     float dEm[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) dEm[n] = on ? pf_de[n] : 0.f;
-    float z2r[16], z1r[16];
-    bx_load_z(z2r, Z2g, grow, col0);
+    for (int n = 0; n < 4; ++n) dEm[n] = (on && n < E) ? pf_de[n] : 0.f;
+    float z1r[16];
+    bx_load_z(z1r, Z1g, grow, col0);        // used after phase B's GEMMs
     // ------------------------------------------------------------------ phase A
     if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(dEm[0], dEm[1], dEm[2], dEm[3]);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(stg + row * BX_STG + col0 + 8 * q) =
           make_float4(z3r[4 * q + 0], z3r[4 * q + 1], z3r[4 * q + 2], z3r[4 * q + 3]);
+    BX_T(1);
     NG_LDS_BARRIER();
+    BX_T(2);
     // dWo[k][n] += sum_rows Z3[row][k] dE[row][n]   (thread: k = cn, rows 16rq..16rq+15), fp32 on the VALU
 #pragma unroll 4
     for (int r = 16 * rq; r < 16 * rq + 16; ++r) {
@@ -281,35 +342,57 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
           g[4 * q + j] = pre * (1.0f - __expf(-z3r[4 * q + j]));
         }
       bx_bias_accum(g, sDb + (zrt * 3 + 2) * FH + col0, l31);
-      bx_img_write(GA, row, col0, g);
+      bx_img_write<BX_ROWG>(GA, prg, col0, g);
     }
-    bx_img_write(IZ, row, col0, z2r);       // Z2 pieces
-    bx_load_z(z1r, Z1g, grow, col0);        // lands during phase B
+    bx_img_write<BX_ROWZ>(IZ, prz, col0, z2r);       // Z2 pieces
+    u32x4 w0[3];
+    bx_wload(w0, wrs, lane * 16, ((1 * 4 + zk) * 8) * 3 * 1024, 0);
+    BX_T(3);
     NG_LDS_BARRIER();
+    BX_T(4);
     // ------------------------------------------------------------------ phase B (layer 3)
-    bx_dw_gemm(accW[2], IZ, GA, kslab, nsl0, lane);
+    // the two waves of a SIMD (zrt = 0 / 1) take the two independent GEMMs of the phase in opposite order, so that
+    // one wave's epilogue (VALU: s', bias sums, split) runs beside the other's MFMAs
+    if (zrt == 0) bx_dw_gemm(accW[2], IZ, GA, kslab, nsl0, lane);
+    BX_T(5);
     {
       float g[16];
-      bx_dz_gemm(g, GA, wrs, 1, zk, zrt, lane);
+      // the wave whose epilogue comes NEXT gets the matrix pipe first (the arbiter otherwise favours the partner,
+      // which then runs both of its GEMMs back to back and both epilogues end up side by side)
+      if (zrt != 0) __builtin_amdgcn_s_setprio(2);
+      bx_dz_gemm(g, GA, prg, wrs, w0, 1, zk, lane);
+      if (zrt != 0) __builtin_amdgcn_s_setprio(0);
+      BX_T(6);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z2r[r]);
       bx_bias_accum(g, sDb + (zrt * 3 + 1) * FH + col0, l31);
-      bx_img_write(GB, row, col0, g);       // G2
+      bx_img_write<BX_ROWG>(GB, prg, col0, g);       // G2
     }
+    BX_T(7);
+    if (zrt != 0) bx_dw_gemm(accW[2], IZ, GA, kslab, nsl0, lane);
+    BX_T(8);
     NG_LDS_BARRIER();
-    bx_img_write(IZ, row, col0, z1r);       // Z1 pieces
+    BX_T(9);
+    bx_img_write<BX_ROWZ>(IZ, prz, col0, z1r);       // Z1 pieces
+    bx_wload(w0, wrs, lane * 16, ((0 * 4 + zk) * 8) * 3 * 1024, 0);
     NG_LDS_BARRIER();
+    BX_T(10);
     // ------------------------------------------------------------------ phase C (layer 2)
-    bx_dw_gemm(accW[1], IZ, GB, kslab, nsl0, lane);
+    if (zrt == 0) bx_dw_gemm(accW[1], IZ, GB, kslab, nsl0, lane);
     {
       float g[16];
-      bx_dz_gemm(g, GB, wrs, 0, zk, zrt, lane);
+      if (zrt != 0) __builtin_amdgcn_s_setprio(2);
+      bx_dz_gemm(g, GB, prg, wrs, w0, 0, zk, lane);
+      if (zrt != 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z1r[r]);
       bx_bias_accum(g, sDb + (zrt * 3 + 0) * FH + col0, l31);
-      bx_img_write(GA, row, col0, g);       // G1
+      bx_img_write<BX_ROWG>(GA, prg, col0, g);       // G1
     }
+    BX_T(11);
+    if (zrt != 0) bx_dw_gemm(accW[1], IZ, GB, kslab, nsl0, lane);
     NG_LDS_BARRIER();
+    BX_T(12);
     {   // R = m * rbf(d_eff)  ->  IZ   (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
       float rr[16];
       const float dm = on ? dn : 1.0e19f;
@@ -322,15 +405,23 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
         rr[4 * q + 2] = __builtin_amdgcn_exp2f(u2 * u2 * a.neg_inv_gap_log2e);
         rr[4 * q + 3] = __builtin_amdgcn_exp2f(u3 * u3 * a.neg_inv_gap_log2e);
       }
-      bx_img_write(IZ, row, col0, rr);
+      bx_img_write<BX_ROWZ>(IZ, prz, col0, rr);
     }
     NG_LDS_BARRIER();
+    BX_T(13);
     // ------------------------------------------------------------------ phase D (layer 1)
-    if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * FTM);
+    prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
     bx_dw_gemm(accW[0], IZ, GA, kslab, nsl0, lane);
+    BX_T(14);
     NG_LDS_BARRIER();
+    BX_T(15);
   }
 
+#ifdef BX_STAMP
+  __syncthreads();
+  if (blockIdx.x == 3 && tid < 128) a.stamps[tid] = sStamp[tid];
+  __syncthreads();
+#endif
   // ---------------------------------------------------------------------- write this workgroup's partial
   float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
   {
@@ -374,9 +465,32 @@ int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
   a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
   a.wt_img = wt_img; a.Wo = W[3]; a.z_save = z_save; a.de = de;
   a.partial = partial; a.part_stride = part_stride; a.E = E;
+  a.stamps = nullptr;
+#ifdef BX_STAMP
+  static unsigned long long* dbg = nullptr;
+  if (!dbg) { hipMalloc(&dbg, 1024); }
+  a.stamps = dbg;
+#endif
   ProfScope ps(ctx, st, "edge_bwd_x3");
   hipLaunchKernelGGL(edge_bwd_x3_kernel, dim3(grid), dim3(BX_THREADS), BX_LDS_BYTES, st, a);
   NG_HIP(ctx, hipGetLastError());
+#ifdef BX_STAMP
+  {
+    static int calls = 0;
+    if (++calls == 3) {
+      unsigned long long h[128];
+      hipStreamSynchronize(st);
+      hipMemcpy(h, a.stamps, 1024, hipMemcpyDeviceToHost);
+      for (int w = 0; w < 2; ++w)
+        for (int t = 0; t < 4; ++t) {
+          printf("wave %d tile %d:", 4 * w, t);
+          for (int k = 1; k < 16; ++k) printf(" %5lld", (long long)(h[(w * 4 + t) * 16 + k] - h[(w * 4 + t) * 16 + k - 1]));
+          if (t < 3) printf(" | next %5lld", (long long)(h[(w * 4 + t + 1) * 16] - h[(w * 4 + t) * 16 + 15]));
+          printf("\n");
+        }
+    }
+  }
+#endif
   return NG_OK;
 }
 
