@@ -37,7 +37,7 @@ PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 PEAK_MFMA_BF16_TFLOPS = 2516.6  # dense bf16: 256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz
 # kernels that run fp32 arithmetic on the bf16 pipe (three-way operand split, 6 piece products per multiply):
 # priced with their ALGORITHMIC fp32 flops against bf16 peak / 6
-X3_KERNELS = {"edge_fwd_x3"}
+X3_KERNELS = {"edge_fwd_x3", "edge_bwd_x3"}
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 achievable
 
 ARCH = dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
@@ -56,6 +56,8 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C):
         "edge_fused_fwd": ("mfma", 2.0 * ne * ((Le - 1) * H * H + H * E),
                            f4 * ne * (1 + 1 + E + (Le - 1) * H)),
         "edge_fwd_x3": ("mfma", 2.0 * ne * ((Le - 1) * H * H + H * E),
+                        f4 * ne * (1 + 1 + E + (Le - 1) * H)),
+        "edge_bwd_x3": ("mfma", 2.0 * ne * ((2 * (Le - 1) - 1) * H * H + 2 * H * E),
                         f4 * ne * (1 + 1 + E + (Le - 1) * H)),
         "edge_fused_bwd": ("mfma", 2.0 * ne * ((2 * (Le - 1) - 1) * H * H + 2 * H * E),
                            f4 * ne * (1 + 1 + E + (Le - 1) * H)),
@@ -240,9 +242,9 @@ def main():
                    "atoms_per_gpu": gb.N, "edges_per_gpu": gb.N * K_NEIGH,
                    "parallelism": f"graph-parallel dp{world}", "params": eng.params.count()},
         "loss": final_loss,
-        "matrix_math": ("edge forward: bf16 MFMA on fp32 operands split exactly into 3 bf16 pieces, 6 piece products "
-                        "per multiply, fp32 accumulate (fp32-level error, tests/test_gpu_edge_x3.py); all other "
-                        "contractions: f32-input MFMA"
+        "matrix_math": ("edge MLP forward and backward: bf16 MFMA on fp32 operands split exactly into 3 bf16 pieces, "
+                        "6 piece products per multiply, fp32 accumulate (fp32-level error, tests/test_gpu_edge_x3.py); "
+                        "all other contractions: f32-input MFMA"
                         if os.environ.get("NG_EDGE_MATH", "") != "fp32" else "f32-input MFMA everywhere"),
     }
 

@@ -17,8 +17,7 @@
 //   dW GEMM (wave: k-slab w>>1, n-slabs 2(w&1)+{0,1}; contraction over the tile's 64 edges): both operands are
 //     COLUMNS of an image; ds_read_b64_tr_b16 delivers a lane 4 consecutive edges of its column (two reads = one
 //     8-edge MFMA operand), 48 MFMAs per layer.  The three 128x128 accumulators stay in registers (96 VGPRs).
-//   Bias gradients: the 16 per-lane values are summed over the 32 rows of a lane half with 5 DPP adds and
-//     accumulated in LDS by one owner lane per column (fixed order, no atomics).
+//   Bias gradients ride on the dW GEMM: G^T x ones in one extra accumulator (bx_dw_gemm).
 #include <algorithm>
 #include <string>
 #include <cstdio>
@@ -42,7 +41,7 @@ constexpr int BX_PIECE_G = FTM * BX_ROWG, BX_PIECE_Z = FTM * BX_ROWZ;
 constexpr int BX_IMG_G = 3 * BX_PIECE_G;     // 52,224 B
 constexpr int BX_IMG_Z = 3 * BX_PIECE_Z;     // 50,688 B
 constexpr int BX_STG = 132;                  // fp32 staging row stride (floats)
-constexpr int BX_MISC_FLOATS = FH * 4 + FTM * 4 + 2 * 3 * FH + FH;   // sWo4 | sdE | sDb | sCen
+constexpr int BX_MISC_FLOATS = FH * 4 + FTM * 4 + FH;   // sWo4 | sdE | sCen
 constexpr int BX_IMGS = BX_IMG_Z + 2 * BX_IMG_G;
 #ifdef BX_STAMP
 constexpr int BX_LDS_BYTES = BX_IMGS + BX_MISC_FLOATS * 4 + 1024;
@@ -131,24 +130,33 @@ __device__ __forceinline__ void bx_dw_load(BxDwFrags& f, const char* zb, const c
 
 // acc[j][n][k] += sum_edges G[e][n] Zin[e][k]   (D rows n = G columns of slab nsl0 + j, D cols k = Zin columns of kslab)
 // the operands of step ks+1 are requested before the 12 MFMAs of step ks
-__device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], const char* __restrict__ imgZ,
+// Bias gradient on the matrix pipe: db[n] = sum_e G[e][n] = G^T x ones.  In the step ks == kslab (the four waves
+// that share an n-slab pair split the tile's edges) the G fragments are multiplied once more by a B operand that
+// is 1.0 in five columns (5c .. 5c+4, c = 2 layer + j) and 0 elsewhere: ONE accumulator collects all six
+// (layer, n-slab) column sums in disjoint column groups — 6 MFMAs per layer instead of 80 DPP adds + an LDS update.
+__device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], f32x16& accB, int cbase, const char* __restrict__ imgZ,
                                            const char* __restrict__ imgG, int kslab, int nsl0, int lane) {
+  const unsigned grp = (unsigned)((lane & 31) / 5);
+  const unsigned o0 = grp == (unsigned)cbase ? 0x3F803F80u : 0u, o1 = grp == (unsigned)(cbase + 1) ? 0x3F803F80u : 0u;
+  const u32x4 ones0 = {o0, o0, o0, o0}, ones1 = {o1, o1, o1, o1};
   const int g = lane >> 4, i = lane & 15;
   // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2) of the quad, columns 4(i&3)..+3
   const char* zb = imgZ + (4 * (g >> 1) + 8 * (i >> 2)) * BX_ROWZ + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * kslab;
   const char* g0 = imgG + (2 * (i >> 2) + 8 * (g >> 1)) * BX_ROWG + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * nsl0;
-  BxDwFrags f[2];
-  bx_dw_load(f[0], zb, g0, 0);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    if (ks < 3) bx_dw_load(f[(ks + 1) & 1], zb, g0, ks + 1);
-    const BxDwFrags& c = f[ks & 1];
+    BxDwFrags c;       // single-buffered: the kernel has no registers for a second set; the partner wave covers the LDS latency
+    bx_dw_load(c, zb, g0, ks);
     acc[0] = mfma_bf16(c.a0[2], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[2], c.b[0], acc[1]);
     acc[0] = mfma_bf16(c.a0[0], c.b[2], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[2], acc[1]);
     acc[0] = mfma_bf16(c.a0[1], c.b[1], acc[0]); acc[1] = mfma_bf16(c.a1[1], c.b[1], acc[1]);
     acc[0] = mfma_bf16(c.a0[1], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[1], c.b[0], acc[1]);
     acc[0] = mfma_bf16(c.a0[0], c.b[1], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[1], acc[1]);
     acc[0] = mfma_bf16(c.a0[0], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[0], acc[1]);
+    if (ks == kslab) {
+#pragma unroll
+      for (int p = 2; p >= 0; --p) { accB = mfma_bf16(c.a0[p], ones0, accB); accB = mfma_bf16(c.a1[p], ones1, accB); }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -173,55 +181,32 @@ __device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restr
   f32x16 acc0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-  u32x4 wa[3][3], b[2][3];
+  u32x4 wa[2][3], b[2][3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) { wa[0][p] = w0[p]; b[0][p] = *reinterpret_cast<const u32x4*>(gb + p * BX_PIECE_G); }
-  bx_wload(wa[1], wrs, wvo, wso, 1);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    if (ks < 6) bx_wload(wa[(ks + 2) % 3], wrs, wvo, wso, ks + 2);
     if (ks < 7) {
+      bx_wload(wa[(ks + 1) & 1], wrs, wvo, wso, ks + 1);
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[(ks + 1) & 1][p] = *reinterpret_cast<const u32x4*>(gb + 32 * (ks + 1) + p * BX_PIECE_G);
     }
-    acc0 = mma6(wa[ks % 3], b[ks & 1], acc0);
+    acc0 = mma6(wa[ks & 1], b[ks & 1], acc0);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) out[r] = acc0[r];
 }
 
-// sum over the 32 lanes of this lane's half; valid in lanes 31 and 63
-__device__ __forceinline__ float bx_half_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast15 -> rows 1, 3
-  return v;
-}
-
-// db[col] += sum_rows g[.]: lane 31 / 63 own columns sdb[8q + j] (sdb already offset by 32 zk + 4 half)
-__device__ __forceinline__ void bx_bias_accum(const float (&g)[16], float* __restrict__ sdb, int l31) {
-  float s[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s[r] = bx_half_sum(g[r]);
-  if (l31 == 31) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 c = *reinterpret_cast<float4*>(sdb + 8 * q);
-      c.x += s[4 * q + 0]; c.y += s[4 * q + 1]; c.z += s[4 * q + 2]; c.w += s[4 * q + 3];
-      *reinterpret_cast<float4*>(sdb + 8 * q) = c;
-    }
-  }
-}
-
-// this lane's 16 values of a saved activation row (clamped row: rows past the end multiply a zero gradient)
-__device__ __forceinline__ void bx_load_z(float (&z)[16], const float* __restrict__ Zg, int64_t grow, int col0) {
-  typedef float nt4 __attribute__((ext_vector_type(4)));
+// this lane's 16 values of a saved activation row (clamped row: rows past the end multiply a zero gradient).
+// Buffer loads: scalar resource + one 32-bit lane offset — per-lane 64-bit pointers for five arrays got spilled and
+// every reload put a vmcnt(0) into the middle of the prefetch.
+__device__ __forceinline__ void bx_load_z(float (&z)[16], __amdgpu_buffer_rsrc_t rs, int voff) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const nt4 v = *reinterpret_cast<const nt4*>(Zg + grow * FH + col0 + 8 * q);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 32 * q, 0);
+    const f32x4v v = __builtin_bit_cast(f32x4v, raw);
     z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
   }
 }
@@ -244,8 +229,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   float* stg = reinterpret_cast<float*>(GB);
   float* sWo4 = reinterpret_cast<float*>(smem_bx + BX_IMGS);      // [128][4]
   float* sdE = sWo4 + FH * 4;         // [64][4]
-  float* sDb = sdE + FTM * 4;         // [2 zrt][3 layers][128]
-  float* sCen = sDb + 2 * 3 * FH;     // [128]
+  float* sCen = sdE + FTM * 4;        // [128]
 #ifdef BX_STAMP
   unsigned long long* sStamp = reinterpret_cast<unsigned long long*>(sCen + FH);   // [2][4][16]
   int titer = -1;
@@ -262,7 +246,6 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   const int E = a.E;
 
   for (int t = tid; t < FH * 4; t += BX_THREADS) sWo4[t] = (t & 3) < E ? a.Wo[(t >> 2) * E + (t & 3)] : 0.f;
-  for (int t = tid; t < 2 * 3 * FH; t += BX_THREADS) sDb[t] = 0.f;
   if (tid < FH) sCen[tid] = a.centers[tid];
 
   f32x16 accW[3][2];
@@ -272,13 +255,21 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accW[l][j][r] = 0.f;
+  f32x16 accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = 0.f;
   float accWo[4] = {0.f, 0.f, 0.f, 0.f};
   float accbo = 0.f;
 
   const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
-  const float* Z1g = a.z_save;
-  const float* Z2g = a.z_save + a.n_edges * FH;
-  const float* Z3g = a.z_save + 2 * a.n_edges * FH;
+  // one buffer resource per array (offsets are 32-bit: n_edges * 512 B < 4 GB, checked by the host)
+  const unsigned zbytes = (unsigned)(a.n_edges * FH * 4);
+  const __amdgpu_buffer_rsrc_t rsZ1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + a.n_edges * FH), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + 2 * a.n_edges * FH), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_src), 0, (unsigned)(a.n_edges * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_eff), 0, (unsigned)(a.n_edges * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDe = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.de), 0, (unsigned)(a.n_edges * a.E * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wt_img), 0, 2 * 4 * 8 * 3 * 1024, 0x00020000);
   __syncthreads();
@@ -290,12 +281,14 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   // clamped, the masks are applied at the point of use in the next iteration.
   auto prefetch = [&](int64_t row0) {
     const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
-    bx_load_z(z3r, Z3g, gr, col0);
-    bx_load_z(z2r, Z2g, gr, col0);
-    pf_ds = a.d_src[gr];
-    pf_dn = a.d_eff[gr];
+    const int gi = (int)gr;
+    bx_load_z(z3r, rsZ3, gi * (FH * 4) + col0 * 4);
+    bx_load_z(z2r, rsZ2, gi * (FH * 4) + col0 * 4);
+    pf_ds = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDs, gi * 4, 0, 0));
+    pf_dn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDn, gi * 4, 0, 0));
 #pragma unroll
-    for (int n = 0; n < 4; ++n) pf_de[n] = a.de[gr * E + std::min(n, E - 1)];
+    for (int n = 0; n < 4; ++n)
+      pf_de[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDe, (gi * E + std::min(n, E - 1)) * 4, 0, 0));
   };
   if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
 
@@ -313,7 +306,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
 #pragma unroll
     for (int n = 0; n < 4; ++n) dEm[n] = (on && n < E) ? pf_de[n] : 0.f;
     float z1r[16];
-    bx_load_z(z1r, Z1g, grow, col0);        // used after phase B's GEMMs
+    bx_load_z(z1r, rsZ1, (int)grow * (FH * 4) + col0 * 4);        // used after phase B's GEMMs
     // ------------------------------------------------------------------ phase A
     if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(dEm[0], dEm[1], dEm[2], dEm[3]);
 #pragma unroll
@@ -341,7 +334,6 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
           const float pre = dEm[0] * w.x + dEm[1] * w.y + dEm[2] * w.z + dEm[3] * w.w;
           g[4 * q + j] = pre * (1.0f - __expf(-z3r[4 * q + j]));
         }
-      bx_bias_accum(g, sDb + (zrt * 3 + 2) * FH + col0, l31);
       bx_img_write<BX_ROWG>(GA, prg, col0, g);
     }
     bx_img_write<BX_ROWZ>(IZ, prz, col0, z2r);       // Z2 pieces
@@ -353,7 +345,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     // ------------------------------------------------------------------ phase B (layer 3)
     // the two waves of a SIMD (zrt = 0 / 1) take the two independent GEMMs of the phase in opposite order, so that
     // one wave's epilogue (VALU: s', bias sums, split) runs beside the other's MFMAs
-    if (zrt == 0) bx_dw_gemm(accW[2], IZ, GA, kslab, nsl0, lane);
+    if (zrt == 0) bx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
     BX_T(5);
     {
       float g[16];
@@ -365,11 +357,10 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       BX_T(6);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z2r[r]);
-      bx_bias_accum(g, sDb + (zrt * 3 + 1) * FH + col0, l31);
       bx_img_write<BX_ROWG>(GB, prg, col0, g);       // G2
     }
     BX_T(7);
-    if (zrt != 0) bx_dw_gemm(accW[2], IZ, GA, kslab, nsl0, lane);
+    if (zrt != 0) bx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
     BX_T(8);
     NG_LDS_BARRIER();
     BX_T(9);
@@ -378,7 +369,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     NG_LDS_BARRIER();
     BX_T(10);
     // ------------------------------------------------------------------ phase C (layer 2)
-    if (zrt == 0) bx_dw_gemm(accW[1], IZ, GB, kslab, nsl0, lane);
+    if (zrt == 0) bx_dw_gemm(accW[1], accB, 2, IZ, GB, kslab, nsl0, lane);
     {
       float g[16];
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
@@ -386,11 +377,10 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z1r[r]);
-      bx_bias_accum(g, sDb + (zrt * 3 + 0) * FH + col0, l31);
       bx_img_write<BX_ROWG>(GA, prg, col0, g);       // G1
     }
     BX_T(11);
-    if (zrt != 0) bx_dw_gemm(accW[1], IZ, GB, kslab, nsl0, lane);
+    if (zrt != 0) bx_dw_gemm(accW[1], accB, 2, IZ, GB, kslab, nsl0, lane);
     NG_LDS_BARRIER();
     BX_T(12);
     {   // R = m * rbf(d_eff)  ->  IZ   (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
@@ -411,7 +401,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     BX_T(13);
     // ------------------------------------------------------------------ phase D (layer 1)
     prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
-    bx_dw_gemm(accW[0], IZ, GA, kslab, nsl0, lane);
+    bx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
     BX_T(14);
     NG_LDS_BARRIER();
     BX_T(15);
@@ -440,9 +430,20 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   }
   // bias sums of the two edge halves, dWo / dbo of the four row quarters: summed through LDS (IZ is free now)
   float* red = reinterpret_cast<float*>(IZ);
+  float* dbw = reinterpret_cast<float*>(GA);     // [4 k-slab waves][3 layers][128]
   const int red_stride = 3 * FH + FH * E + E;
+  {
+    const int c = l31 / 5;     // this lane's column group; its first column carries the sums
+    if (c < 6 && l31 == 5 * c && (c & 1) >= 0) {
+      const int layer = c >> 1, j = c & 1;
 #pragma unroll
-  for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = rq < 2 ? sDb[(rq * 3 + l) * FH + cn] : 0.f;
+      for (int r = 0; r < 16; ++r)
+        dbw[(kslab * 3 + layer) * FH + 32 * (nsl0 + j) + (r & 3) + 8 * (r >> 2) + 4 * half] = accB[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = dbw[(rq * 3 + l) * FH + cn];
   for (int n = 0; n < E; ++n) red[rq * red_stride + 3 * FH + cn * E + n] = accWo[n];
   if (cn < E) red[rq * red_stride + 3 * FH + FH * E + cn] = accbo;
   __syncthreads();
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
 }
 
-bool edge_bwd_x3_supported(int E) { return E >= 1 && E <= 4; }
+bool edge_bwd_x3_supported(int E, int64_t n_edges) { return E >= 1 && E <= 4 && n_edges * FH * 4 < ((int64_t)1 << 32); }
 
 size_t edge_bwd_x3_ws_bytes() { return (size_t)2 * 4 * 8 * 3 * 1024; }
 

@@ -56,7 +56,7 @@ int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
 
 namespace ng {
 // backward on the bf16 matrix pipe with split operands (edge_bwd_x3.hip); partial layout of edge_fused_bwd.hip
-bool edge_bwd_x3_supported(int E);
+bool edge_bwd_x3_supported(int E, int64_t n_edges);
 size_t edge_bwd_x3_ws_bytes();
 int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,

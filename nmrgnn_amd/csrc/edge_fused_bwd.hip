@@ -387,8 +387,10 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   // NG_EDGE_BWD=v2 selects the one-wave-per-SIMD variant (edge_fused_bwd2.hip: no spills, 4 barriers per
   // tile, but 56 % vs 62 % of the MFMA peak at the bench shape); default is the 8-wave kernel in this file
   const char* ver = getenv("NG_EDGE_BWD");
-  const char* xm = getenv("NG_EDGE_BWD_MATH");   // "bf16x3": split-operand kernel (edge_bwd_x3.hip)
-  if (xm && std::string(xm) == "bf16x3" && edge_bwd_x3_supported(E)) {
+  // default: split-operand kernel on the bf16 matrix pipe (edge_bwd_x3.hip); NG_EDGE_MATH=fp32 (both directions) or
+  // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
+  const char* xm = getenv("NG_EDGE_BWD_MATH");
+  if (edge_x3_enabled() && !(xm && std::string(xm) == "fp32") && edge_bwd_x3_supported(E, n_edges)) {
     int rc3 = edge_bwd_x3_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
                                  (char*)(partial + (size_t)grid * stride), partial, stride, grid);
     if (rc3) return rc3;

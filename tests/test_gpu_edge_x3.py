@@ -76,3 +76,85 @@ def test_edge_forward_split_vs_float64(gpu_device, monkeypatch, n, E, save):
                 assert rms["bf16x3"] < 1.2 * rms["fp32"] + 1e-8, (l, rms)
     # masked edges give exact zeros, rows past the end are never written
     assert np.all(out["bf16x3"][0][d_src == 0] == 0.0)
+
+
+def ref_edge_bwd(d_src, d_eff, centers, gap, Ws, bs, de):
+    """float64 backward of ref_edge w.r.t. the weights and biases (distances are not trainable)"""
+    m = (d_src > 0).astype(np.float64)
+    R = np.exp(-(d_eff[:, None] - centers[None, :]) ** 2 / gap) * m[:, None]
+    xs = [R]
+    for W, b in zip(Ws[:-1], bs[:-1]):
+        xs.append(softplus(xs[-1] @ W + b))
+    dE = de * m[:, None]
+    dWs, dbs = [None] * 4, [None] * 4
+    dWs[3], dbs[3] = xs[3].T @ dE, dE.sum(0)
+    g = dE @ Ws[3].T
+    for l in (2, 1, 0):
+        G = g * (1.0 - np.exp(-xs[l + 1]))
+        dWs[l], dbs[l] = xs[l].T @ G, G.sum(0)
+        g = G @ Ws[l].T
+    return dWs, dbs, xs[1:]
+
+
+def run_gpu_bwd(dev, d_src, d_eff, centers, gap, Ws, zs, de, E):
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr, ptr_array
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    n = len(d_src)
+    td, te, tc, tde = t(d_src), t(d_eff), t(centers), t(de)
+    tW = [t(w) for w in Ws]
+    tz = t(np.stack(zs))
+    dW = [torch.full((H, H), 7.0, device=dev) for _ in range(3)] + [torch.full((H, E), 7.0, device=dev)]
+    db = [torch.full((H,), 7.0, device=dev) for _ in range(3)] + [torch.full((E,), 7.0, device=dev)]
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.check(ctx.lib.ng_edge_mlp_bwd(ctx.handle, st, n, H, E, 4, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
+                                      ptr(tz), ptr(tde), ptr_array(dW), ptr_array(db)), "ng_edge_mlp_bwd")
+    torch.cuda.synchronize()
+    return [w.cpu().numpy().astype(np.float64) for w in dW], [b.cpu().numpy().astype(np.float64) for b in db]
+
+
+@pytest.mark.parametrize("n,E", [(1, 3), (63, 3), (65, 1), (5000, 4), (70001, 3), (4096, 2), (3000, 8), (1048576, 3)])
+def test_edge_backward_split_vs_float64(gpu_device, monkeypatch, n, E):
+    """weight / bias gradients of the edge path: split-operand kernel (default, E <= 4; E = 8 exercises the fall-back)
+    and the f32-input MFMA kernel against float64, on the SAME saved activations (float32-rounded float64 ones)"""
+    rng = np.random.default_rng(7 * n + E)
+    d_src = rng.uniform(0.05, 1.2, n)
+    d_src[rng.random(n) < 0.15] = 0.0
+    d_eff = np.where(d_src > 0, d_src + 0.025 * rng.standard_normal(n), d_src)
+    centers = np.linspace(0.0, 1.2, H)
+    gap = centers[1] - centers[0]
+    Ws = [rng.standard_normal((H, H)) * 0.15 for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2]
+    bs = [rng.standard_normal(H) * 0.1 for _ in range(3)] + [rng.standard_normal(E) * 0.1]
+    de = rng.standard_normal((n, E))
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    Wf, bf = [f32(w) for w in Ws], [f32(b) for b in bs]
+    _, _, zs = ref_edge_bwd(f32(d_src), f32(d_eff), f32(centers), float(np.float32(gap)), Wf, bf, f32(de))
+    zs32 = [f32(z) for z in zs]            # what the forward would have saved
+    # reference gradients computed FROM the float32-rounded activations, like the kernels do
+    m = (f32(d_src) > 0).astype(np.float64)
+    R = np.exp(-(f32(d_eff)[:, None] - f32(centers)[None, :]) ** 2 / float(np.float32(gap))) * m[:, None]
+    xs = [R] + zs32
+    dE = f32(de) * m[:, None]
+    # a gradient entry is a sum over the edges: its rounding error scales with the sum of |terms| (mag), not with the
+    # (often cancelling) result
+    ref_dW, ref_db, mag_dW, mag_db = [None] * 4, [None] * 4, [None] * 4, [None] * 4
+    ref_dW[3], ref_db[3] = xs[3].T @ dE, dE.sum(0)
+    mag_dW[3], mag_db[3] = np.abs(xs[3]).T @ np.abs(dE), np.abs(dE).sum(0)
+    g = dE @ Wf[3].T
+    for l in (2, 1, 0):
+        G = g * (1.0 - np.exp(-xs[l + 1]))
+        ref_dW[l], ref_db[l] = xs[l].T @ G, G.sum(0)
+        mag_dW[l], mag_db[l] = np.abs(xs[l]).T @ np.abs(G), np.abs(G).sum(0)
+        g = G @ Wf[l].T
+    out = {}
+    for math in ("bf16x3", "fp32"):
+        monkeypatch.setenv("NG_EDGE_MATH", math)
+        out[math] = run_gpu_bwd(gpu_device, d_src, d_eff, centers, gap, Ws, zs32, de, E)
+    for l in range(4):
+        for name, ref, mag, k in (("dW", ref_dW[l], mag_dW[l], 0), ("db", ref_db[l], mag_db[l], 1)):
+            scale = max(mag.max(), 1e-6)
+            err = {mth: np.abs(o[k][l] - ref).max() / scale for mth, o in out.items()}
+            assert err["bf16x3"] < 1e-6, (name, l, err)                 # ~16 fp32 roundings of the term scale
+            assert err["bf16x3"] < 4.0 * err["fp32"] + 1e-7, (name, l, err)

@@ -12,7 +12,7 @@ VARIANTS = [
     {"NG_MP_PATH": "win"}, {"NG_MP_PATH": "split"}, {"NG_MP_PATH": "fused"}, {"NG_MP_PATH": "layered"}, {"NG_EDGE_BWD": "v2"}, {"NG_EDGE_FWD": "tm32"}, {"NG_EDGE_FWD": "tm128"},
     {"NG_EDGE_PATH": "layered"}, {"NG_DENSE_PATH": "generic"}, {"NG_FC_PATH": "layered"}, {"NG_HEAD_PATH": "generic"},
     {"NG_MP_BWD": "split"}, {"NG_MP_BWD": "edge"},
-    {"NG_MP_PATH": "layered", "NG_AGG_PATH": "window"}, {"NG_EDGE_MATH": "fp32"}, {"NG_EDGE_BWD_MATH": "bf16x3"},
+    {"NG_MP_PATH": "layered", "NG_AGG_PATH": "window"}, {"NG_EDGE_MATH": "fp32"}, {"NG_EDGE_BWD_MATH": "fp32"},
 ]
 
 
