@@ -283,14 +283,18 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
     const int gi = (int)gr;
     bx_load_z(z3r, rsZ3, gi * (FH * 4) + col0 * 4);
-    bx_load_z(z2r, rsZ2, gi * (FH * 4) + col0 * 4);
     pf_ds = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDs, gi * 4, 0, 0));
     pf_dn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDn, gi * 4, 0, 0));
 #pragma unroll
     for (int n = 0; n < 4; ++n)
       pf_de[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDe, (gi * E + std::min(n, E - 1)) * 4, 0, 0));
   };
-  if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
+  // Z2 of the next tile: its registers are free only after phase B's epilogue
+  auto prefetch_z2 = [&](int64_t row0) {
+    const int gi = (int)std::min<int64_t>(row0 + row, a.n_edges - 1);
+    bx_load_z(z2r, rsZ2, gi * (FH * 4) + col0 * 4);
+  };
+  if ((int64_t)blockIdx.x < ntiles) { prefetch((int64_t)blockIdx.x * FTM); prefetch_z2((int64_t)blockIdx.x * FTM); }
 
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -375,6 +379,9 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
       bx_dz_gemm(g, GB, prg, wrs, w0, 0, zk, lane);
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
+      // next tile's Z3 / d / dE (registers dead since phase A).  Issued BEHIND the last W^T fragment loads of the tile:
+      // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
+      prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z1r[r]);
       bx_img_write<BX_ROWG>(GA, prg, col0, g);       // G1
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     NG_LDS_BARRIER();
     BX_T(13);
     // ------------------------------------------------------------------ phase D (layer 1)
-    prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
+    prefetch_z2(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
     bx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
     BX_T(14);
     NG_LDS_BARRIER();
