@@ -125,8 +125,14 @@ __device__ __forceinline__ void x3_load_a(const u32x4* fr, int step, u32x4 (&a0)
 // half a hidden layer: two output blocks from the chunk in `slot`; 8 steps (bi, s), the weight fragments of
 // step i+1 are requested before the 12 MFMAs of step i (explicit two-deep pipeline: left to itself the compiler
 // hoists every ds_read of the chunk and spills).  The accumulators start at the bias.
+__device__ __forceinline__ float x3_softplus(float x);
+
+// PRE: while this chunk multiplies, the softplus of the two blocks the PREVIOUS chunk finished (pre0, pre1) runs in
+// its shadow, four elements per step — VALU work taken out of the lock-stepped layer epilogue
+template <bool PRE>
 __device__ __forceinline__ void x3_hidden_chunk(const char* slot, const u32x4 (&bf)[4][2][3], f32x16& acc0,
-                                                f32x16& acc1, const float* __restrict__ sb, int bo0, int lane) {
+                                                f32x16& acc1, const float* __restrict__ sb, int bo0, int lane,
+                                                f32x16& pre0, f32x16& pre1) {
   const u32x4* fr = reinterpret_cast<const u32x4*>(slot) + lane;
   u32x4 a0[2][3], a1[2][3];
   x3_load_a(fr, 0, a0[0], a1[0]);
@@ -136,6 +142,10 @@ __device__ __forceinline__ void x3_hidden_chunk(const char* slot, const u32x4 (&
   for (int step = 0; step < 8; ++step) {
     if (step < 7) x3_load_a(fr, step + 1, a0[(step + 1) & 1], a1[(step + 1) & 1]);
     mma6x2(a0[step & 1], a1[step & 1], bf[step >> 1][step & 1], acc0, acc1);
+    if (PRE) {
+      pre0[2 * step] = x3_softplus(pre0[2 * step]); pre0[2 * step + 1] = x3_softplus(pre0[2 * step + 1]);
+      pre1[2 * step] = x3_softplus(pre1[2 * step]); pre1[2 * step + 1] = x3_softplus(pre1[2 * step + 1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -158,7 +168,7 @@ __device__ __forceinline__ f32x16 x3_bias(const float* __restrict__ sb, int bo, 
 // layer epilogue for one output block: softplus, optional save, split into the next layer's B fragments.
 // Saved rows go through a wave-private LDS tile: a lane holds 16-B pieces of 32 different rows (512-B stride in
 // memory: measured 1.7 TB/s), after the transposition 8 lanes write one 128-B line of a row.
-template <bool SAVE>
+template <bool SAVE, bool SP>
 __device__ __forceinline__ void x3_epilogue(const f32x16& acc, u32x4 (&bfo)[2][3], float* __restrict__ tb,
                                             float* __restrict__ zblk, float* __restrict__ dummy, int rows_left,
                                             int lane) {
@@ -166,8 +176,8 @@ __device__ __forceinline__ void x3_epilogue(const f32x16& acc, u32x4 (&bfo)[2][3
   const int hf = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float z0 = x3_softplus(acc[4 * q + 0]), z1 = x3_softplus(acc[4 * q + 1]);
-    const float z2 = x3_softplus(acc[4 * q + 2]), z3 = x3_softplus(acc[4 * q + 3]);
+    const float z0 = SP ? x3_softplus(acc[4 * q + 0]) : acc[4 * q + 0], z1 = SP ? x3_softplus(acc[4 * q + 1]) : acc[4 * q + 1];
+    const float z2 = SP ? x3_softplus(acc[4 * q + 2]) : acc[4 * q + 2], z3 = SP ? x3_softplus(acc[4 * q + 3]) : acc[4 * q + 3];
     if (SAVE) *reinterpret_cast<float4*>(tb + l31 * X3_TLD + 8 * q + 4 * hf) = make_float4(z0, z1, z2, z3);
     // registers 4q..4q+3  ->  k-step s = q>>1, k-slots t = 4(q&1)..+3  ->  dwords 2(q&1), 2(q&1)+1
     const int s = q >> 1, j = 2 * (q & 1);
@@ -269,18 +279,19 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_x3_kernel(EdgeX3Args a) {
     for (int layer = 0; layer < 3; ++layer) {
       f32x16 acc[4];
       X3_STEP_BEGIN();
-      x3_hidden_chunk(ring + use_s * X3_CHUNK, bf, acc[0], acc[1], sBias + layer * FH, 0, lane);
+      x3_hidden_chunk<false>(ring + use_s * X3_CHUNK, bf, acc[0], acc[1], sBias + layer * FH, 0, lane, acc[2], acc[3]);
       X3_STEP_END();
       X3_STEP_BEGIN();
-      x3_hidden_chunk(ring + use_s * X3_CHUNK, bf, acc[2], acc[3], sBias + layer * FH, 2, lane);
+      x3_hidden_chunk<true>(ring + use_s * X3_CHUNK, bf, acc[2], acc[3], sBias + layer * FH, 2, lane, acc[0], acc[1]);
       X3_STEP_END();
       // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
       const int64_t wrow0 = tile * X3_TM + 32 * wave;
       const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
       float* zw = SAVE ? a.z_save + ((int64_t)layer * a.n_edges + wrow0) * FH : nullptr;
-#pragma unroll
-      for (int bo = 0; bo < 4; ++bo)
-        x3_epilogue<SAVE>(acc[bo], bf[bo], sT + wave * (32 * X3_TLD), zw + 32 * bo, a.dummy, rows_left, lane);
+      x3_epilogue<SAVE, false>(acc[0], bf[0], sT + wave * (32 * X3_TLD), zw, a.dummy, rows_left, lane);
+      x3_epilogue<SAVE, false>(acc[1], bf[1], sT + wave * (32 * X3_TLD), zw + 32, a.dummy, rows_left, lane);
+      x3_epilogue<SAVE, true>(acc[2], bf[2], sT + wave * (32 * X3_TLD), zw + 64, a.dummy, rows_left, lane);
+      x3_epilogue<SAVE, true>(acc[3], bf[3], sT + wave * (32 * X3_TLD), zw + 96, a.dummy, rows_left, lane);
     }
     // ---- output layer: rows 0..E-1 of one 32-row block
     {
