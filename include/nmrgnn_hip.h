@@ -77,11 +77,19 @@ int ng_rbf_expand(ng_ctx*, void* stream, int64_t n, int H, const float* d_src, c
  *   centers[H], gap   RBF grid (layers.py:126-129)
  *   W[t] [in,out], b[t] [out]  host arrays (length Le) of device pointers, Keras Dense layout
  *   e_out  [n_edges,E]
- *   z_save [Le-1, n_edges, H] softplus outputs of the hidden layers (NULL for inference)
+ *   z_save [Le-1, n_edges, H] softplus outputs of the hidden layers (NULL for inference): the tape handed to
+ *          ng_edge_mlp_bwd; its element order inside a layer is given by ng_edge_tape_layout()
  */
 int ng_edge_mlp_fwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
                     const float* d_src, const float* d_eff, const float* centers, float gap,
                     const float* const* W, const float* const* b, float* e_out, float* z_save);
+/* Element order of a z_save layer for this shape (same footprint either way; depends on NG_EDGE_* switches, so ask
+ * in the process that runs the kernels):
+ *   0: row-major [n_edges][H]
+ *   1: inside every FULL group of 32 consecutive edges the 32 x 128 block is stored in the kernels' register layout:
+ *      edge r (0..31), feature 32*bo + 8*q + 4*hf + j  ->  float ((bo*4 + q)*64 + hf*32 + r)*4 + j of the group's
+ *      4096; a last partial group is row-major.  (Both kernels then move whole contiguous KBs per wave.) */
+int ng_edge_tape_layout(int H, int E, int Le, int64_t n_edges);
 /* de [n_edges,E] upstream gradient; writes dW[t], db[t] (overwrites) */
 int ng_edge_mlp_bwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
                     const float* d_src, const float* d_eff, const float* centers, float gap,

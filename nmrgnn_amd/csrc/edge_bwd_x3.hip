@@ -201,11 +201,14 @@ __device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restr
 // this lane's 16 values of a saved activation row (clamped row: rows past the end multiply a zero gradient).
 // Buffer loads: scalar resource + one 32-bit lane offset — per-lane 64-bit pointers for five arrays got spilled and
 // every reload put a vmcnt(0) into the middle of the prefetch.
-__device__ __forceinline__ void bx_load_z(float (&z)[16], __amdgpu_buffer_rsrc_t rs, int voff) {
+// Tape layout (edge_fused.h: edge_tape_blocked): inside a FULL 32-edge group the block this wave needs is stored in
+// exactly this register layout — four contiguous 1-KB wave loads; the last partial group is row-major (16-B pieces
+// of 32 rows, 32 B apart).  voff: this lane's byte offset, qbytes: distance between its four loads (wave-uniform).
+__device__ __forceinline__ void bx_load_z(float (&z)[16], __amdgpu_buffer_rsrc_t rs, int voff, int qbytes) {
   typedef float f32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 32 * q, 0);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, q * qbytes, 0);
     const f32x4v v = __builtin_bit_cast(f32x4v, raw);
     z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
   }
@@ -244,6 +247,10 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   const int col0 = 32 * zk + 4 * half;                  // its columns: col0 + 8q + j
   const int prz = bx_prow_z(row), prg = bx_prow_g(row); // where that row lives in the images
   const int E = a.E;
+  // tape offsets of this wave's block for the tile starting at ROW0 (see bx_load_z)
+#define BX_ZFULL(ROW0) ((ROW0) + 32 * zrt + 32 <= a.n_edges)
+#define BX_ZOFF(ROW0, GI) (BX_ZFULL(ROW0) ? (int)(((ROW0) / 32 + zrt) * 16384 + (zk * 256 + lane) * 16) : (GI) * (FH * 4) + col0 * 4)
+#define BX_ZQ(ROW0) (BX_ZFULL(ROW0) ? 1024 : 32)
 
   for (int t = tid; t < FH * 4; t += BX_THREADS) sWo4[t] = (t & 3) < E ? a.Wo[(t >> 2) * E + (t & 3)] : 0.f;
   if (tid < FH) sCen[tid] = a.centers[tid];
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   auto prefetch = [&](int64_t row0) {
     const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
     const int gi = (int)gr;
-    bx_load_z(z3r, rsZ3, gi * (FH * 4) + col0 * 4);
+    bx_load_z(z3r, rsZ3, BX_ZOFF(row0, gi), BX_ZQ(row0));
     pf_ds = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDs, gi * 4, 0, 0));
     pf_dn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDn, gi * 4, 0, 0));
 #pragma unroll
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   // Z2 of the next tile: its registers are free only after phase B's epilogue
   auto prefetch_z2 = [&](int64_t row0) {
     const int gi = (int)std::min<int64_t>(row0 + row, a.n_edges - 1);
-    bx_load_z(z2r, rsZ2, gi * (FH * 4) + col0 * 4);
+    bx_load_z(z2r, rsZ2, BX_ZOFF(row0, gi), BX_ZQ(row0));
   };
   if ((int64_t)blockIdx.x < ntiles) { prefetch((int64_t)blockIdx.x * FTM); prefetch_z2((int64_t)blockIdx.x * FTM); }
 
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
 #pragma unroll
     for (int n = 0; n < 4; ++n) dEm[n] = (on && n < E) ? pf_de[n] : 0.f;
     float z1r[16];
-    bx_load_z(z1r, rsZ1, (int)grow * (FH * 4) + col0 * 4);        // used after phase B's GEMMs
+    bx_load_z(z1r, rsZ1, BX_ZOFF(row0, (int)grow), BX_ZQ(row0));        // used after phase B's GEMMs
     // ------------------------------------------------------------------ phase A
     if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(dEm[0], dEm[1], dEm[2], dEm[3]);
 #pragma unroll
@@ -459,6 +466,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
 }
 
 bool edge_bwd_x3_supported(int E, int64_t n_edges) { return E >= 1 && E <= 4 && n_edges * FH * 4 < ((int64_t)1 << 32); }
+
+bool edge_tape_blocked(int E, int64_t n_edges) {
+  const char* xm = getenv("NG_EDGE_BWD_MATH");
+  return edge_x3_enabled() && !(xm && std::string(xm) == "fp32") && edge_bwd_x3_supported(E, n_edges);
+}
 
 size_t edge_bwd_x3_ws_bytes() { return (size_t)2 * 4 * 8 * 3 * 1024; }
 

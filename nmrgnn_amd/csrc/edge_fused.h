@@ -57,6 +57,11 @@ int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
 namespace ng {
 // backward on the bf16 matrix pipe with split operands (edge_bwd_x3.hip); partial layout of edge_fused_bwd.hip
 bool edge_bwd_x3_supported(int E, int64_t n_edges);
+// Layout of the saved-activation tape z_save[Le-1][n_edges][128] between the edge forward and backward:
+// false: row-major.  true (both directions run the split-operand kernels): inside every FULL group of 32 consecutive
+// edges the 32 x 128 block is stored in the kernels' register layout, float index ((bo*4 + q)*64 + hf*32 + r)*4 + j for
+// edge r, feature 32 bo + 8 q + 4 hf + j; a last partial group stays row-major.  Same footprint either way.
+bool edge_tape_blocked(int E, int64_t n_edges);
 size_t edge_bwd_x3_ws_bytes();
 int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,

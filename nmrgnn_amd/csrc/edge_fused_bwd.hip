@@ -389,8 +389,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const char* ver = getenv("NG_EDGE_BWD");
   // default: split-operand kernel on the bf16 matrix pipe (edge_bwd_x3.hip); NG_EDGE_MATH=fp32 (both directions) or
   // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
-  const char* xm = getenv("NG_EDGE_BWD_MATH");
-  if (edge_x3_enabled() && !(xm && std::string(xm) == "fp32") && edge_bwd_x3_supported(E, n_edges)) {
+  if (edge_tape_blocked(E, n_edges)) {
     int rc3 = edge_bwd_x3_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
                                  (char*)(partial + (size_t)grid * stride), partial, stride, grid);
     if (rc3) return rc3;

@@ -168,17 +168,23 @@ __device__ __forceinline__ f32x16 x3_bias(const float* __restrict__ sb, int bo, 
 // layer epilogue for one output block: softplus, optional save, split into the next layer's B fragments.
 // Saved rows go through a wave-private LDS tile: a lane holds 16-B pieces of 32 different rows (512-B stride in
 // memory: measured 1.7 TB/s), after the transposition 8 lanes write one 128-B line of a row.
-template <bool SAVE, bool SP>
+// SAVE: 0 none; 1 row-major tape through the LDS transposition; 2 blocked tape (edge_fused.h: edge_tape_blocked):
+// inside a full 32-edge group the element (edge l31, feature 32 bo + 8 q + 4 hf + j) lives at
+// ((bo*4 + q)*64 + lane)*4 + j — exactly this kernel's accumulator layout and the backward kernel's load layout, so
+// every wave store (and load) is one contiguous KB and needs no transposition.  zp / qstride: this lane's first store
+// address for the block and the distance between its four stores (the last, partial group stays row-major).
+template <int SAVE, bool SP>
 __device__ __forceinline__ void x3_epilogue(const f32x16& acc, u32x4 (&bfo)[2][3], float* __restrict__ tb,
                                             float* __restrict__ zblk, float* __restrict__ dummy, int rows_left,
-                                            int lane) {
+                                            int lane, float* __restrict__ zp, int qstride) {
   typedef float nt4 __attribute__((ext_vector_type(4)));
   const int hf = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float z0 = SP ? x3_softplus(acc[4 * q + 0]) : acc[4 * q + 0], z1 = SP ? x3_softplus(acc[4 * q + 1]) : acc[4 * q + 1];
     const float z2 = SP ? x3_softplus(acc[4 * q + 2]) : acc[4 * q + 2], z3 = SP ? x3_softplus(acc[4 * q + 3]) : acc[4 * q + 3];
-    if (SAVE) *reinterpret_cast<float4*>(tb + l31 * X3_TLD + 8 * q + 4 * hf) = make_float4(z0, z1, z2, z3);
+    if (SAVE == 1) *reinterpret_cast<float4*>(tb + l31 * X3_TLD + 8 * q + 4 * hf) = make_float4(z0, z1, z2, z3);
+    if (SAVE == 2) __builtin_nontemporal_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
     // registers 4q..4q+3  ->  k-step s = q>>1, k-slots t = 4(q&1)..+3  ->  dwords 2(q&1), 2(q&1)+1
     const int s = q >> 1, j = 2 * (q & 1);
     unsigned h, m, l;
@@ -187,7 +193,7 @@ __device__ __forceinline__ void x3_epilogue(const f32x16& acc, u32x4 (&bfo)[2][3
     split3_pair(z2, z3, h, m, l);
     bfo[s][0][j + 1] = h; bfo[s][1][j + 1] = m; bfo[s][2][j + 1] = l;
   }
-  if (SAVE) {
+  if (SAVE == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (lane >> 3) + 8 * i, c = 4 * (lane & 7);
@@ -200,7 +206,7 @@ __device__ __forceinline__ void x3_epilogue(const f32x16& acc, u32x4 (&bfo)[2][3
 
 #define X3_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <bool SAVE>
+template <int SAVE>
 __global__ __launch_bounds__(512, 1) void edge_fwd_x3_kernel(EdgeX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_x3[];
   char* ring = smem_x3;
@@ -287,11 +293,22 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_x3_kernel(EdgeX3Args a) {
       // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
       const int64_t wrow0 = tile * X3_TM + 32 * wave;
       const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
-      float* zw = SAVE ? a.z_save + ((int64_t)layer * a.n_edges + wrow0) * FH : nullptr;
-      x3_epilogue<SAVE, false>(acc[0], bf[0], sT + wave * (32 * X3_TLD), zw, a.dummy, rows_left, lane);
-      x3_epilogue<SAVE, false>(acc[1], bf[1], sT + wave * (32 * X3_TLD), zw + 32, a.dummy, rows_left, lane);
-      x3_epilogue<SAVE, true>(acc[2], bf[2], sT + wave * (32 * X3_TLD), zw + 64, a.dummy, rows_left, lane);
-      x3_epilogue<SAVE, true>(acc[3], bf[3], sT + wave * (32 * X3_TLD), zw + 96, a.dummy, rows_left, lane);
+      float* zl = SAVE ? a.z_save + (int64_t)layer * a.n_edges * FH : nullptr;
+      float* zw = SAVE ? zl + wrow0 * FH : nullptr;
+      const bool full = rows_left >= 32;
+      float* zp = nullptr;
+      int bstride = 0, qstride = 0;
+      if (SAVE == 2) {
+        zp = full ? zl + (tile * 8 + wave) * 4096 + lane * 4
+                  : (l31 < rows_left ? zl + (wrow0 + l31) * FH + 4 * hf : a.dummy + 4 * hf);
+        bstride = full ? 1024 : 32;
+        qstride = full ? 256 : 8;
+      }
+      float* tb = sT + wave * (32 * X3_TLD);
+      x3_epilogue<SAVE, false>(acc[0], bf[0], tb, zw, a.dummy, rows_left, lane, zp, qstride);
+      x3_epilogue<SAVE, false>(acc[1], bf[1], tb, zw + 32, a.dummy, rows_left, lane, zp + bstride, qstride);
+      x3_epilogue<SAVE, true>(acc[2], bf[2], tb, zw + 64, a.dummy, rows_left, lane, zp + 2 * bstride, qstride);
+      x3_epilogue<SAVE, true>(acc[3], bf[3], tb, zw + 96, a.dummy, rows_left, lane, zp + 3 * bstride, qstride);
     }
     // ---- output layer: rows 0..E-1 of one 32-row block
     {
@@ -361,8 +378,9 @@ int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const size_t lds = X3_RING + X3_TBYTES + (size_t)(FH + 3 * FH + 32) * 4;
   ProfScope ps(ctx, st, "edge_fwd_x3");
-  if (z_save) hipLaunchKernelGGL(edge_fwd_x3_kernel<true>, dim3(grid), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(edge_fwd_x3_kernel<false>, dim3(grid), dim3(512), lds, st, a);
+  if (z_save && edge_tape_blocked(E, n_edges)) hipLaunchKernelGGL(edge_fwd_x3_kernel<2>, dim3(grid), dim3(512), lds, st, a);
+  else if (z_save) hipLaunchKernelGGL(edge_fwd_x3_kernel<1>, dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(edge_fwd_x3_kernel<0>, dim3(grid), dim3(512), lds, st, a);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

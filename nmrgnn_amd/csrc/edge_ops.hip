@@ -327,6 +327,10 @@ extern "C" int ng_edge_mlp_fwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H
                               gap, W, b, e_out, z_save);
 }
 
+extern "C" int ng_edge_tape_layout(int H, int E, int Le, int64_t n_edges) {
+  return edge_fused_supported(H, E, Le) && !force_layered() && edge_tape_blocked(E, n_edges) ? 1 : 0;
+}
+
 extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
                                const float* d_src, const float* d_eff, const float* centers,
                                float gap, const float* const* W, const float* z_save,

@@ -25,6 +25,26 @@ def ref_edge(d_src, d_eff, centers, gap, Ws, bs):
     return m[:, None] * (x @ Ws[-1] + bs[-1]), zs
 
 
+def tape_perm(n):
+    """index map of the blocked tape: blocked_flat[perm] == row-major flat, for one layer [n][128]"""
+    idx = np.arange(n * H, dtype=np.int64).reshape(n, H)            # row-major positions
+    out = idx.copy().reshape(-1)
+    G = n // 32
+    if G:
+        r = np.arange(32)[:, None]
+        f = np.arange(H)[None, :]
+        bo, q, hf, j = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
+        within = ((bo * 4 + q) * 64 + hf * 32 + r) * 4 + j          # [32][128] position inside a group
+        pos = (np.arange(G)[:, None, None] * 4096 + within[None]).reshape(G * 32, H)
+        out = np.concatenate([pos.reshape(-1), idx[G * 32:].reshape(-1)])
+    return out                                                      # out[row*H + col] = position in the tape
+
+
+def tape_layout(E, n):
+    from nmrgnn_amd import _lib
+    return int(_lib.get_context(0).lib.ng_edge_tape_layout(H, E, 4, n))
+
+
 def run_gpu(dev, d_src, d_eff, centers, gap, Ws, bs, E, save):
     import torch
     from nmrgnn_amd import _lib
@@ -40,7 +60,13 @@ def run_gpu(dev, d_src, d_eff, centers, gap, Ws, bs, E, save):
     ctx.check(ctx.lib.ng_edge_mlp_fwd(ctx.handle, st, n, H, E, 4, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
                                       ptr_array(tb), ptr(e), ptr(z)), "ng_edge_mlp_fwd")
     torch.cuda.synchronize()
-    return e.cpu().numpy().astype(np.float64), (z.cpu().numpy().astype(np.float64) if save else None)
+    zz = None
+    if save:
+        zz = z.cpu().numpy().astype(np.float64)
+        if tape_layout(E, n):                        # blocked tape -> row-major for the comparison
+            perm = tape_perm(n)
+            zz = np.stack([zz[l].reshape(-1)[perm].reshape(n, H) for l in range(3)])
+    return e.cpu().numpy().astype(np.float64), zz
 
 
 @pytest.mark.parametrize("n,E,save", [(1, 3, True), (255, 3, True), (257, 1, True), (70001, 3, True), (5000, 8, False),
@@ -104,7 +130,14 @@ def run_gpu_bwd(dev, d_src, d_eff, centers, gap, Ws, zs, de, E):
     n = len(d_src)
     td, te, tc, tde = t(d_src), t(d_eff), t(centers), t(de)
     tW = [t(w) for w in Ws]
-    tz = t(np.stack(zs))
+    zs = np.stack(zs)
+    if tape_layout(E, n):                            # hand the kernel the tape in the layout it expects
+        perm = tape_perm(n)
+        blk = np.empty_like(zs).reshape(3, -1)
+        for l in range(3):
+            blk[l][perm] = zs[l].reshape(-1)
+        zs = blk.reshape(3, n, H)
+    tz = t(zs)
     dW = [torch.full((H, H), 7.0, device=dev) for _ in range(3)] + [torch.full((H, E), 7.0, device=dev)]
     db = [torch.full((H,), 7.0, device=dev) for _ in range(3)] + [torch.full((E,), 7.0, device=dev)]
     ctx = _lib.get_context(0)
