@@ -4,8 +4,7 @@
 //
 // Why.  On gfx950 the f32-input MFMA runs at the fp32 VECTOR rate and shares the VALU's issue: PMC shows
 // SQ_VALU_MFMA_COEXEC_CYCLES = 0 for edge_fused_fwd/bwd and a 72 % busy matrix pipe whose idle share is the
-// kernels' VALU + LDS issue time (profiles/pmc_mfma.json).  The bf16 MFMA is 16x faster per flop and co-executes
-// with VALU work.  Every fp32 operand x is split exactly into three bf16 pieces x = h + m + l (8 mantissa bits
+// kernels' VALU + LDS issue time (profiles/pmc_mfma.json).  The bf16 MFMA is a separate pipe, 16x faster per flop.  Every fp32 operand x is split exactly into three bf16 pieces x = h + m + l (8 mantissa bits
 // each; h = rne(x), m = rne(x-h), l = rne(x-h-m); the subtractions are exact) and a product a*b is formed from
 // the six piece products whose weight is >= 2^-16 of |a||b|:  hh + hm + mh + hl + lh + mm, each exact in the
 // fp32 accumulator.  What is dropped (ml + lm + ll and the split residuals) is <= 4 * 2^-24 |a||b| — the size of
@@ -23,8 +22,8 @@
 // The weight image is packed once per call with the same permutation (x3_pack_kernel).
 //
 // Weights reach LDS by LDS-DMA in 48-KB chunks (half a layer: 2 output blocks x 4 input blocks x 2 k-steps x
-// 3 pieces x 1 KB fragments), 7 chunks per tile (3 layers x 2 + output layer), through a ring of three slots:
-// while chunk c is consumed, c+1 is resident and c+2 in flight; one barrier per chunk.  L2 -> CU traffic is
+// 3 pieces x 1 KB fragments), 7 chunks per tile (3 layers x 2 + output layer), through a ring of two slots:
+// while chunk c is consumed, c+1 lands; one barrier per chunk.  L2 -> CU traffic is
 // 336 KB per 256 edges (the fp32 kernel: 192 KB per 64).
 #include <algorithm>
 #include <string>
