@@ -11,7 +11,7 @@ python - <<'PY'
 import csv, glob, json, collections
 res = collections.defaultdict(dict)
 names = {"edge_fused_bwd_kernel": "edge_fused_bwd", "edge_fused_bwd2_kernel": "edge_fused_bwd",
-         "edge_fused_fwd_kernel": "edge_fused_fwd", "edge_fwd_x3_kernel<true>": "edge_fwd_x3", "edge_fwd_x3_kernel<false>": "edge_fwd_x3_inference", "edge_bwd_x3_kernel": "edge_bwd_x3", "split_agg_kernel": "mp_aggregate",
+         "edge_fused_fwd_kernel": "edge_fused_fwd", "edge_fwd_x3_kernel<2>": "edge_fwd_x3", "edge_fwd_x3_kernel<1>": "edge_fwd_x3_rowmajor", "edge_fwd_x3_kernel<0>": "edge_fwd_x3_inference", "edge_bwd_x3_kernel": "edge_bwd_x3", "split_agg_kernel": "mp_aggregate",
          "split_agg_csc2_kernel": "mp_aggregate_csc", "split_edge_grad2_kernel": "mp_edge_grad",
          "tall_tn_kernel<192": "mp_dw", "tall_gemm_kernel<192, 64, false>": "mp_update_fwd|mp_dh",
          "tall_gemm_kernel<64, 192, true>": "mp_dA", "mp_win_fwd_kernel": "mp_win_fwd",
