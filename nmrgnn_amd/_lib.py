@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnmrgnn_hip.so")
+# NMRGNN_HIP_LIB: another build of the same library (A/B measurements of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("NMRGNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libnmrgnn_hip.so")
 
 NG_ACT_NONE, NG_ACT_SOFTPLUS = 0, 1
 ACT_CODES = {None: NG_ACT_NONE, "linear": NG_ACT_NONE, "softplus": NG_ACT_SOFTPLUS}

@@ -214,6 +214,11 @@ __device__ __forceinline__ void bx_load_z(float (&z)[16], __amdgpu_buffer_rsrc_t
   }
 }
 
+// x * s'(.) with s' = 1 - exp(-z) recovered from the softplus OUTPUT z:  x - x * 2^(-z log2 e)   (mul, exp, fma)
+__device__ __forceinline__ float bx_sprime(float x, float z) {
+  return fmaf(-x, __builtin_amdgcn_exp2f(-1.4426950408889634f * z), x);
+}
+
 #ifdef BX_STAMP
 #define BX_T(k)                                                                              \
   do {                                                                                       \
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
         for (int j = 0; j < 4; ++j) {
           const float4 w = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));
           const float pre = dEm[0] * w.x + dEm[1] * w.y + dEm[2] * w.z + dEm[3] * w.w;
-          g[4 * q + j] = pre * (1.0f - __expf(-z3r[4 * q + j]));
+          g[4 * q + j] = bx_sprime(pre, z3r[4 * q + j]);
         }
       bx_img_write<BX_ROWG>(GA, prg, col0, g);
     }
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
       BX_T(6);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z2r[r]);
+      for (int r = 0; r < 16; ++r) g[r] = bx_sprime(g[r], z2r[r]);
       bx_img_write<BX_ROWG>(GB, prg, col0, g);       // G2
     }
     BX_T(7);
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
       prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - __expf(-z1r[r]);
+      for (int r = 0; r < 16; ++r) g[r] = bx_sprime(g[r], z1r[r]);
       bx_img_write<BX_ROWG>(GA, prg, col0, g);       // G1
     }
     BX_T(11);
