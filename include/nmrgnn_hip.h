@@ -90,11 +90,17 @@ int ng_edge_mlp_fwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le
  *      edge r (0..31), feature 32*bo + 8*q + 4*hf + j  ->  float ((bo*4 + q)*64 + hf*32 + r)*4 + j of the group's
  *      4096; a last partial group is row-major.  (Both kernels then move whole contiguous KBs per wave.) */
 int ng_edge_tape_layout(int H, int E, int Le, int64_t n_edges);
-/* de [n_edges,E] upstream gradient; writes dW[t], db[t] (overwrites) */
+/* de [n_edges,E] upstream gradient; writes dW[t], db[t] (overwrites).
+ * ng_edge_mlp_bwd_tape: tape_layout = the value ng_edge_tape_layout() returned when the forward wrote z_save (the
+ * layout then no longer depends on the switches in force at backward time); ng_edge_mlp_bwd == tape_layout -1 (ask again). */
 int ng_edge_mlp_bwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
                     const float* d_src, const float* d_eff, const float* centers, float gap,
                     const float* const* W, const float* z_save, const float* de,
                     float* const* dW, float* const* db);
+int ng_edge_mlp_bwd_tape(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
+                         const float* d_src, const float* d_eff, const float* centers, float gap,
+                         const float* const* W, const float* z_save, const float* de,
+                         float* const* dW, float* const* db, int tape_layout);
 
 /* ---- node path ----------------------------------------------------------------------------- */
 /* embed_layer, nmrgnn/model.py:241,262: h0 = atoms[N,C] @ Wemb[C,F] */

@@ -72,6 +72,7 @@ struct EdgeBwdX3Args {
   float* partial;       // [grid][part_stride], layout of edge_fused_bwd.hip
   int part_stride;
   int E;
+  int tape_blocked;     // z_save layout: 1 = blocked inside full 32-edge groups (edge_fused.h), 0 = row-major
   unsigned long long* stamps;
 };
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   const int prz = bx_prow_z(row), prg = bx_prow_g(row); // where that row lives in the images
   const int E = a.E;
   // tape offsets of this wave's block for the tile starting at ROW0 (see bx_load_z)
-#define BX_ZFULL(ROW0) ((ROW0) + 32 * zrt + 32 <= a.n_edges)
+#define BX_ZFULL(ROW0) (a.tape_blocked && (ROW0) + 32 * zrt + 32 <= a.n_edges)
 #define BX_ZOFF(ROW0, GI) (BX_ZFULL(ROW0) ? (int)(((ROW0) / 32 + zrt) * 16384 + (zk * 256 + lane) * 16) : (GI) * (FH * 4) + col0 * 4)
 #define BX_ZQ(ROW0) (BX_ZFULL(ROW0) ? 1024 : 32)
 
@@ -482,14 +483,14 @@ size_t edge_bwd_x3_ws_bytes() { return (size_t)2 * 4 * 8 * 3 * 1024; }
 // wt_img: edge_bwd_x3_ws_bytes() of scratch; partial / stride / grid as in edge_fused_bwd()
 int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid) {
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked) {
   hipLaunchKernelGGL(x3_pack_wt_kernel, dim3(16), dim3(256), 0, st, W[1], W[2], (unsigned*)wt_img);
   NG_HIP(ctx, hipGetLastError());
   EdgeBwdX3Args a;
   a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
   a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
   a.wt_img = wt_img; a.Wo = W[3]; a.z_save = z_save; a.de = de;
-  a.partial = partial; a.part_stride = part_stride; a.E = E;
+  a.partial = partial; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;
   a.stamps = nullptr;
 #ifdef BX_STAMP
   static unsigned long long* dbg = nullptr;

@@ -17,7 +17,7 @@ int edge_fused_pack(ng_ctx* ctx, hipStream_t st, const float* const* W, float* W
 namespace ng {
 int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
-                   const float* z_save, const float* de, float* const* dW, float* const* db);
+                   const float* z_save, const float* de, float* const* dW, float* const* db, int tape_layout = -1);
 }  // namespace ng
 
 // Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also drains vmcnt(0), which
@@ -65,5 +65,5 @@ bool edge_tape_blocked(int E, int64_t n_edges);
 size_t edge_bwd_x3_ws_bytes();
 int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid);
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked);
 }  // namespace ng

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(1024) void edge_bwd_reduce_kernel(const float* __re
 
 int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
-                   const float* z_save, const float* de, float* const* dW, float* const* db) {
+                   const float* z_save, const float* de, float* const* dW, float* const* db, int tape_layout) {
   const int64_t ntiles = cdiv(n_edges, FTM);
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
@@ -389,9 +389,13 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const char* ver = getenv("NG_EDGE_BWD");
   // default: split-operand kernel on the bf16 matrix pipe (edge_bwd_x3.hip); NG_EDGE_MATH=fp32 (both directions) or
   // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
-  if (edge_tape_blocked(E, n_edges)) {
+  // tape_layout: what the forward that wrote z_save reported (ng_edge_tape_layout), -1 = decide as the forward would
+  // now.  A blocked tape can only be read by the split-operand kernel; that kernel reads row-major tapes as well.
+  const bool blocked = tape_layout < 0 ? edge_tape_blocked(E, n_edges) : tape_layout == 1;
+  if (blocked && !edge_bwd_x3_supported(E, n_edges)) return fail(ctx, NG_ERR_INVALID, "edge_mlp_bwd: blocked tape for an unsupported shape");
+  if (blocked || edge_tape_blocked(E, n_edges)) {
     int rc3 = edge_bwd_x3_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
-                                 (char*)(partial + (size_t)grid * stride), partial, stride, grid);
+                                 (char*)(partial + (size_t)grid * stride), partial, stride, grid, blocked ? 1 : 0);
     if (rc3) return rc3;
   } else if (ver && std::string(ver) == "v2") {
     int rc2 = edge_fused_bwd2_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, WpkT, W[3], z_save,

@@ -331,10 +331,10 @@ extern "C" int ng_edge_tape_layout(int H, int E, int Le, int64_t n_edges) {
   return edge_fused_supported(H, E, Le) && !force_layered() && edge_tape_blocked(E, n_edges) ? 1 : 0;
 }
 
-extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
-                               const float* d_src, const float* d_eff, const float* centers,
-                               float gap, const float* const* W, const float* z_save,
-                               const float* de, float* const* dW, float* const* db) {
+extern "C" int ng_edge_mlp_bwd_tape(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
+                                    const float* d_src, const float* d_eff, const float* centers,
+                                    float gap, const float* const* W, const float* z_save,
+                                    const float* de, float* const* dW, float* const* db, int tape_layout) {
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, H % 16 == 0 && H <= 512, "edge_mlp: edge_hidden_size % 16 == 0, <= 512");
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "edge_mlp: edge_feature_size <= 8");
@@ -350,7 +350,15 @@ extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H
     return NG_OK;
   }
   if (edge_fused_supported(H, E, Le) && !force_layered())
-    return edge_fused_bwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de, dW, db);
+    return edge_fused_bwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de, dW, db, tape_layout);
+  NG_REQUIRE(ctx, tape_layout != 1, "edge_mlp_bwd: a blocked tape needs the fused edge path");
   return edge_mlp_bwd_layered(ctx, st, n_edges, H, E, Le, d_src, d_eff, centers, gap, W, z_save, de,
                               dW, db);
+}
+
+extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
+                               const float* d_src, const float* d_eff, const float* centers,
+                               float gap, const float* const* W, const float* z_save,
+                               const float* de, float* const* dW, float* const* db) {
+  return ng_edge_mlp_bwd_tape(ctx, stream, n_edges, H, E, Le, d_src, d_eff, centers, gap, W, z_save, de, dW, db, -1);
 }

@@ -31,7 +31,7 @@ def rbf_grid(low, high, count):
 
 class Tape:
     """activations kept between forward(training=True) and backward()"""
-    __slots__ = ("batch", "d_eff", "z_save", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
+    __slots__ = ("batch", "d_eff", "z_save", "z_layout", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
                  "peaks")
 
 
@@ -119,6 +119,9 @@ class Engine:
             self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
                      "ng_add_scaled")
         z_save = self._new(self.Le - 1, ne, H) if training else None
+        # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
+        # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, ne)) if training else 0
         e = self._new(ne, E)
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
@@ -163,6 +166,7 @@ class Engine:
         if training:
             tp = Tape()
             tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e
+            tp.z_layout = z_layout
             tp.h, tp.A, tp.S, tp.fx, tp.fs, tp.g, tp.drop_mask, tp.peaks = hs, As, Ss, fx, fs, g, mask, peaks
             self.tape = tp
         return peaks
@@ -220,9 +224,9 @@ class Engine:
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_bwd(h, st, ne, H, E, self.Le, ptr(b.edges), ptr(tp.d_eff),
-                                     ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
-                                     ptr(de), ptr_array(dW), ptr_array(dB)), "ng_edge_mlp_bwd")
+        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, ne, H, E, self.Le, ptr(b.edges), ptr(tp.d_eff),
+                                          ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
+                                          ptr(de), ptr_array(dW), ptr_array(dB), tp.z_layout), "ng_edge_mlp_bwd")
         self.tape = None
 
     # ------------------------------------------------------------------ loss / optimiser

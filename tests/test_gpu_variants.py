@@ -90,3 +90,36 @@ def test_mp_layer_paths_vs_numpy(gpu_device, monkeypatch, path, N, K, E, span):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(A.cpu().numpy(), refA, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(S.cpu().numpy(), ref - h, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("fwd_env,bwd_env", [({}, {"NG_EDGE_BWD_MATH": "fp32"}), ({"NG_EDGE_BWD_MATH": "fp32"}, {}),
+                                             ({}, {"NG_EDGE_MATH": "fp32"})])
+def test_switch_flipped_between_forward_and_backward(gpu_device, monkeypatch, fwd_env, bwd_env):
+    """the edge tape's element order is fixed when the forward writes it and handed to the backward
+    (ng_edge_tape_layout -> ng_edge_mlp_bwd_tape): flipping a kernel switch in between must not change the gradients"""
+    import torch
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    hp = make_hp(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
+    b = small_batch(5, 77, seed=11)
+    eng = Engine(hp, 10, device=gpu_device, seed=3)
+    randomize_biases(eng)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=5)
+    mask = eng.dropout_mask(N * 32, seed=6)
+    dpe = torch.from_numpy(np.random.default_rng(1).standard_normal(N).astype(np.float32)).to(gpu_device)
+    eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
+    eng.backward(dpe)
+    base = eng.params.grads_dict()
+    for k, v in fwd_env.items():
+        monkeypatch.setenv(k, v)
+    eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
+    for k in fwd_env:
+        monkeypatch.delenv(k)
+    for k, v in bwd_env.items():
+        monkeypatch.setenv(k, v)
+    eng.backward(dpe)
+    var = eng.params.grads_dict()
+    for k in base:
+        assert rel_err(var[k], base[k]) < 2e-4, k
