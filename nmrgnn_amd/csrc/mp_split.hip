@@ -359,12 +359,18 @@ int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, 
   // window-resident fused kernel of mp_win_bwd.hip when the neighbour count allows it
   const char* bsel = getenv("NG_MP_BWD");
   const bool win_edge = mp_win_bwd_supported(SF, E, K) && !(bsel && std::string(bsel) == "split");
-  int rc = win_edge ? mpw_pack(ctx, st, E, 2, w, WfragT) : mp_pack(ctx, st, E, 2, w, WfragT);
-  if (rc) return rc;
   const bool win_node = win_edge && !(bsel && std::string(bsel) == "edge") && N * K * 4 <= N * KF &&
                         mp_win_node_scratch_floats(ctx, E) <= dw_scr;
-  rc = win_node ? mpw_pack(ctx, st, E, 1, w, WfragN) : mp_pack(ctx, st, E, 1, w, WfragN);
-  if (rc) return rc;
+  int rc;
+  if (win_edge && win_node) {
+    rc = mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // both weight images in one launch
+    if (rc) return rc;
+  } else {
+    rc = win_edge ? mpw_pack(ctx, st, E, 2, w, WfragT) : mp_pack(ctx, st, E, 2, w, WfragT);
+    if (rc) return rc;
+    rc = win_node ? mpw_pack(ctx, st, E, 1, w, WfragN) : mp_pack(ctx, st, E, 1, w, WfragN);
+    if (rc) return rc;
+  }
   if (win_edge) {
     rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum,
                          dummy);

@@ -50,7 +50,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // mode 0 (forward):       Wsrc(k = n*64 + l, o = m) = w[l][m][n]
 // mode 1 (back to nodes): Wsrc(k = n*64 + m, o = l) = w[l][m][n]
 // mode 2 (dA = dP Wp^T):  Wsrc(k = m, o = n*64 + l) = w[l][m][n]
-__global__ void mpw_pack_kernel(int E, int mode, const float* __restrict__ w, float* __restrict__ out) {
+// blockIdx.y selects the job: the backward packs its two images (modes 2 and 1) in one launch
+__global__ void mpw_pack_kernel(int E, int mode0, const float* __restrict__ w, float* __restrict__ out0, int mode1,
+                                float* __restrict__ out1) {
+  const int mode = blockIdx.y == 0 ? mode0 : mode1;
+  float* out = blockIdx.y == 0 ? out0 : out1;
   const int KF = E * WF;
   const int kdim = mode == 2 ? WF : KF;
   const int odim = mode == 2 ? KF : WF;
@@ -76,7 +80,13 @@ __global__ void mpw_pack_kernel(int E, int mode, const float* __restrict__ w, fl
 }
 
 int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
-  hipLaunchKernelGGL(mpw_pack_kernel, dim3(24), dim3(256), 0, st, E, mode, w, out);
+  hipLaunchKernelGGL(mpw_pack_kernel, dim3(24, 1), dim3(256), 0, st, E, mode, w, out, 0, (float*)nullptr);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+int mpw_pack2(ng_ctx* ctx, hipStream_t st, int E, const float* w, int mode_a, float* out_a, int mode_b, float* out_b) {
+  hipLaunchKernelGGL(mpw_pack_kernel, dim3(24, 2), dim3(256), 0, st, E, mode_a, w, out_a, mode_b, out_b);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

@@ -80,6 +80,7 @@ int tall_tn(ng_ctx* ctx, hipStream_t st, int64_t N, const float* A, int lda, int
 bool mp_win_supported(int F, int E, int K);
 bool mp_win_enabled(int F, int E, int K);
 int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out);
+int mpw_pack2(ng_ctx* ctx, hipStream_t st, int E, const float* w, int mode_a, float* out_a, int mode_b, float* out_b);
 int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
                const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
                float* s_save);
