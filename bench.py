@@ -308,10 +308,20 @@ def main():
                     traffic = 2.0 * pmc["FETCH_SIZE_KB"] * 1024 + pmc["WRITE_SIZE_KB"] * 1024
             except Exception:
                 pass
+            # matrix-pipe utilisation of the same kernel from the PMC pass (tools/pmc_mfma.sh -> profiles/pmc_mfma.json):
+            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD * SIMDs); null when not collected
+            mfma_busy = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_mfma.json")) as f:
+                    for kname, v in json.load(f).items():
+                        if dom["kernel"] + "_kernel" in kname and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+                            mfma_busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+            except Exception:
+                pass
             alg = work[dom["kernel"]]
             out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"],
                                "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                               "frac": dom["frac"], "traffic": traffic,
+                               "frac": dom["frac"], "traffic": traffic, "mfma_pipe_busy": mfma_busy,
                                "algorithmic_bytes": alg[2], "algorithmic_flops": alg[1],
                                "avg_launch_ms": dom["avg_ms"]}
         out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
