@@ -12,6 +12,8 @@
 // Conventions (ours; nmrdata is not part of the reference tree): self excluded, ascending distance,
 // distances * scale (0.1: Angstrom -> nm), unused slots (n-1 < K) are (0, 0.0); nlist holds
 // frame-offset (batch-global) indices, inv_degree = 1/#(local index > 0) as library.py:115-116.
+#include <string>
+
 #include "ng_common.h"
 
 namespace ng {
@@ -75,6 +77,96 @@ __global__ __launch_bounds__(256) void knn_kernel(int n, int K, float scale,
   inv_degree[row] = deg > 0 ? 1.0f / (float)deg : 0.f;
 }
 
+// The same search with S = 8 lanes per query atom: lane s of a group scans the candidates t = s (mod 8) of every tile
+// into its own sorted list, then the eight lists are merged by K rounds of "smallest head wins" over DPP.  Work per
+// query is unchanged; the serial chain per thread is 8x shorter and a frame spreads over 8x as many workgroups —
+// what a single molecule-sized frame needs (2770 atoms: 0.47 ms -> see tools/knn_time.py).  Order and ties are
+// those of the one-lane kernel: (distance, index) ascending.
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_kernel_s8(int n, int K, float scale, const float* __restrict__ pos,
+                                                     int32_t* __restrict__ nlist, float* __restrict__ edges,
+                                                     float* __restrict__ inv_degree) {
+  __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
+  const int frame = blockIdx.y;
+  const int sl = threadIdx.x & 7;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const float* fp = pos + (int64_t)frame * n * 3;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (i < n) { qx = fp[3 * i]; qy = fp[3 * i + 1]; qz = fp[3 * i + 2]; }
+  float bd[KMAX];
+  int bi[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = 0x7fffffff; }
+
+  for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+    const int cnt = min(KNN_TILE, n - t0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+      sx[t] = fp[3 * (t0 + t)]; sy[t] = fp[3 * (t0 + t) + 1]; sz[t] = fp[3 * (t0 + t) + 2];
+    }
+    __syncthreads();
+    if (i < n) {
+      for (int t = sl; t < cnt; t += 8) {
+        const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const int j = t0 + t;
+        if (d2 < bd[KMAX - 1] && j != i) {
+#pragma unroll
+          for (int k = KMAX - 1; k >= 1; --k) {
+            const bool shift = bd[k - 1] > d2;
+            const bool here = !shift && bd[k] > d2;
+            bi[k] = shift ? bi[k - 1] : (here ? j : bi[k]);
+            bd[k] = shift ? bd[k - 1] : (here ? d2 : bd[k]);
+          }
+          if (bd[0] > d2) { bd[0] = d2; bi[0] = j; }
+        }
+      }
+    }
+  }
+  // merge: round k takes the lexicographically smallest (distance, index) head of the eight lanes
+  float rd[KMAX];
+  int ri[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    float md = bd[0];
+    int mi = bi[0];
+#define NG_KNN_STEP(CTRL)                                                                                        \
+    {                                                                                                            \
+      const float od = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, md), CTRL, 0xf, 0xf, false)); \
+      const int oi = __builtin_amdgcn_update_dpp(0, mi, CTRL, 0xf, 0xf, false);                                 \
+      const bool take = od < md || (od == md && oi < mi);                                                        \
+      md = take ? od : md;                                                                                       \
+      mi = take ? oi : mi;                                                                                       \
+    }
+    NG_KNN_STEP(0xB1)    // quad_perm 1,0,3,2
+    NG_KNN_STEP(0x4E)    // quad_perm 2,3,0,1
+    NG_KNN_STEP(0x141)   // row_half_mirror: the other quad of the group of eight
+#undef NG_KNN_STEP
+    rd[k] = md; ri[k] = mi;
+    const bool mine = bi[0] == mi && bd[0] == md;
+#pragma unroll
+    for (int q = 0; q < KMAX - 1; ++q) {
+      bd[q] = mine ? bd[q + 1] : bd[q];
+      bi[q] = mine ? bi[q + 1] : bi[q];
+    }
+    bd[KMAX - 1] = mine ? INFINITY : bd[KMAX - 1];
+    bi[KMAX - 1] = mine ? 0x7fffffff : bi[KMAX - 1];
+  }
+  if (i >= n || sl != 0) return;
+  const int64_t row = (int64_t)frame * n + i;
+  int deg = 0;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < K) {
+      const bool ok = rd[k] < INFINITY;
+      nlist[row * K + k] = ok ? frame * n + ri[k] : 0;
+      edges[row * K + k] = ok ? sqrtf(rd[k]) * scale : 0.f;
+      deg += (ok && ri[k] > 0) ? 1 : 0;
+    }
+  }
+  inv_degree[row] = deg > 0 ? 1.0f / (float)deg : 0.f;
+}
+
 }  // namespace ng
 
 extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, float scale,
@@ -89,7 +181,11 @@ extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, floa
   if (G == 0 || n == 0) return NG_OK;
   ProfScope ps(ctx, st, "knn_graph");
   const dim3 grid((unsigned)cdiv(n, 256), (unsigned)G), block(256);
-  if (K <= 16)
+  const char* one = getenv("NG_KNN");      // NG_KNN=serial: one lane per query (the first kernel)
+  if (K <= 16 && !(one && std::string(one) == "serial"))
+    hipLaunchKernelGGL(knn_kernel_s8<16>, dim3((unsigned)cdiv(n, 32), (unsigned)G), block, 0, st, n, K, scale, pos, nlist,
+                       edges, inv_degree);
+  else if (K <= 16)
     hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, st, n, K, scale, pos, nlist, edges, inv_degree);
   else if (K <= 32)
     hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, st, n, K, scale, pos, nlist, edges, inv_degree);

@@ -20,6 +20,7 @@ for fpb in (1, 10, 50):
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter(); tg = 0.0
         for b0 in range(0, 100, fpb):
+            torch.cuda.synchronize()           # the previous batch's model call is asynchronous: do not bill it to the graph build
             t1 = time.perf_counter()
             gb = frames_to_batch(atoms, frames[b0:b0 + fpb], 16, device=dev)
             torch.cuda.synchronize(); tg += time.perf_counter() - t1
