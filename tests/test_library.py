@@ -192,3 +192,21 @@ def test_gpu_knn_tiny_and_ragged(gpu_device):
     assert nl[0, :2].tolist() == [1, 2] and np.allclose(ed[0, :2], [0.1, 0.2]) and not ed[0, 2:].any()
     assert nl[1, :2].tolist() == [0, 2] and not nl[:, 2:].any()
     np.testing.assert_allclose(inv, [0.5, 1.0, 1.0])                     # index 0 never counts (library.py:115)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 7, 33, 1500])
+def test_gpu_knn_eight_lane_kernel_equals_serial_kernel(gpu_device, monkeypatch, n):
+    """the 8-lanes-per-query kernel and the one-lane kernel give identical lists, exact distance ties included
+    (integer grid coordinates): (distance, index) ascending in both"""
+    from nmrgnn_amd.graph import frames_to_batch
+    rng = np.random.default_rng(n)
+    pos = rng.integers(0, 6, size=(2, n, 3)).astype(np.float32)
+    atoms = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]
+    out = {}
+    for mode in ("serial", "lanes8"):
+        monkeypatch.setenv("NG_KNN", mode)
+        gb = frames_to_batch(atoms, pos, 16, device=gpu_device)
+        out[mode] = (gb.nlist.cpu().numpy(), gb.edges.cpu().numpy(), gb.inv_degree.cpu().numpy())
+    for a, b in zip(out["serial"], out["lanes8"]):
+        assert np.array_equal(a, b)
