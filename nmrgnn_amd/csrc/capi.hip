@@ -27,6 +27,26 @@ void* workspace(ng_ctx* ctx, size_t bytes) {
   return p;
 }
 
+void* aux_workspace(ng_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->aux_bytes) return ctx->aux;
+  const size_t want = bytes + bytes / 2;
+  if (ctx->aux) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->aux);
+    ctx->aux = nullptr;
+    ctx->aux_bytes = 0;
+  }
+  void* p = nullptr;
+  const hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    ctx->err = std::string("aux workspace hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+    return nullptr;
+  }
+  ctx->aux = p;
+  ctx->aux_bytes = want;
+  return p;
+}
+
 ProfScope::ProfScope(ng_ctx* c, hipStream_t s, const char* name) : ctx(c), stream(s) {
   if (!ctx || !ctx->prof) return;
   hipEvent_t a = nullptr, b = nullptr;
@@ -67,6 +87,7 @@ extern "C" int ng_ctx_create(int device, ng_ctx** out) {
 extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   if (!ctx) return;
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->aux) (void)hipFree(ctx->aux);
   for (auto& r : ctx->recs) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);

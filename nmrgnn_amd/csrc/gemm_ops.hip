@@ -128,6 +128,7 @@ int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act
               float* S, const char* tag) {
   NG_REQUIRE(ctx, Kin % 8 == 0 && Nout % 4 == 0, "dense_fwd: Kin%8, Nout%4");
   if (M == 0) return NG_OK;
+  if (gemm_x3_fwd_ok(M, Kin, Nout)) return gemm_x3_fwd(ctx, st, M, Kin, Nout, act, X, W, b, rowscale, R, Y, S, tag);
   ProfScope ps(ctx, st, tag);
   LoadPlain lq{X, M, Kin, Kin};
   LoadPlain lp{W, Kin, Nout, Nout};

@@ -1,0 +1,202 @@
+// Generic dense forward on the bf16 matrix pipe with exactly split fp32 operands (x3_common.cuh):
+//   Y = act(rowscale * (X W) + b) (+ R),   X [M][K], W [K][N] row-major fp32,   K % 32 == 0, N % 128 == 0.
+// The matrix-bound shapes of the reference's default width (atom_feature_size = 256: the MPLayer update
+// [N, 768] x [768, 256] of nmrgnn/layers.py:39-40 and the FCBlock layers of model.py:191-196) ran at 87-99 TF on the
+// f32-input MFMA tile GEMM (gemm_ops.hip); this kernel serves dense_fwd for them.  NG_GEMM_MATH=fp32 opts out.
+//
+// 256 threads = 4 waves, tile 128 rows x 128 columns, two workgroups per CU; per 32-wide k-step:
+//   W pieces: fragment-ordered image packed once per call, 24 KB per (column tile, k-step) copied to LDS by LDS-DMA;
+//   X pieces: each thread loads 16 consecutive floats of one row (prefetched one step ahead), splits them and writes
+//             the three piece planes [128][32 + 8] bf16;
+//   wave (n-half, m-half): 2 x 2 blocks of 32 x 32, v_mfma_f32_32x32x16_bf16, A = W^T pieces (rows n), B = X pieces
+//   (columns m), so a lane ends with 4 consecutive n of one row m: 16-byte stores.
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+
+#include "edge_fused.h"     // NG_LDS_BARRIER
+#include "mfma_gemm.cuh"    // act_apply
+#include "ng_internal.h"
+#include "x3_common.cuh"
+
+namespace ng {
+
+constexpr int GX_BM = 128, GX_BN = 128, GX_BK = 32;
+constexpr int GX_XROW = 80;                       // bytes per row of an X piece plane (64 + 16: conflict-free b128 rows)
+constexpr int GX_XPLANE = GX_BM * GX_XROW;        // 10,240
+constexpr int GX_WCHUNK = 4 * 2 * 3 * 1024;       // [n-block][k-step of 16][piece][1 KB]
+constexpr int GX_LDS = 3 * GX_XPLANE + GX_WCHUNK; // 55,296
+
+// image[(ct * KT + kt)][nb][ks][p][lane][8 bf16]:  lane (row n = 128 ct + 32 nb + (l&31), k-slot t) =
+//   piece_p( W[k = 32 kt + 16 ks + 8 (l>>5) + t][n] )
+__global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img) {
+  const int KT = K / GX_BK;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (ct, kt, nb, ks, lane)
+  if (idx >= (int64_t)(N / GX_BN) * KT * 4 * 2 * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) & 1, nb = (idx >> 7) & 3;
+  const int kt = (int)((idx >> 9) % KT), ct = (int)((idx >> 9) / KT);
+  const int n = GX_BN * ct + 32 * nb + (lane & 31), k0 = GX_BK * kt + 16 * ks + 8 * (lane >> 5);
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    split3_pair(W[(int64_t)(k0 + 2 * j) * N + n], W[(int64_t)(k0 + 2 * j + 1) * N + n], h[j], m[j], l[j]);
+  unsigned* dst = img + ((int64_t)(ct * KT + kt) * (GX_WCHUNK / 4)) + ((nb * 2 + ks) * 3) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = m[j]; dst[512 + j] = l[j]; }
+}
+
+struct GxArgs {
+  int64_t M;
+  int K, N;
+  const float* X;
+  const char* Wimg;
+  const float* bias;
+  const float* rowscale;
+  const float* R;
+  float* Y;
+  float* S;
+  int act;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gx[];
+  char* sX = smem_gx;                       // [3][128][80 B]
+  char* sW = smem_gx + 3 * GX_XPLANE;       // [4][2][3][1 KB]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nh = wave & 1, mh = wave >> 1;
+  const int64_t m0 = (int64_t)blockIdx.x * GX_BM;
+  const int ct = blockIdx.y;
+  const int KT = a.K / GX_BK;
+
+  // this thread's slice of the X tile: row tid >> 1, 16 floats at column 16 (tid & 1) of the k-step
+  const int xr = tid >> 1, xh = tid & 1;
+  const float* xp = a.X + std::min<int64_t>(m0 + xr, a.M - 1) * a.K + 16 * xh;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / GX_BN) * KT * GX_WCHUNK), 0x00020000);
+
+  float4 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(xp + 4 * i);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+#pragma unroll 1
+  for (int kt = 0; kt < KT; ++kt) {
+    NG_LDS_BARRIER();                       // the previous step's fragment reads are done
+    // W pieces of this step: 24 one-KB wave copies, 6 per wave
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int kb = wave + 4 * c;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sW + kb * 1024), 16,
+                                               lane * 16, (ct * KT + kt) * GX_WCHUNK + kb * 1024, 0, 0);
+    }
+    // X pieces: split the 16 prefetched values, two 16-B stores per plane
+    {
+      const float v[16] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w, xv[1].x, xv[1].y, xv[1].z, xv[1].w,
+                           xv[2].x, xv[2].y, xv[2].z, xv[2].w, xv[3].x, xv[3].y, xv[3].z, xv[3].w};
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+      char* d = sX + xr * GX_XROW + 32 * xh;
+      *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
+      *reinterpret_cast<u32x4*>(d + GX_XPLANE) = u32x4{m[0], m[1], m[2], m[3]};
+      *reinterpret_cast<u32x4*>(d + GX_XPLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
+      *reinterpret_cast<u32x4*>(d + 2 * GX_XPLANE) = u32x4{l[0], l[1], l[2], l[3]};
+      *reinterpret_cast<u32x4*>(d + 2 * GX_XPLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W copies has landed
+    NG_LDS_BARRIER();
+    // next step's X slice, requested behind the wait so that its HBM latency hides under this step's MFMAs
+    // (clamped k: the last prefetch re-reads the last step)
+    {
+      const float* xn = xp + (int64_t)GX_BK * std::min(kt + 1, KT - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(xn + 4 * i);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 wa[2][3], xb[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          wa[j][p] = *reinterpret_cast<const u32x4*>(sW + (((2 * nh + j) * 2 + ks) * 3 + p) * 1024 + lane * 16);
+          xb[j][p] = *reinterpret_cast<const u32x4*>(sX + p * GX_XPLANE + (32 * (2 * mh + j) + l31) * GX_XROW +
+                                                     (16 * ks + 8 * half) * 2);
+        }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = mma6(wa[j], xb[i], acc[j][i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // epilogue: lane holds, for row m = m0 + 32 (2 mh + i) + l31, columns n = 128 ct + 32 (2 nh + j) + 8 q + 4 half + (0..3)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m0 + 32 * (2 * mh + i) + l31;
+    if (m >= a.M) continue;
+    const float rs = a.rowscale ? a.rowscale[m] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = GX_BN * ct + 32 * (2 * nh + j) + 8 * q + 4 * half;
+        float4 v = make_float4(acc[j][i][4 * q + 0] * rs, acc[j][i][4 * q + 1] * rs, acc[j][i][4 * q + 2] * rs,
+                               acc[j][i][4 * q + 3] * rs);
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (a.act != NG_ACT_NONE) {
+          v.x = act_apply(a.act, v.x); v.y = act_apply(a.act, v.y);
+          v.z = act_apply(a.act, v.z); v.w = act_apply(a.act, v.w);
+        }
+        const int64_t o = m * a.N + n;
+        if (a.S) *reinterpret_cast<float4*>(a.S + o) = v;
+        if (a.R) {
+          const float4 r = *reinterpret_cast<const float4*>(a.R + o);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(a.Y + o) = v;
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool gemm_x3_fwd_ok(int64_t M, int K, int N) {
+  const char* v = getenv("NG_GEMM_MATH");
+  if (v && std::string(v) == "fp32") return false;
+  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && M >= 4096 &&
+         (int64_t)(N / GX_BN) * (K / GX_BK) * GX_WCHUNK < ((int64_t)1 << 31);
+}
+
+int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
+                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag) {
+  const size_t img_bytes = (size_t)(N / GX_BN) * (K / GX_BK) * GX_WCHUNK;
+  char* img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
+  if (!img) return NG_ERR_NOMEM;
+  {
+    const int64_t n_thr = (int64_t)(N / GX_BN) * (K / GX_BK) * 4 * 2 * 64;
+    hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, K, N, W, (unsigned*)img);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  GxArgs a;
+  a.M = M; a.K = K; a.N = N; a.X = X; a.Wimg = img; a.bias = b; a.rowscale = rowscale; a.R = R; a.Y = Y; a.S = S;
+  a.act = act;
+  ProfScope ps(ctx, st, tag);
+  hipLaunchKernelGGL(gemm_x3_fwd_kernel, dim3((unsigned)cdiv(M, GX_BM), (unsigned)(N / GX_BN)), dim3(256), GX_LDS, st, a);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+}  // namespace ng

@@ -20,6 +20,9 @@ struct ng_ctx {
   // growable scratch (split-K partials, repacked weights, aggregated tiles)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  // second, independent scratch for leaf kernels whose callers already hold pointers into `ws`
+  void* aux = nullptr;
+  size_t aux_bytes = 0;
   // optional per-kernel hipEvent bracketing
   bool prof = false;
   std::vector<ng_prof_rec> recs;
@@ -50,6 +53,7 @@ inline int fail(ng_ctx* ctx, int code, const std::string& msg) {
 
 // scratch: returns nullptr on failure (error string set)
 void* workspace(ng_ctx* ctx, size_t bytes);
+void* aux_workspace(ng_ctx* ctx, size_t bytes);
 
 // RAII-less profiling bracket: call begin before the launch(es), end after.
 struct ProfScope {

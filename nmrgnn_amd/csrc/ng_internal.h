@@ -19,6 +19,11 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
              int w_map, int F, int E, float* scratch, const char* tag = "dense_dw");
 size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db);
 
+// split-operand forward GEMM on the bf16 matrix pipe (gemm_x3.hip); same contract as dense_fwd
+bool gemm_x3_fwd_ok(int64_t M, int K, int N);
+int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
+                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag);
+
 // fused persistent edge path (edge_fused.hip), edge_hidden_size == 128, edge_fc_layers == 4
 bool edge_fused_supported(int H, int E, int Le);
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,

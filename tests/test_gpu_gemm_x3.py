@@ -1,0 +1,47 @@
+"""ng_dense_fwd on the split-operand tile GEMM (gemm_x3.hip; shapes K % 32 == 0, N % 128 == 0, M >= 4096) against float64
+and against the f32-input MFMA GEMM (NG_GEMM_MATH=fp32): bias, activation, residual, saved activation, ragged M."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def softplus(x):
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+@pytest.mark.parametrize("M,K,N,act,residual", [(4096, 128, 128, 1, 0), (5000, 256, 256, 1, 1), (138500, 768, 256, 0, 0),
+                                                (4097, 64, 128, 0, 0), (300000, 128, 128, 1, 0)])
+def test_dense_fwd_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, residual):
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    rng = np.random.default_rng(M + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    pre = X.astype(np.float64) @ W.astype(np.float64) + b
+    s_ref = softplus(pre) if act else pre
+    y_ref = s_ref + (X if residual else 0)
+    mag = (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)).max()
+    out = {}
+    for math in ("bf16x3", "fp32"):
+        monkeypatch.setenv("NG_GEMM_MATH", math)
+        tX, tW, tb = (torch.from_numpy(a).to(gpu_device) for a in (X, W, b))
+        Y = torch.full((M, N), 7.0, device=gpu_device)
+        S = torch.full((M, N), 7.0, device=gpu_device)
+        ctx = _lib.get_context(0)
+        st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+        ctx.check(ctx.lib.ng_dense_fwd(ctx.handle, st, M, K, N, act, residual, ptr(tX), ptr(tW), ptr(tb), ptr(Y), ptr(S)),
+                  "ng_dense_fwd")
+        torch.cuda.synchronize()
+        out[math] = (Y.cpu().numpy().astype(np.float64), S.cpu().numpy().astype(np.float64))
+    for k, (y, s) in out.items():
+        assert np.isfinite(y).all(), k
+        assert np.abs(y - y_ref).max() < 2e-6 * mag, k
+        assert np.abs(s - s_ref).max() < 2e-6 * mag, k
+    e3 = np.sqrt(((out["bf16x3"][0] - y_ref) ** 2).mean())
+    e1 = np.sqrt(((out["fp32"][0] - y_ref) ** 2).mean())
+    assert e3 < 1.5 * e1 + 1e-8, (e3, e1)
