@@ -146,6 +146,7 @@ int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
              const char* tag) {
   NG_REQUIRE(ctx, Nout % 8 == 0 && Kin % 4 == 0, "dense_dx: Nout%8, Kin%4");
   if (M == 0) return NG_OK;
+  if (gemm_x3_fwd_ok(M, Nout, Kin)) return gemm_x3_dx(ctx, st, M, Kin, Nout, act, dY, S, rowscale, W, add, dX, tag);
   ProfScope ps(ctx, st, tag);
   LoadGradAct lq{dY, act == NG_ACT_NONE ? nullptr : S, rowscale, M, Nout, act};
   LoadPlain lp{W, Kin, Nout, Nout};  // [k_out][n]: K-contiguous along the contraction n

@@ -29,7 +29,8 @@ constexpr int GX_LDS = 3 * GX_XPLANE + GX_WCHUNK; // 55,296
 
 // image[(ct * KT + kt)][nb][ks][p][lane][8 bf16]:  lane (row n = 128 ct + 32 nb + (l&31), k-slot t) =
 //   piece_p( W[k = 32 kt + 16 ks + 8 (l>>5) + t][n] )
-__global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img) {
+// trans: the weights are stored [N][K] (dX = dP W^T: contraction over the stored matrix's columns)
+__global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img, int trans) {
   const int KT = K / GX_BK;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (ct, kt, nb, ks, lane)
   if (idx >= (int64_t)(N / GX_BN) * KT * 4 * 2 * 64) return;
@@ -39,7 +40,8 @@ __global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsign
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    split3_pair(W[(int64_t)(k0 + 2 * j) * N + n], W[(int64_t)(k0 + 2 * j + 1) * N + n], h[j], m[j], l[j]);
+    split3_pair(trans ? W[(int64_t)n * K + k0 + 2 * j] : W[(int64_t)(k0 + 2 * j) * N + n],
+                trans ? W[(int64_t)n * K + k0 + 2 * j + 1] : W[(int64_t)(k0 + 2 * j + 1) * N + n], h[j], m[j], l[j]);
   unsigned* dst = img + ((int64_t)(ct * KT + kt) * (GX_WCHUNK / 4)) + ((nb * 2 + ks) * 3) * 256 + lane * 4;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = m[j]; dst[512 + j] = l[j]; }
@@ -56,8 +58,13 @@ struct GxArgs {
   float* Y;
   float* S;
   int act;
+  // GRAD prologue: X := X * act'(Sin) * rs_in[m]   (dP = dY * act'(S) * rowscale of dense_dx)
+  const float* Sin;
+  const float* rs_in;
+  int act_in;
 };
 
+template <bool GRAD>
 __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_gx[];
   char* sX = smem_gx;                       // [3][128][80 B]
@@ -75,9 +82,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / GX_BN) * KT * GX_WCHUNK), 0x00020000);
 
-  float4 xv[4];
+  const float* sp = GRAD && a.Sin ? a.Sin + std::min<int64_t>(m0 + xr, a.M - 1) * a.K + 16 * xh : nullptr;
+  const float rsi = GRAD && a.rs_in ? a.rs_in[std::min<int64_t>(m0 + xr, a.M - 1)] : 1.0f;
+  float4 xv[4], sv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(xp + 4 * i);
+  for (int i = 0; i < 4; ++i) {
+    xv[i] = *reinterpret_cast<const float4*>(xp + 4 * i);
+    if (GRAD && sp) sv[i] = *reinterpret_cast<const float4*>(sp + 4 * i);
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -99,8 +111,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     }
     // X pieces: split the 16 prefetched values, two 16-B stores per plane
     {
-      const float v[16] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w, xv[1].x, xv[1].y, xv[1].z, xv[1].w,
-                           xv[2].x, xv[2].y, xv[2].z, xv[2].w, xv[3].x, xv[3].y, xv[3].z, xv[3].w};
+      float v[16] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w, xv[1].x, xv[1].y, xv[1].z, xv[1].w,
+                     xv[2].x, xv[2].y, xv[2].z, xv[2].w, xv[3].x, xv[3].y, xv[3].z, xv[3].w};
+      if (GRAD) {
+        if (sp) {
+          const float sg[16] = {sv[0].x, sv[0].y, sv[0].z, sv[0].w, sv[1].x, sv[1].y, sv[1].z, sv[1].w,
+                                sv[2].x, sv[2].y, sv[2].z, sv[2].w, sv[3].x, sv[3].y, sv[3].z, sv[3].w};
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] *= act_grad_from_out(a.act_in, sg[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= rsi;
+      }
       unsigned h[8], m[8], l[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
@@ -117,9 +139,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     // next step's X slice, requested behind the wait so that its HBM latency hides under this step's MFMAs
     // (clamped k: the last prefetch re-reads the last step)
     {
-      const float* xn = xp + (int64_t)GX_BK * std::min(kt + 1, KT - 1);
+      const int64_t koff = (int64_t)GX_BK * std::min(kt + 1, KT - 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(xn + 4 * i);
+      for (int i = 0; i < 4; ++i) {
+        xv[i] = *reinterpret_cast<const float4*>(xp + koff + 4 * i);
+        if (GRAD && sp) sv[i] = *reinterpret_cast<const float4*>(sp + koff + 4 * i);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -180,23 +205,39 @@ bool gemm_x3_fwd_ok(int64_t M, int K, int N) {
          (int64_t)(N / GX_BN) * (K / GX_BK) * GX_WCHUNK < ((int64_t)1 << 31);
 }
 
-int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
-                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag) {
-  const size_t img_bytes = (size_t)(N / GX_BN) * (K / GX_BK) * GX_WCHUNK;
+static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int trans, bool grad, const char* tag) {
+  const size_t img_bytes = (size_t)(a.N / GX_BN) * (a.K / GX_BK) * GX_WCHUNK;
   char* img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
   if (!img) return NG_ERR_NOMEM;
   {
-    const int64_t n_thr = (int64_t)(N / GX_BN) * (K / GX_BK) * 4 * 2 * 64;
-    hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, K, N, W, (unsigned*)img);
+    const int64_t n_thr = (int64_t)(a.N / GX_BN) * (a.K / GX_BK) * 4 * 2 * 64;
+    hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, a.K, a.N, W, (unsigned*)img, trans);
     NG_HIP(ctx, hipGetLastError());
   }
-  GxArgs a;
-  a.M = M; a.K = K; a.N = N; a.X = X; a.Wimg = img; a.bias = b; a.rowscale = rowscale; a.R = R; a.Y = Y; a.S = S;
-  a.act = act;
+  a.Wimg = img;
   ProfScope ps(ctx, st, tag);
-  hipLaunchKernelGGL(gemm_x3_fwd_kernel, dim3((unsigned)cdiv(M, GX_BM), (unsigned)(N / GX_BN)), dim3(256), GX_LDS, st, a);
+  const dim3 grid((unsigned)cdiv(a.M, GX_BM), (unsigned)(a.N / GX_BN));
+  if (grad) hipLaunchKernelGGL(gemm_x3_fwd_kernel<true>, grid, dim3(256), GX_LDS, st, a);
+  else hipLaunchKernelGGL(gemm_x3_fwd_kernel<false>, grid, dim3(256), GX_LDS, st, a);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
+}
+
+int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
+                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag) {
+  GxArgs a{};
+  a.M = M; a.K = K; a.N = N; a.X = X; a.bias = b; a.rowscale = rowscale; a.R = R; a.Y = Y; a.S = S; a.act = act;
+  return gx_launch(ctx, st, a, W, 0, false, tag);
+}
+
+// dX[m][k] = (add ? add[m][k] : 0) + sum_n dP[m][n] W[k][n],  dP = dY * act'(S) * rowscale   (dense_dx's contract);
+// here the contraction runs over Nout and the output has Kin columns
+int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
+               const float* rowscale, const float* W, const float* add, float* dX, const char* tag) {
+  GxArgs a{};
+  a.M = M; a.K = Nout; a.N = Kin; a.X = dY; a.R = add; a.Y = dX; a.act = NG_ACT_NONE;
+  a.Sin = act == NG_ACT_NONE ? nullptr : S; a.rs_in = rowscale; a.act_in = act;
+  return gx_launch(ctx, st, a, W, 1, true, tag);
 }
 
 }  // namespace ng

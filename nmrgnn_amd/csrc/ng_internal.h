@@ -23,6 +23,8 @@ size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool h
 bool gemm_x3_fwd_ok(int64_t M, int K, int N);
 int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag);
+int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
+               const float* rowscale, const float* W, const float* add, float* dX, const char* tag);
 
 // fused persistent edge path (edge_fused.hip), edge_hidden_size == 128, edge_fc_layers == 4
 bool edge_fused_supported(int H, int E, int Le);

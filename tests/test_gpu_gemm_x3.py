@@ -45,3 +45,44 @@ def test_dense_fwd_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, resid
     e3 = np.sqrt(((out["bf16x3"][0] - y_ref) ** 2).mean())
     e1 = np.sqrt(((out["fp32"][0] - y_ref) ** 2).mean())
     assert e3 < 1.5 * e1 + 1e-8, (e3, e1)
+
+
+@pytest.mark.parametrize("M,K,N,act,residual", [(4096, 128, 128, 1, 0), (5000, 256, 256, 1, 1), (70000, 256, 768, 0, 0)])
+def test_dense_bwd_dx_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, residual):
+    """dX of ng_dense_bwd (dP = dY * act'(s); dX = (residual ? dY : 0) + dP W^T) on the split-operand GEMM; dW / db stay on
+    the f32-input kernels and are compared as well"""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    if residual:
+        N = K
+    rng = np.random.default_rng(M + N)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    pre = X.astype(np.float64) @ W.astype(np.float64) + b
+    s = (softplus(pre) if act else pre).astype(np.float32)
+    dP = dY.astype(np.float64) * ((1.0 - np.exp(-s.astype(np.float64))) if act else 1.0)
+    dX_ref = dP @ W.astype(np.float64).T + (dY if residual else 0)
+    dW_ref = X.astype(np.float64).T @ dP
+    mag = (np.abs(dP) @ np.abs(W.astype(np.float64)).T).max()
+    res = {}
+    for math in ("bf16x3", "fp32"):
+        monkeypatch.setenv("NG_GEMM_MATH", math)
+        tX, tW, tS, tdY = (torch.from_numpy(a).to(gpu_device) for a in (X, W, s, dY))
+        dX = torch.full((M, K), 7.0, device=gpu_device)
+        dW = torch.full((K, N), 7.0, device=gpu_device)
+        db = torch.full((N,), 7.0, device=gpu_device)
+        ctx = _lib.get_context(0)
+        st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+        ctx.check(ctx.lib.ng_dense_bwd(ctx.handle, st, M, K, N, act, residual, ptr(tX), ptr(tW), ptr(tS), ptr(tdY), ptr(dX),
+                                       ptr(dW), ptr(db)), "ng_dense_bwd")
+        torch.cuda.synchronize()
+        res[math] = dX.cpu().numpy().astype(np.float64)
+        assert np.isfinite(res[math]).all()
+        assert np.abs(res[math] - dX_ref).max() < 2e-6 * mag, math
+        assert np.abs(dW.cpu().numpy() - dW_ref).max() < 1e-4 * np.abs(dW_ref).max()
+    e3 = np.sqrt(((res["bf16x3"] - dX_ref) ** 2).mean())
+    e1 = np.sqrt(((res["fp32"] - dX_ref) ** 2).mean())
+    assert e3 < 1.5 * e1 + 1e-8, (e3, e1)
