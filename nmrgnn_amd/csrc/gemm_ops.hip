@@ -199,7 +199,10 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   const DwPlan p = dw_plan(ctx, M, Kin, Nout, db != nullptr);
   float* partial = scratch;
   float* cs_partial = scratch + p.nz * n_elem;
-  {
+  if (gemm_x3_dw_ok(M, Kin, Nout)) {
+    int rc = gemm_x3_dw(ctx, st, M, Kin, Nout, act, X, dY, S, rowscale, partial, (int)p.nz, p.k_chunk, tag);
+    if (rc) return rc;
+  } else {
     ProfScope ps(ctx, st, tag);
     LoadPlain lq{X, M, Kin, Kin};
     LoadGradAct lp{dY, S, rowscale, M, Nout, act};

@@ -240,4 +240,155 @@ int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int ac
   return gx_launch(ctx, st, a, W, 1, true, tag);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dW[k][n] = sum_m X[m][k] dP[m][n]   (dP = dY * act'(S) * rowscale), the contraction runs over the ROWS of both
+// operands: both live in LDS as bf16 piece images [32 rows][128 + 8] and are read as COLUMNS with ds_read_b64_tr_b16
+// (rows stored permuted so that the four rows of a read sit 8 banks apart — see edge_bwd_x3.hip).  256 threads, output
+// tile 128 (k) x 128 (n), 32 rows per step, the rows split over blockIdx.z into partials [z][K][N] that the caller
+// reduces (dense_dw).  MFMA: A = dP columns (rows n of D), B = X columns (columns k of D): a lane ends with 4
+// consecutive n of one k.
+typedef short gx_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int GT_ROWB = 272;                    // image row stride (bytes)
+constexpr int GT_PLANE = 32 * GT_ROWB;          // 8,704
+constexpr int GT_LDS = 2 * 3 * GT_PLANE;        // 52,224
+
+struct GtArgs {
+  int64_t M, rows_per_z;
+  int K, N;                // X [M][K], dY/S [M][N]
+  const float* X;
+  const float* dY;
+  const float* S;          // may be nullptr
+  const float* rowscale;   // may be nullptr
+  int act;
+  float* partial;          // [nz][K][N]
+};
+
+__device__ __forceinline__ u32x4 gt_tr_frag(const char* p) {
+  const gx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gx_s16x4*)p);
+  const gx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gx_s16x4*)(p + GT_ROWB));
+  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+  return u32x4{a[0], a[1], b[0], b[1]};
+}
+
+__device__ __forceinline__ void gt_store16(char* img, int prow, int col0, const float (&v)[16]) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+  char* d = img + prow * GT_ROWB + col0 * 2;
+  *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
+  *reinterpret_cast<u32x4*>(d + GT_PLANE) = u32x4{m[0], m[1], m[2], m[3]};
+  *reinterpret_cast<u32x4*>(d + GT_PLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
+  *reinterpret_cast<u32x4*>(d + 2 * GT_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
+  *reinterpret_cast<u32x4*>(d + 2 * GT_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gt[];
+  char* sXi = smem_gt;                    // X image  [3][32][272 B]
+  char* sPi = smem_gt + 3 * GT_PLANE;     // dP image
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nh = wave & 1, kh = wave >> 1;
+  const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_z;
+  const int64_t r1 = std::min<int64_t>(r0 + a.rows_per_z, a.M);
+
+  // loader: thread -> row tid >> 3 of the 32-row step, 16 columns at 16 (tid & 7)
+  const int lr = tid >> 3, lc = 16 * (tid & 7);
+  const int e16 = lr & 15;
+  const int prow = 16 * (lr >> 4) + 2 * (e16 & 3) + ((e16 >> 2) & 1) + 8 * (e16 >> 3);   // see bx_prow_g
+  float xv[16], pv[16];
+  auto load = [&](int64_t row) {
+    const bool ok = row < r1;
+    const int64_t rc = ok ? row : a.M - 1;
+    const float* xp = a.X + rc * a.K + k0 + lc;
+    const float* dp = a.dY + rc * a.N + n0 + lc;
+    const float rs = ok ? (a.rowscale ? a.rowscale[rc] : 1.0f) : 0.0f;     // rows past the end contribute zero
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 x = *reinterpret_cast<const float4*>(xp + 4 * i);
+      float4 d = *reinterpret_cast<const float4*>(dp + 4 * i);
+      if (a.S) {
+        const float4 s = *reinterpret_cast<const float4*>(a.S + rc * a.N + n0 + lc + 4 * i);
+        d.x *= act_grad_from_out(a.act, s.x); d.y *= act_grad_from_out(a.act, s.y);
+        d.z *= act_grad_from_out(a.act, s.z); d.w *= act_grad_from_out(a.act, s.w);
+      }
+      xv[4 * i + 0] = x.x; xv[4 * i + 1] = x.y; xv[4 * i + 2] = x.z; xv[4 * i + 3] = x.w;
+      pv[4 * i + 0] = d.x * rs; pv[4 * i + 1] = d.y * rs; pv[4 * i + 2] = d.z * rs; pv[4 * i + 3] = d.w * rs;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // transposing-read lane offsets: 16-lane group g reads [4 rows][16 columns]; lane i supplies row (i>>2), columns 4(i&3)..
+  const int g = lane >> 4, li = lane & 15;
+  const int lane_off = (2 * (li >> 2) + 8 * (g >> 1)) * GT_ROWB + (16 * (g & 1) + 4 * (li & 3)) * 2;
+
+  load(r0 + lr);
+#pragma unroll 1
+  for (int64_t rb = r0; rb < r1; rb += 32) {
+    NG_LDS_BARRIER();
+    gt_store16(sXi, prow, lc, xv);
+    gt_store16(sPi, prow, lc, pv);
+    NG_LDS_BARRIER();
+    load(rb + 32 + lr);                   // next step (rows past r1 load row M-1 and are zeroed)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 pa[2][3], xb[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          pa[j][p] = gt_tr_frag(sPi + p * GT_PLANE + 16 * ks * GT_ROWB + lane_off + 64 * (2 * nh + j));
+          xb[j][p] = gt_tr_frag(sXi + p * GT_PLANE + 16 * ks * GT_ROWB + lane_off + 64 * (2 * kh + j));
+        }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = mma6(pa[j], xb[i], acc[j][i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // D rows = n (from dP), D cols = k (from X): lane holds k = k0 + 32 (2 kh + i) + l31, n = n0 + 32 (2 nh + j) + 8q + 4 half + (0..3)
+  float* part = a.partial + (int64_t)blockIdx.z * a.K * a.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = k0 + 32 * (2 * kh + i) + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + 32 * (2 * nh + j) + 8 * q + 4 * half;
+        *reinterpret_cast<float4*>(part + (int64_t)k * a.N + n) =
+            make_float4(acc[j][i][4 * q + 0], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+      }
+  }
+}
+
+bool gemm_x3_dw_ok(int64_t M, int Kin, int Nout) {
+  const char* v = getenv("NG_GEMM_MATH");
+  if (v && std::string(v) == "fp32") return false;
+  return Kin % 128 == 0 && Nout % 128 == 0 && M >= 4096;
+}
+
+// partial[z][Kin][Nout], z < nz, rows [z * rows_per_z, ...): same partial layout as the f32-input dense_dw GEMM
+int gemm_x3_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
+               const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const char* tag) {
+  GtArgs a;
+  a.M = M; a.rows_per_z = rows_per_z; a.K = Kin; a.N = Nout; a.X = X; a.dY = dY; a.S = S; a.rowscale = rowscale;
+  a.act = act; a.partial = partial;
+  ProfScope ps(ctx, st, tag);
+  hipLaunchKernelGGL(gemm_x3_dw_kernel, dim3((unsigned)(Kin / 128), (unsigned)(Nout / 128), (unsigned)nz), dim3(256), GT_LDS,
+                     st, a);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 }  // namespace ng
