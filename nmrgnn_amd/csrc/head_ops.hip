@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
     }
     float p = x.x * u0 + x.y * u1 + x.z * u2 + x.w * u3;
     p = sum8(p);
-    if (LPR == 16) p += __shfl_xor(p, 8, 64);
+    if (LPR >= 16) p += __shfl_xor(p, 8, 64);
+    if (LPR == 32) p += __shfl_xor(p, 16, 64);
     if (q == 0) peaks[i] = p + v;
   }
 }
@@ -184,6 +185,10 @@ bool head_fast_supported(int Fh, int C) {
   return (size_t)(256 / (Fh / 4)) * (Fh * C + C) * 4 <= 96 * 1024;     // LDS of the backward's final sum
 }
 
+bool head_fwd_fast_supported(int Fh, int C) {
+  return fast_enabled() && (Fh == 32 || Fh == 64 || Fh == 128) && C >= 1 && C <= HC_MAX;
+}
+
 int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
                   const float* Wout, const float* bout, const float* atoms, const float* pstd,
                   const float* pavg, float* peaks) {
@@ -193,6 +198,9 @@ int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   ProfScope ps(ctx, st, "head_fwd");
   if (lpr == 8)
     hipLaunchKernelGGL((head_fwd_fast_kernel<8>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, atoms,
+                       pstd, pavg, peaks);
+  else if (lpr == 32)     // the reference's default width: fc output 128 (the one-thread-per-atom kernel took 91 us for 2770 atoms)
+    hipLaunchKernelGGL((head_fwd_fast_kernel<32>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, atoms,
                        pstd, pavg, peaks);
   else
     hipLaunchKernelGGL((head_fwd_fast_kernel<16>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout,

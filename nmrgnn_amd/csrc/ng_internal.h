@@ -127,6 +127,7 @@ int aggregate_window_csc(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, i
                          const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, float* B);
 // bandwidth-shaped head / embedding kernels (head_ops.hip); NG_HEAD_PATH=generic selects the old ones
 bool head_fast_supported(int Fh, int C);
+bool head_fwd_fast_supported(int Fh, int C);
 int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
                   const float* Wout, const float* bout, const float* atoms, const float* pstd,
                   const float* pavg, float* peaks);

@@ -810,7 +810,7 @@ extern "C" int ng_head_fwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, C >= 1 && C <= MAX_C, "head: number of elements <= 32");
   if (N == 0) return NG_OK;
-  if (head_fast_supported(Fh, C))
+  if (head_fwd_fast_supported(Fh, C))
     return head_fwd_fast(ctx, (hipStream_t)stream, N, Fh, C, g, drop_mask, Wout, bout, atoms, peak_std,
                          peak_avg, peaks);
   ProfScope ps(ctx, (hipStream_t)stream, "head_fwd");
