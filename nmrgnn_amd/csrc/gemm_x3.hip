@@ -4,11 +4,11 @@
 // [N, 768] x [768, 256] of nmrgnn/layers.py:39-40 and the FCBlock layers of model.py:191-196) ran at 87-99 TF on the
 // f32-input MFMA tile GEMM (gemm_ops.hip); this kernel serves dense_fwd for them.  NG_GEMM_MATH=fp32 opts out.
 //
-// 256 threads = 4 waves, tile 128 rows x 128 columns, two workgroups per CU; per 32-wide k-step:
-//   W pieces: fragment-ordered image packed once per call, 24 KB per (column tile, k-step) copied to LDS by LDS-DMA;
+// 256 threads = 4 waves, tile 128 rows x 256 columns (128 when N % 256 != 0), two workgroups per CU; per 32-wide k-step:
+//   W pieces: fragment-ordered image packed once per call, 48 / 24 KB per (column tile, k-step) copied to LDS by LDS-DMA;
 //   X pieces: each thread loads 16 consecutive floats of one row (prefetched one step ahead), splits them and writes
 //             the three piece planes [128][32 + 8] bf16;
-//   wave (n-half, m-half): 2 x 2 blocks of 32 x 32, v_mfma_f32_32x32x16_bf16, A = W^T pieces (rows n), B = X pieces
+//   wave (n-half, m-half): 4 x 2 (2 x 2) blocks of 32 x 32, v_mfma_f32_32x32x16_bf16, A = W^T pieces (rows n), B = X pieces
 //   (columns m), so a lane ends with 4 consecutive n of one row m: 16-byte stores.
 #include <algorithm>
 #include <cstdlib>
@@ -24,25 +24,28 @@ namespace ng {
 constexpr int GX_BM = 128, GX_BN = 128, GX_BK = 32;
 constexpr int GX_XROW = 80;                       // bytes per row of an X piece plane (64 + 16: conflict-free b128 rows)
 constexpr int GX_XPLANE = GX_BM * GX_XROW;        // 10,240
-constexpr int GX_WCHUNK = 4 * 2 * 3 * 1024;       // [n-block][k-step of 16][piece][1 KB]
-constexpr int GX_LDS = 3 * GX_XPLANE + GX_WCHUNK; // 55,296
+// NBW = 32-column blocks per wave (2 -> 128-column tiles, 4 -> 256-column tiles: half the barriers and X splits per MFMA)
+constexpr int gx_wchunk(int nbw) { return 2 * nbw * 2 * 3 * 1024; }   // [n-block][k-step of 16][piece][1 KB]
+constexpr int gx_lds(int nbw) { return 3 * GX_XPLANE + gx_wchunk(nbw); } // 55,296 / 79,872: two workgroups per CU
 
 // image[(ct * KT + kt)][nb][ks][p][lane][8 bf16]:  lane (row n = 128 ct + 32 nb + (l&31), k-slot t) =
 //   piece_p( W[k = 32 kt + 16 ks + 8 (l>>5) + t][n] )
 // trans: the weights are stored [N][K] (dX = dP W^T: contraction over the stored matrix's columns)
-__global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img, int trans) {
+__global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img, int trans, int nbw) {
   const int KT = K / GX_BK;
+  const int BN = 64 * nbw, NB = 2 * nbw;           // columns / 32-column blocks per tile
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (ct, kt, nb, ks, lane)
-  if (idx >= (int64_t)(N / GX_BN) * KT * 4 * 2 * 64) return;
-  const int lane = idx & 63, ks = (idx >> 6) & 1, nb = (idx >> 7) & 3;
-  const int kt = (int)((idx >> 9) % KT), ct = (int)((idx >> 9) / KT);
-  const int n = GX_BN * ct + 32 * nb + (lane & 31), k0 = GX_BK * kt + 16 * ks + 8 * (lane >> 5);
+  if (idx >= (int64_t)(N / BN) * KT * NB * 2 * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) & 1;
+  const int nb = (int)((idx >> 7) % NB);
+  const int kt = (int)(((idx >> 7) / NB) % KT), ct = (int)(((idx >> 7) / NB) / KT);
+  const int n = BN * ct + 32 * nb + (lane & 31), k0 = GX_BK * kt + 16 * ks + 8 * (lane >> 5);
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     split3_pair(trans ? W[(int64_t)n * K + k0 + 2 * j] : W[(int64_t)(k0 + 2 * j) * N + n],
                 trans ? W[(int64_t)n * K + k0 + 2 * j + 1] : W[(int64_t)(k0 + 2 * j + 1) * N + n], h[j], m[j], l[j]);
-  unsigned* dst = img + ((int64_t)(ct * KT + kt) * (GX_WCHUNK / 4)) + ((nb * 2 + ks) * 3) * 256 + lane * 4;
+  unsigned* dst = img + ((int64_t)(ct * KT + kt) * (NB * 2 * 3 * 256)) + ((nb * 2 + ks) * 3) * 256 + lane * 4;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = m[j]; dst[512 + j] = l[j]; }
 }
@@ -64,8 +67,9 @@ struct GxArgs {
   int act_in;
 };
 
-template <bool GRAD>
+template <bool GRAD, int NBW>
 __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
+  constexpr int WCHUNK = gx_wchunk(NBW), BN = 64 * NBW;
   extern __shared__ __attribute__((aligned(16))) char smem_gx[];
   char* sX = smem_gx;                       // [3][128][80 B]
   char* sW = smem_gx + 3 * GX_XPLANE;       // [4][2][3][1 KB]
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
   const int xr = tid >> 1, xh = tid & 1;
   const float* xp = a.X + std::min<int64_t>(m0 + xr, a.M - 1) * a.K + 16 * xh;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / GX_BN) * KT * GX_WCHUNK), 0x00020000);
+      const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / BN) * KT * WCHUNK), 0x00020000);
 
   const float* sp = GRAD && a.Sin ? a.Sin + std::min<int64_t>(m0 + xr, a.M - 1) * a.K + 16 * xh : nullptr;
   const float rsi = GRAD && a.rs_in ? a.rs_in[std::min<int64_t>(m0 + xr, a.M - 1)] : 1.0f;
@@ -91,9 +95,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     if (GRAD && sp) sv[i] = *reinterpret_cast<const float4*>(sp + 4 * i);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[NBW][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NBW; ++j)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -102,12 +106,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
 #pragma unroll 1
   for (int kt = 0; kt < KT; ++kt) {
     NG_LDS_BARRIER();                       // the previous step's fragment reads are done
-    // W pieces of this step: 24 one-KB wave copies, 6 per wave
+    // W pieces of this step: one-KB wave copies, 3 NBW per wave
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < 3 * NBW; ++c) {
       const int kb = wave + 4 * c;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sW + kb * 1024), 16,
-                                               lane * 16, (ct * KT + kt) * GX_WCHUNK + kb * 1024, 0, 0);
+                                               lane * 16, (ct * KT + kt) * WCHUNK + kb * 1024, 0, 0);
     }
     // X pieces: split the 16 prefetched values, two 16-B stores per plane
     {
@@ -148,17 +152,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 wa[2][3], xb[2][3];
+      u32x4 wa[NBW][3], xb[2][3];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NBW; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          wa[j][p] = *reinterpret_cast<const u32x4*>(sW + (((2 * nh + j) * 2 + ks) * 3 + p) * 1024 + lane * 16);
-          xb[j][p] = *reinterpret_cast<const u32x4*>(sX + p * GX_XPLANE + (32 * (2 * mh + j) + l31) * GX_XROW +
+        for (int p = 0; p < 3; ++p)
+          wa[j][p] = *reinterpret_cast<const u32x4*>(sW + (((NBW * nh + j) * 2 + ks) * 3 + p) * 1024 + lane * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          xb[i][p] = *reinterpret_cast<const u32x4*>(sX + p * GX_XPLANE + (32 * (2 * mh + i) + l31) * GX_XROW +
                                                      (16 * ks + 8 * half) * 2);
-        }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NBW; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[j][i] = mma6(wa[j], xb[i], acc[j][i]);
       __builtin_amdgcn_sched_barrier(0);
@@ -172,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     if (m >= a.M) continue;
     const float rs = a.rowscale ? a.rowscale[m] : 1.0f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NBW; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = GX_BN * ct + 32 * (2 * nh + j) + 8 * q + 4 * half;
+        const int n = BN * ct + 32 * (NBW * nh + j) + 8 * q + 4 * half;
         float4 v = make_float4(acc[j][i][4 * q + 0] * rs, acc[j][i][4 * q + 1] * rs, acc[j][i][4 * q + 2] * rs,
                                acc[j][i][4 * q + 3] * rs);
         if (a.bias) {
@@ -201,24 +208,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
 bool gemm_x3_fwd_ok(int64_t M, int K, int N) {
   const char* v = getenv("NG_GEMM_MATH");
   if (v && std::string(v) == "fp32") return false;
-  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && M >= 4096 &&
-         (int64_t)(N / GX_BN) * (K / GX_BK) * GX_WCHUNK < ((int64_t)1 << 31);
+  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && M >= 4096 && (int64_t)N * K * 6 < ((int64_t)1 << 31);
 }
 
 static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int trans, bool grad, const char* tag) {
-  const size_t img_bytes = (size_t)(a.N / GX_BN) * (a.K / GX_BK) * GX_WCHUNK;
+  const int nbw = a.N % 256 == 0 ? 4 : 2;          // 256-column tiles when N allows
+  const int BN = 64 * nbw;
+  const size_t img_bytes = (size_t)a.N * a.K * 6;  // three bf16 pieces per weight
   char* img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
   if (!img) return NG_ERR_NOMEM;
   {
-    const int64_t n_thr = (int64_t)(a.N / GX_BN) * (a.K / GX_BK) * 4 * 2 * 64;
-    hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, a.K, a.N, W, (unsigned*)img, trans);
+    const int64_t n_thr = (int64_t)(a.N / 32) * (a.K / 16) * 64;
+    hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, a.K, a.N, W, (unsigned*)img, trans,
+                       nbw);
     NG_HIP(ctx, hipGetLastError());
   }
   a.Wimg = img;
   ProfScope ps(ctx, st, tag);
-  const dim3 grid((unsigned)cdiv(a.M, GX_BM), (unsigned)(a.N / GX_BN));
-  if (grad) hipLaunchKernelGGL(gemm_x3_fwd_kernel<true>, grid, dim3(256), GX_LDS, st, a);
-  else hipLaunchKernelGGL(gemm_x3_fwd_kernel<false>, grid, dim3(256), GX_LDS, st, a);
+  const dim3 grid((unsigned)cdiv(a.M, GX_BM), (unsigned)(a.N / BN));
+  if (nbw == 4) {
+    if (grad) hipLaunchKernelGGL((gemm_x3_fwd_kernel<true, 4>), grid, dim3(256), gx_lds(4), st, a);
+    else hipLaunchKernelGGL((gemm_x3_fwd_kernel<false, 4>), grid, dim3(256), gx_lds(4), st, a);
+  } else {
+    if (grad) hipLaunchKernelGGL((gemm_x3_fwd_kernel<true, 2>), grid, dim3(256), gx_lds(2), st, a);
+    else hipLaunchKernelGGL((gemm_x3_fwd_kernel<false, 2>), grid, dim3(256), gx_lds(2), st, a);
+  }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
