@@ -248,7 +248,9 @@ def gnn_forward(inputs, p, hp, peak_std=None, peak_avg=None, training=False,
     noised = edge_input
     if training and hp["noise"] > 0:
         assert noise is not None, "training=True needs an explicit noise draw"
-        noised = edge_input + dtype(hp["noise"]) * np.asarray(noise, dtype)  # model.py:253
+        # model.py:253; the traced graph holds stddev as a float32 constant (0.025f), see
+        # tests/golden/make_savedmodel_exec.py
+        noised = edge_input + dtype(np.float32(hp["noise"])) * np.asarray(noise, dtype)
     centers, gap = rbf_centers(hp["rbf_low"], hp["rbf_high"], hp["edge_hidden_size"])
     rbf = rbf_expand(noised, centers, gap, dtype)                    # model.py:254
     rbf = rbf * edge_mask                                            # model.py:257
@@ -433,7 +435,8 @@ def gnn_forward_backward(inputs, p, hp, dpeaks, peak_std=None, peak_avg=None,
 
     # ---------------- forward, keeping intermediates
     mask = (d > 0).astype(dtype)[..., None]
-    dn = d + (hp["noise"] * np.asarray(noise, dtype) if (training and hp["noise"] > 0) else 0.0)
+    dn = d + (dtype(np.float32(hp["noise"])) * np.asarray(noise, dtype)
+              if (training and hp["noise"] > 0) else 0.0)
     centers, gap = rbf_centers(hp["rbf_low"], hp["rbf_high"], H)
     z = [rbf_expand(dn, centers, gap) * mask]
     pre_e = []

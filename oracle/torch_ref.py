@@ -61,7 +61,7 @@ def forward(inputs, p, hp, peak_std=None, peak_avg=None, training=False, noise=N
     avg = torch.zeros(C, dtype=dtype) if peak_avg is None else torch.as_tensor(peak_avg, dtype=dtype)[:C]
     mask = (d > 0).to(dtype)[..., None]
     if training and hp["noise"] > 0:
-        d = d + hp["noise"] * torch.as_tensor(noise, dtype=dtype)
+        d = d + float(np.float32(hp["noise"])) * torch.as_tensor(noise, dtype=dtype)   # 0.025f in the traced graph
     centers, gap = O.rbf_centers(hp["rbf_low"], hp["rbf_high"], hp["edge_hidden_size"])
     centers = torch.tensor(centers, dtype=dtype)
     x = torch.exp(-(d[..., None] - centers) ** 2 / float(gap)) * mask

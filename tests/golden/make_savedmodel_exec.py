@@ -1,0 +1,528 @@
+#!/usr/bin/env python
+"""EXECUTE the reference's own traced graph and commit what it produces.
+
+``/root/reference/nmrgnn/models/baseline/saved_model.pb`` holds the TensorFlow graph that the
+reference's ``GNNModel.call`` (nmrgnn/model.py:245-274) was traced to: FunctionDef
+``__inference__wrapped_model_4657940`` (training=False, 189 nodes) and
+``__inference_gnn-model_layer_call_and_return_conditional_losses_4659631`` (training=True, with
+GaussianNoise + Dropout).  TensorFlow is not installable here and the bundle's weight VALUES are
+missing, but the GRAPH is the reference's arithmetic, op by op.  This script
+
+  1. decodes the FunctionDefs with the protobuf wire-format reader of make_savedmodel_constants.py,
+  2. interprets every node in NumPy (the ~30 op types the two functions use, see ``OPS``), feeding
+     seeded weights at the ``ReadVariableOp`` sites (resource argument -> Keras variable, SURVEY
+     App. A) and explicit draws at the two random ops of the training function,
+  3. writes inputs + outputs to ``tests/golden/golden_savedmodel.npz``.
+
+Nothing here calls the oracle or the HIP engine: the expected values come from the reference's graph
+alone.  The graph is evaluated twice: in float64 (every float tensor promoted; the mathematical
+value of the reference's graph: ``peaks64``) and in float32 (TensorFlow's own precision, NumPy
+summation order: ``peaks32``) so that tests can state how far fp32 evaluation of the reference
+itself sits from its exact value.
+
+Run in the build container only (reads /root/reference); the .npz travels, this script's input
+does not.  Weights are NOT stored (1.07 M floats at the baseline width): they are regenerated from
+``weight_seed`` by ``seeded_weights`` below (tests/helpers.py carries the same generator) and
+pinned by a SHA-256 of their bytes.
+"""
+import hashlib
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+from make_savedmodel_constants import PB, fields  # noqa: E402
+
+FN_INFER = "__inference__wrapped_model_4657940"
+FN_TRAIN = "__inference_gnn-model_layer_call_and_return_conditional_losses_4659631"
+
+# TensorFlow DataType enum values that occur in these functions
+DT_FLOAT, DT_INT32, DT_INT64, DT_BOOL, DT_RESOURCE = 1, 3, 9, 10, 20
+
+
+# ----------------------------------------------------------------------------------------------
+# protobuf decoding (NodeDef / AttrValue / TensorProto / FunctionDef)
+# ----------------------------------------------------------------------------------------------
+def _signed(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def parse_shape(b):
+    dims = []
+    for fn, wt, v in fields(b):
+        if fn == 2:
+            size = 0
+            for f2, w2, v2 in fields(v):
+                if f2 == 1:
+                    size = _signed(v2)
+            dims.append(size)
+    return dims
+
+
+def parse_tensor(b):
+    dtype, shape, content = None, [], b""
+    fvals, ivals, lvals, bvals = [], [], [], []
+    for fn, wt, v in fields(b):
+        if fn == 1:
+            dtype = v
+        elif fn == 2:
+            shape = parse_shape(v)
+        elif fn == 4:
+            content = v
+        elif fn == 5:
+            fvals += list(struct.unpack(f"<{len(v)//4}f", v)) if wt == 2 else [struct.unpack("<f", v)[0]]
+        elif fn == 7:
+            if wt == 2:
+                i = 0
+                from make_savedmodel_constants import varint
+                while i < len(v):
+                    x, i = varint(v, i)
+                    ivals.append(_signed(x))
+            else:
+                ivals.append(_signed(v))
+        elif fn == 10:
+            if wt == 2:
+                i = 0
+                from make_savedmodel_constants import varint
+                while i < len(v):
+                    x, i = varint(v, i)
+                    lvals.append(_signed(x))
+            else:
+                lvals.append(_signed(v))
+        elif fn == 11:
+            bvals.append(bool(v))
+    np_dt = {DT_FLOAT: np.float32, DT_INT32: np.int32, DT_INT64: np.int64, DT_BOOL: np.bool_}.get(dtype)
+    if np_dt is None:                        # DT_STRING etc. (save/restore plumbing): not on the path
+        return None
+    n = int(np.prod(shape)) if shape else 1
+    if content:
+        arr = np.frombuffer(content, dtype=np_dt).copy()
+    else:
+        vals = {DT_FLOAT: fvals, DT_INT32: ivals, DT_INT64: lvals, DT_BOOL: bvals}[dtype]
+        if len(vals) == 0:
+            vals = [0]
+        if len(vals) < n:                    # TensorProto: a short value list repeats its last entry
+            vals = list(vals) + [vals[-1]] * (n - len(vals))
+        arr = np.asarray(vals, dtype=np_dt)
+    return arr.reshape(shape)
+
+
+def parse_attr(b):
+    out = {}
+    for fn, wt, v in fields(b):
+        if fn == 2:
+            out["s"] = v.decode("latin-1")
+        elif fn == 3:
+            out["i"] = _signed(v)
+        elif fn == 4:
+            out["f"] = struct.unpack("<f", v)[0]
+        elif fn == 5:
+            out["b"] = bool(v)
+        elif fn == 6:
+            out["type"] = v
+        elif fn == 7:
+            out["shape"] = parse_shape(v)
+        elif fn == 8:
+            out["tensor"] = parse_tensor(v)
+    return out
+
+
+def parse_nodedef(b):
+    n = {"attr": {}, "input": []}
+    for fn, wt, v in fields(b):
+        if fn == 1:
+            n["name"] = v.decode()
+        elif fn == 2:
+            n["op"] = v.decode()
+        elif fn == 3:
+            n["input"].append(v.decode())
+        elif fn == 5:
+            key, val = None, None
+            for f2, w2, v2 in fields(v):
+                if f2 == 1:
+                    key = v2.decode()
+                elif f2 == 2:
+                    val = v2
+            if key != "_output_shapes":
+                n["attr"][key] = parse_attr(val)
+    return n
+
+
+def load_functions(pb_path=PB):
+    """{function name: dict(args=[(name, dtype)], nodes=[NodeDef...], ret={out: tensor name})} and the
+    top-level graph's Const nodes."""
+    b = open(pb_path, "rb").read()
+    funcs, top_consts = {}, {}
+    for fn, wt, v in fields(b):
+        if fn != 2:
+            continue
+        for f2, w2, v2 in fields(v):
+            if f2 != 2:
+                continue
+            for f3, w3, v3 in fields(v2):          # GraphDef
+                if f3 == 1:
+                    nd = parse_nodedef(v3)
+                    if nd["op"] == "Const" and nd["attr"]["value"].get("tensor") is not None:
+                        top_consts[nd["name"]] = nd["attr"]["value"]["tensor"]
+                elif f3 == 2:                          # FunctionDefLibrary
+                    for f4, w4, v4 in fields(v3):
+                        if f4 != 1:
+                            continue
+                        fd = {"args": [], "outs": [], "nodes": [], "ret": {}}
+                        for f5, w5, v5 in fields(v4):
+                            if f5 == 1:                # OpDef signature
+                                for f6, w6, v6 in fields(v5):
+                                    if f6 == 1:
+                                        fd["name"] = v6.decode()
+                                    elif f6 in (2, 3):
+                                        an, at = None, None
+                                        for f7, w7, v7 in fields(v6):
+                                            if f7 == 1:
+                                                an = v7.decode()
+                                            elif f7 == 3:
+                                                at = v7
+                                        (fd["args"] if f6 == 2 else fd["outs"]).append((an, at))
+                            elif f5 == 3:
+                                fd["nodes"].append(parse_nodedef(v5))
+                            elif f5 == 4:
+                                k, val = None, None
+                                for f6, w6, v6 in fields(v5):
+                                    if f6 == 1:
+                                        k = v6.decode()
+                                    elif f6 == 2:
+                                        val = v6.decode()
+                                fd["ret"][k] = val
+                        funcs[fd["name"]] = fd
+    return funcs, top_consts
+
+
+# ----------------------------------------------------------------------------------------------
+# op semantics (TensorFlow 2.3 kernels, restated from the op definitions)
+# ----------------------------------------------------------------------------------------------
+def _tf_softplus(x):
+    """tensorflow/core/kernels/softplus_op.h: x > -thr -> x ; x < thr -> exp(x) ; else log1p(exp(x)),
+    thr = log(eps) + 2."""
+    eps = np.finfo(x.dtype).eps
+    thr = np.log(eps).astype(x.dtype) + x.dtype.type(2)
+    with np.errstate(over="ignore"):
+        ex = np.exp(x)
+        mid = np.log1p(ex)
+    return np.where(x > -thr, x, np.where(x < thr, ex, mid)).astype(x.dtype)
+
+
+def _strided_slice(x, begin, end, strides, attr):
+    """Only the form the graph uses: ``x[..., tf.newaxis]`` (ellipsis_mask=1, new_axis_mask=2)."""
+    g = lambda k: attr.get(k, {}).get("i", 0)
+    assert (g("ellipsis_mask"), g("new_axis_mask"), g("begin_mask"), g("end_mask"),
+            g("shrink_axis_mask")) == (1, 2, 0, 0, 0), "unexpected StridedSlice form"
+    assert list(begin) == [0, 0] and list(end) == [0, 0] and list(strides) == [1, 1]
+    return x[..., None]
+
+
+class Interp:
+    def __init__(self, fd, float_dtype, variables, random_feed=None):
+        self.fd, self.ft = fd, np.dtype(float_dtype)
+        self.variables = variables              # resource argument name -> ndarray
+        self.random_feed = random_feed or {}    # node name -> ndarray
+        self.ops_seen = {}
+
+    def _flt(self, a):
+        a = np.asarray(a)
+        return a.astype(self.ft) if a.dtype.kind == "f" else a
+
+    def run(self, feeds):
+        env = {}
+        for (name, dt) in self.fd["args"]:
+            if dt == DT_RESOURCE:
+                env[name] = ("resource", name)
+            else:
+                env[name] = self._flt(feeds[name])
+        pending = list(self.fd["nodes"])
+        by_name = {n["name"]: n for n in pending}
+
+        def value(ref):
+            assert not ref.startswith("^")
+            parts = ref.split(":")
+            if len(parts) == 1:
+                return env[ref]
+            assert parts[-1] == "0", ref
+            node = parts[0]
+            if node not in env:
+                env[node] = self.eval(by_name[node], value)
+            return env[node]
+
+        (out_name, ret_ref), = self.fd["ret"].items()
+        res = value(ret_ref)
+        self.env = env
+        return res
+
+    def eval(self, n, value):
+        op, a = n["op"], n["attr"]
+        self.ops_seen[op] = self.ops_seen.get(op, 0) + 1
+        x = [value(r) for r in n["input"] if not r.startswith("^")]
+        if op == "Const":
+            return self._flt(a["value"]["tensor"])
+        if op == "ReadVariableOp":
+            kind, res = x[0]
+            return self._flt(self.variables[res])
+        if op == "Identity":
+            return x[0]
+        if op == "Greater":
+            return x[0] > x[1]
+        if op == "GreaterEqual":
+            return x[0] >= x[1]
+        if op == "Cast":
+            dst = a["DstT"]["type"]
+            if dst == DT_FLOAT:
+                return x[0].astype(self.ft)
+            return x[0].astype({DT_INT32: np.int32, DT_INT64: np.int64, DT_BOOL: np.bool_}[dst])
+        if op == "StridedSlice":
+            return _strided_slice(x[0], x[1], x[2], x[3], a)
+        if op == "Sub":
+            return x[0] - x[1]
+        if op in ("AddV2", "Add"):
+            return x[0] + x[1]
+        if op == "Mul":
+            return x[0] * x[1]
+        if op == "RealDiv":
+            return x[0] / x[1]
+        if op == "Neg":
+            return -x[0]
+        if op == "Pow":
+            return np.power(x[0], x[1])
+        if op == "Exp":
+            return np.exp(x[0])
+        if op == "Softplus":
+            return _tf_softplus(x[0])
+        if op == "Shape":
+            return np.asarray(x[0].shape, np.int32)
+        if op == "GatherV2":
+            assert a.get("batch_dims", {}).get("i", 0) == 0
+            return np.take(x[0], x[1], axis=int(x[2]))
+        if op == "Prod":
+            return np.prod(x[0], axis=tuple(np.atleast_1d(x[1]).tolist()),
+                           keepdims=a.get("keep_dims", {}).get("b", False)).astype(x[0].dtype)
+        if op == "Sum":
+            return np.sum(x[0], axis=tuple(np.atleast_1d(x[1]).tolist()),
+                          keepdims=a.get("keep_dims", {}).get("b", False))
+        if op == "ConcatV2":
+            return np.concatenate([np.atleast_1d(v) for v in x[:-1]], axis=int(x[-1]))
+        if op == "Pack":
+            return np.stack(x, axis=a.get("axis", {}).get("i", 0))
+        if op == "Transpose":
+            return np.transpose(x[0], np.asarray(x[1]).tolist())
+        if op == "Reshape":
+            return np.reshape(x[0], np.asarray(x[1]).tolist())
+        if op == "MatMul":
+            A = x[0].T if a.get("transpose_a", {}).get("b", False) else x[0]
+            B = x[1].T if a.get("transpose_b", {}).get("b", False) else x[1]
+            return A @ B
+        if op == "BiasAdd":
+            assert a.get("data_format", {}).get("s", "NHWC") == "NHWC"
+            return x[0] + x[1]
+        if op == "Einsum":
+            return np.einsum(a["equation"]["s"], *x)
+        if op in ("RandomStandardNormal", "RandomUniform"):
+            draw = self._flt(self.random_feed[n["name"]])
+            assert list(draw.shape) == np.asarray(x[0]).tolist(), (draw.shape, x[0])
+            return draw
+        raise NotImplementedError(f"op {op} ({n['name']})")
+
+
+# resource argument (suffix after the function's name prefix) -> (state-dict key of this repo).
+# edge-fc-block/dense..dense_3, mp-block/MPLayer w x4 (einsum, einsum_1..3),
+# fc-block/dense_4..7, out_layer = dense_8, embed_layer = dense_9.
+def variable_map(fd):
+    m = {}
+    for name, dt in fd["args"]:
+        if dt != DT_RESOURCE:
+            continue
+        s = name.replace("gnn_model_", "")
+        key = None
+        for t in range(4):
+            tag = "dense" if t == 0 else f"dense_{t}"
+            if s.startswith(f"edge_fc_block_{tag}_tensordot"):
+                key = f"edge_fc/{t}/kernel"
+            elif s.startswith(f"edge_fc_block_{tag}_biasadd"):
+                key = f"edge_fc/{t}/bias"
+        for l in range(4):
+            tag = "einsum" if l == 0 else f"einsum_{l}"
+            if s.startswith(f"mp_block_mplayer_{tag}_einsum_readvariableop"):
+                key = f"mp/{l}/w"
+        for t in range(4):
+            if s.startswith(f"fc_block_dense_{4+t}_matmul"):
+                key = f"fc/{t}/kernel"
+            elif s.startswith(f"fc_block_dense_{4+t}_biasadd"):
+                key = f"fc/{t}/bias"
+        if s.startswith("dense_8_matmul"):
+            key = "out/kernel"
+        elif s.startswith("dense_8_biasadd"):
+            key = "out/bias"
+        elif s.startswith("dense_9_matmul"):
+            key = "embed/kernel"
+        assert key is not None, name
+        m[name] = key
+    assert len(set(m.values())) == len(m) == 23, m
+    return m
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded inputs
+# ----------------------------------------------------------------------------------------------
+def weight_shapes(F, E=3, H=128, C=10):
+    out = []
+    for t in range(4):
+        ko = H if t < 3 else E
+        out += [(f"edge_fc/{t}/kernel", (H, ko)), (f"edge_fc/{t}/bias", (ko,))]
+    out += [(f"mp/{l}/w", (F, F, E)) for l in range(4)]
+    for t in range(4):
+        ko = F if t < 3 else F // 2
+        out += [(f"fc/{t}/kernel", (F, ko)), (f"fc/{t}/bias", (ko,))]
+    out += [("out/kernel", (F // 2, C)), ("out/bias", (C,)), ("embed/kernel", (C, F))]
+    return out
+
+
+def seeded_weights(F, seed, bias_scale=0.05):
+    """Keras-like scales (uniform +-sqrt(6/(fan_in+fan_out)), rank-3 fans as Keras computes them) and
+    NON-zero biases so the bias/mask paths matter.  float32 values.  (tests/helpers.py: same code.)"""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in weight_shapes(F):
+        if len(shape) == 1:
+            p[name] = (bias_scale * rng.standard_normal(shape)).astype(np.float32)
+            continue
+        if len(shape) == 2:
+            fi, fo = shape
+        else:
+            fi, fo = shape[1] * shape[0], shape[2] * shape[0]
+        lim = np.sqrt(6.0 / (fi + fo))
+        p[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    return p
+
+
+def weights_digest(p):
+    h = hashlib.sha256()
+    for k in sorted(p):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(p[k], np.float32).tobytes())
+    return h.hexdigest()
+
+
+def graph_108M():
+    """tests/data/108M.pdb (the reference's tests/108M.pdb) through this repo's host graph builder: the
+    tuple is an INPUT of the comparison, its conventions do not matter here."""
+    from nmrgnn_amd import structure as S
+    s = S.read_pdb(os.path.join(ROOT, "tests", "data", "108M.pdb"))
+    nlist, edges = S.knn_graph(s.positions, 16)
+    atoms = S.atoms_onehot(s.elements)
+    return atoms, nlist.astype(np.int32), edges.astype(np.float32), S.inv_degree_of(nlist)
+
+
+def graph_padded(seed=11):
+    """3 synthetic graphs (40/17/9 atoms; the 9-atom one has fewer than 16 possible neighbours, so
+    half its slots are padding), global indices, an atom with NO neighbour at all, every element
+    index 0..9 present."""
+    from nmrgnn_amd import synth
+    rng = np.random.default_rng(seed)
+    atoms, nlist, edges, inv = [], [], [], []
+    off = 0
+    for n in (40, 17, 9):
+        a, nl, d = synth.make_graph(n, 16, 10, 0.15, rng)
+        inv.append(synth.inv_degree(nl))
+        atoms.append(a)
+        nlist.append(np.where(d > 0, nl + off, 0))
+        edges.append(d)
+        off += n
+    atoms, nlist, edges, inv = (np.concatenate(x) for x in (atoms, nlist, edges, inv))
+    edges[5, :] = 0.0
+    nlist[5, :] = 0
+    inv[5] = 0.0
+    el = rng.integers(0, 10, size=atoms.shape[0])
+    el[:10] = np.arange(10)
+    atoms = np.zeros_like(atoms)
+    atoms[np.arange(len(el)), el] = 1.0
+    return atoms.astype(np.float32), nlist.astype(np.int32), edges.astype(np.float32), inv.astype(np.float32)
+
+
+def run_function(fd, top_consts, graph, weights, float_dtype, random_feed=None, keep=()):
+    vmap = variable_map(fd)
+    variables = {res: weights[key] for res, key in vmap.items()}
+    centers = next(v for v in top_consts.values() if v.shape == (128,))
+    gap = next(v for v in top_consts.values() if v.shape == () and v.dtype == np.float32 and 1e-3 < v < 2e-3)
+    names = [n for n, dt in fd["args"] if dt != DT_RESOURCE]
+    # the first four are the serving inputs, the next two the captured RBF constants (sub_y, truediv_y)
+    assert len(names) == 6 and "sub_y" in names[4] and "truediv_y" in names[5], names
+    feeds = dict(zip(names, [graph[0], graph[1], graph[2], graph[3], centers, gap]))
+    it = Interp(fd, float_dtype, variables, random_feed)
+    out = it.run(feeds)
+    extra = {k: it.env[k] for k in keep if k in it.env}
+    return out, it.ops_seen, extra
+
+
+def main():
+    funcs, top_consts = load_functions()
+    out = {}
+    summary = []
+    cases = [("pdb108m", graph_108M(), 256, 4657), ("padded", graph_padded(), 64, 4658)]
+    for tag, g, F, wseed in cases:
+        w = seeded_weights(F, wseed)
+        N, K = g[2].shape
+        fd = funcs[FN_INFER]
+        keep = ("gnn-model/mul_1", "gnn-model/mp-block/add_3")
+        p64, ops, ex64 = run_function(fd, top_consts, g, w, np.float64, keep=keep)
+        p32, _, _ = run_function(fd, top_consts, g, w, np.float32)
+        # training function: explicit standard-normal xi[N,K]; the dropout uniform u[N,F/2] is fed as
+        # 1.0 for a kept unit and 0.0 for a dropped one (the graph only tests u >= 0.2), so the fixture
+        # carries a bit mask instead of 1.2 MB of uniforms
+        rng = np.random.default_rng(wseed + 1)
+        xi = rng.standard_normal((N, K)).astype(np.float32)
+        keep_mask = rng.random((N, F // 2)) >= 0.2
+        u = keep_mask.astype(np.float32)
+        fdt = funcs[FN_TRAIN]
+        feed = {"gaussian_noise/random_normal/RandomStandardNormal": xi,
+                "dropout/dropout/random_uniform/RandomUniform": u}
+        t64, ops_t, _ = run_function(fdt, top_consts, g, w, np.float64, feed)
+        t32, _, _ = run_function(fdt, top_consts, g, w, np.float32, feed)
+        el = np.argmax(g[0], axis=1).astype(np.int8)
+        assert np.array_equal(np.eye(10, dtype=np.float32)[el], g[0])
+        out.update({
+            f"{tag}:elem": el, f"{tag}:nlist": g[1].astype(np.int16 if N < 32768 else np.int32),
+            f"{tag}:edges": g[2], f"{tag}:inv_degree": g[3],
+            f"{tag}:F": np.int64(F), f"{tag}:weight_seed": np.int64(wseed),
+            f"{tag}:weights_sha256": np.array(weights_digest(w)),
+            f"{tag}:peaks64": p64, f"{tag}:peaks32": p32.astype(np.float32),
+            # intermediates of the float64 run (float32-rounded, for debugging a mismatch):
+            # masked edge features e[N,K,3] and every 16th row of the node features after the MP block
+            f"{tag}:e64": ex64["gnn-model/mul_1"].astype(np.float32),
+            f"{tag}:h_mp64_rows16": ex64["gnn-model/mp-block/add_3"][::16].astype(np.float32),
+            f"{tag}:train_xi": xi, f"{tag}:train_keep_bits": np.packbits(keep_mask, axis=None),
+            f"{tag}:train_peaks64": t64, f"{tag}:train_peaks32": t32.astype(np.float32),
+        })
+        summary.append((tag, N, F, float(np.abs(p64).max()), float(np.abs(p32 - p64).max()),
+                        float(np.abs(t32 - t64).max())))
+        print(tag, "N", N, "F", F, "ops", dict(sorted(ops.items())))
+        print("   inference |peaks|max %.4f  fp32-vs-fp64 exec %.3e ; training fp32-vs-fp64 %.3e"
+              % summary[-1][3:])
+    out["peak_std"] = top_consts_std(funcs)
+    out["peak_avg"] = top_consts_avg(funcs)
+    out["source"] = np.array("reference saved_model.pb FunctionDefs %s / %s executed by "
+                             "tests/golden/make_savedmodel_exec.py" % (FN_INFER, FN_TRAIN))
+    np.savez_compressed(os.path.join(HERE, "golden_savedmodel.npz"), **out)
+    print("wrote golden_savedmodel.npz")
+
+
+def top_consts_std(funcs):
+    return next(n for n in funcs[FN_INFER]["nodes"] if n["name"] == "gnn-model/mul_3/y")["attr"]["value"]["tensor"]
+
+
+def top_consts_avg(funcs):
+    return next(n for n in funcs[FN_INFER]["nodes"] if n["name"] == "gnn-model/mul_4/y")["attr"]["value"]["tensor"]
+
+
+if __name__ == "__main__":
+    main()

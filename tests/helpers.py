@@ -35,3 +35,59 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+# ---- reference-graph fixture (tests/golden/golden_savedmodel.npz, made by make_savedmodel_exec.py) ----
+def savedmodel_weight_shapes(F, E=3, H=128, C=10):
+    out = []
+    for t in range(4):
+        ko = H if t < 3 else E
+        out += [(f"edge_fc/{t}/kernel", (H, ko)), (f"edge_fc/{t}/bias", (ko,))]
+    out += [(f"mp/{l}/w", (F, F, E)) for l in range(4)]
+    for t in range(4):
+        ko = F if t < 3 else F // 2
+        out += [(f"fc/{t}/kernel", (F, ko)), (f"fc/{t}/bias", (ko,))]
+    out += [("out/kernel", (F // 2, C)), ("out/bias", (C,)), ("embed/kernel", (C, F))]
+    return out
+
+
+def savedmodel_seeded_weights(F, seed, bias_scale=0.05):
+    """the weight generator of tests/golden/make_savedmodel_exec.py (same draws; pinned by SHA-256)"""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in savedmodel_weight_shapes(F):
+        if len(shape) == 1:
+            p[name] = (bias_scale * rng.standard_normal(shape)).astype(np.float32)
+            continue
+        if len(shape) == 2:
+            fi, fo = shape
+        else:
+            fi, fo = shape[1] * shape[0], shape[2] * shape[0]
+        lim = np.sqrt(6.0 / (fi + fo))
+        p[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    return p
+
+
+def load_savedmodel_case(tag):
+    """One case of the reference-executed fixture: dict with the input tuple, seeded weights (digest
+    checked), explicit training draws and the outputs of the reference's traced graph."""
+    import hashlib
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_savedmodel.npz"))
+    F = int(z[f"{tag}:F"])
+    w = savedmodel_seeded_weights(F, int(z[f"{tag}:weight_seed"]))
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k], np.float32).tobytes())
+    assert h.hexdigest() == str(z[f"{tag}:weights_sha256"]), "seeded weights differ from the fixture's"
+    elem = z[f"{tag}:elem"].astype(np.int64)
+    atoms = np.eye(10, dtype=np.float32)[elem]
+    edges = z[f"{tag}:edges"]
+    N, K = edges.shape
+    keep = np.unpackbits(z[f"{tag}:train_keep_bits"])[:N * (F // 2)].reshape(N, F // 2).astype(bool)
+    return dict(F=F, weights=w, atoms=atoms, nlist=z[f"{tag}:nlist"].astype(np.int32), edges=edges,
+                inv_degree=z[f"{tag}:inv_degree"], peak_std=z["peak_std"], peak_avg=z["peak_avg"],
+                peaks64=z[f"{tag}:peaks64"], peaks32=z[f"{tag}:peaks32"], e64=z[f"{tag}:e64"],
+                h_mp64_rows16=z[f"{tag}:h_mp64_rows16"], train_xi=z[f"{tag}:train_xi"], train_keep=keep,
+                train_peaks64=z[f"{tag}:train_peaks64"], train_peaks32=z[f"{tag}:train_peaks32"])

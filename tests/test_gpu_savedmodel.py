@@ -1,0 +1,97 @@
+"""The HIP path against the REFERENCE'S OWN TRACED GRAPH (tests/golden/golden_savedmodel.npz: the
+SavedModel FunctionDefs of nmrgnn/model.py:245-274 executed op by op in float64 by
+tests/golden/make_savedmodel_exec.py; the oracle is not involved in producing the expected values).
+
+Tolerances.  BASELINE.json's north star is 1e-4 on the predicted shifts.  The head output is multiplied
+by the real peak_std (50.94 for N, 10.6 for C, 6.04 for H; model.py:272-273), so 1e-4 absolute on an N
+shift is 2e-6 on the standardised output after 12 float32 layers.  The fixture records that float32
+evaluation of the reference's own graph (NumPy summation order) already sits 1.7e-4 (F=64 case) and
+5.7e-4 (F=256, 108M.pdb) away from its float64 value.  The test therefore asserts
+  * 5e-5 on the STANDARDISED prediction ((peaks-avg)/std, the quantity the network computes; half the
+    1e-4 budget of the north star at std = 1; measured: <= 1.7e-5), and
+  * on the de-standardised shifts, per element: max error <= max(1e-4, 4 x the error of the
+    reference's own float32 evaluation of the same graph) — both are samples of float32 rounding noise
+    of the same scale (measured: 0.4x - 3.3x),
+and prints the measured per-element errors (C = 2, N = 3, H = 4).  Measured on MI355X, 108M.pdb, F=256:
+C 1.3e-4, N 6.3e-4, H 1.0e-4 against 1.6e-4 / 5.7e-4 / 1.2e-4 for the reference graph in float32.
+"""
+import numpy as np
+import pytest
+
+from helpers import load_savedmodel_case, make_hp
+
+pytestmark = pytest.mark.gpu
+
+STD_ATOL = 5e-5
+
+
+def _engine(gpu_device, c):
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    hp = make_hp(atom_feature_size=c["F"])
+    eng = Engine(hp, 10, c["peak_std"], c["peak_avg"], device=gpu_device, seed=1)
+    eng.params.load_state_dict(c["weights"])
+    gb = GraphBatch(c["atoms"], c["nlist"], c["edges"], c["inv_degree"], device=gpu_device)
+    return eng, gb
+
+
+def _errors(c, peaks, ref64, ref32):
+    elem = np.argmax(c["atoms"], axis=1)
+    std = c["peak_std"].astype(np.float64)
+    rows = []
+    for e in np.unique(elem):
+        m = elem == e
+        err = np.abs(peaks[m] - ref64[m]).max()
+        err32 = np.abs(ref32[m].astype(np.float64) - ref64[m]).max()
+        rows.append((int(e), float(std[e]), float(err), float(err32),
+                     float(err / std[e]) if std[e] > 0 else 0.0))
+    return rows
+
+
+def _check(tag, c, peaks, ref64, ref32, what):
+    rows = _errors(c, peaks.astype(np.float64), ref64, ref32)
+    for e, s, err, err32, err_std in rows:
+        print(f"[{tag}/{what}] element {e} std {s:8.4f}: |hip-ref64| {err:.3e}  |ref32-ref64| {err32:.3e}  "
+              f"standardised {err_std:.3e}")
+    for e, s, err, err32, err_std in rows:
+        assert err_std < STD_ATOL, (tag, what, e, err_std)
+        assert err <= max(1e-4, 4.0 * err32), (tag, what, e, err, err32)
+        if s == 0:
+            assert err == 0.0           # std = avg = 0 elements predict exactly 0 (model.py:272-273)
+
+
+@pytest.mark.parametrize("tag", ["padded", "pdb108m"])
+def test_hip_equals_reference_graph_inference(gpu_device, tag):
+    c = load_savedmodel_case(tag)
+    eng, gb = _engine(gpu_device, c)
+    peaks = eng.forward(gb, training=False).cpu().numpy()
+    _check(tag, c, peaks, c["peaks64"], c["peaks32"], "inference")
+
+
+@pytest.mark.parametrize("tag", ["padded", "pdb108m"])
+def test_hip_equals_reference_graph_training(gpu_device, tag):
+    """training=True trace with the fixture's explicit GaussianNoise / Dropout draws."""
+    import torch
+    c = load_savedmodel_case(tag)
+    eng, gb = _engine(gpu_device, c)
+    xi = torch.from_numpy(c["train_xi"]).to(gpu_device)
+    mask = torch.from_numpy((c["train_keep"].astype(np.float32) * np.float32(1.25))).to(gpu_device)
+    peaks = eng.forward(gb, training=True, noise=xi, dropout_mask=mask).cpu().numpy()
+    _check(tag, c, peaks, c["train_peaks64"], c["train_peaks32"], "training")
+
+
+@pytest.mark.parametrize("math", ["fp32"])
+def test_strict_fp32_mfma_has_the_same_error(gpu_device, monkeypatch, math):
+    """The default path runs its contractions as bf16x3 split products; with f32-input MFMA only
+    (NG_EDGE_MATH / NG_GEMM_MATH = fp32) the error against the reference graph is of the same size,
+    i.e. the remaining distance is float32 arithmetic, not the split."""
+    c = load_savedmodel_case("pdb108m")
+    eng, gb = _engine(gpu_device, c)
+    base = eng.forward(gb, training=False).cpu().numpy().astype(np.float64)
+    monkeypatch.setenv("NG_EDGE_MATH", math)
+    monkeypatch.setenv("NG_GEMM_MATH", math)
+    strict = eng.forward(gb, training=False).cpu().numpy().astype(np.float64)
+    e_def = np.abs(base - c["peaks64"]).max()
+    e_strict = np.abs(strict - c["peaks64"]).max()
+    print(f"[pdb108m] default (split bf16x3) max err {e_def:.3e}; strict f32-MFMA max err {e_strict:.3e}")
+    assert e_def <= 4 * e_strict + 1e-5
