@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
-    from nmrgnn_amd import parallel, synth
+    from nmrgnn_amd import _lib, parallel, synth
     from nmrgnn_amd.engine import Engine
     from nmrgnn_amd.graph import GraphBatch
     from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
@@ -344,6 +344,7 @@ def main():
     if rank == 0 and world == 1 and os.environ.get("NG_EDGE_MATH", "") != "fp32":
         keep = os.environ.get("NG_EDGE_MATH")
         os.environ["NG_EDGE_MATH"] = "fp32"
+        _lib.reload_env()
         for _ in range(2):
             tr.step(gb, y, w)
         torch.cuda.synchronize()
@@ -358,6 +359,7 @@ def main():
             del os.environ["NG_EDGE_MATH"]
         else:
             os.environ["NG_EDGE_MATH"] = keep
+        _lib.reload_env()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -44,6 +44,9 @@ int ng_abi_version(void);
 int ng_ctx_create(int device, ng_ctx** out);
 void ng_ctx_destroy(ng_ctx* ctx);
 const char* ng_last_error(ng_ctx* ctx);
+/* The NG_* path switches (NG_EDGE_MATH, NG_GEMM_MATH, NG_MP_PATH, ... — listed in csrc/ng_common.h) are parsed from
+ * the environment once per process; ng_reload_env() parses them again (tests / A-B tools that flip one in-process). */
+int ng_reload_env(void);
 /* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
 int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ng_ctx_destroy": (None, [_vp]),
     "ng_last_error": (C.c_char_p, [_vp]),
     "ng_ctx_reserve": (_int, [_vp, _u64]),
+    "ng_reload_env": (_int, []),
     "ng_prof_enable": (_int, [_vp, _int]),
     "ng_prof_reset": (_int, [_vp]),
     "ng_prof_read": (_int, [_vp, _int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -97,6 +98,11 @@ def load():
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib
+
+
+def reload_env():
+    """make the library parse its NG_* path switches again (it reads them once per process)"""
+    load().ng_reload_env()
 
 
 class Context:

@@ -6,8 +6,37 @@
 
 namespace ng {
 
+static Switches g_sw;
+static bool g_sw_loaded = false;
+
+static bool env_is(const char* name, const char* value) {
+  const char* v = getenv(name);
+  return v && !strcmp(v, value);
+}
+
+static void load_switches() {
+  Switches s;
+  s.edge_math_fp32 = env_is("NG_EDGE_MATH", "fp32");
+  s.edge_bwd_math_fp32 = env_is("NG_EDGE_BWD_MATH", "fp32");
+  s.gemm_math_fp32 = env_is("NG_GEMM_MATH", "fp32");
+  s.edge_layered = env_is("NG_EDGE_PATH", "layered");
+  s.mp_layered = env_is("NG_MP_PATH", "layered");
+  s.fc_layered = env_is("NG_FC_PATH", "layered");
+  s.dense_generic = env_is("NG_DENSE_PATH", "generic");
+  s.head_generic = env_is("NG_HEAD_PATH", "generic");
+  s.knn_serial = env_is("NG_KNN", "serial");
+  g_sw = s;
+  g_sw_loaded = true;
+}
+
+const Switches& sw() {
+  if (!g_sw_loaded) load_switches();
+  return g_sw;
+}
+
 void* workspace(ng_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return ctx->ws;
+  DeviceGuard dg(ctx->device);     // the scratch belongs to the context's GPU, whatever device is current
   // grow (1.5x headroom); synchronises the device because older launches may still use the block
   size_t want = bytes + bytes / 2;
   if (ctx->ws) {
@@ -29,6 +58,7 @@ void* workspace(ng_ctx* ctx, size_t bytes) {
 
 void* aux_workspace(ng_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->aux_bytes) return ctx->aux;
+  DeviceGuard dg(ctx->device);
   const size_t want = bytes + bytes / 2;
   if (ctx->aux) {
     (void)hipDeviceSynchronize();
@@ -69,12 +99,18 @@ ProfScope::~ProfScope() {
 
 extern "C" int ng_abi_version(void) { return NG_ABI_VERSION; }
 
+extern "C" int ng_reload_env(void) {
+  ng::load_switches();
+  return NG_OK;
+}
+
 extern "C" int ng_ctx_create(int device, ng_ctx** out) {
   if (!out) return NG_ERR_INVALID;
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return NG_ERR_HIP;
-  if (hipSetDevice(device) != hipSuccess) return NG_ERR_HIP;
+  ng::DeviceGuard dg(device);      // the caller's current device is left as it was
+  (void)ng::sw();
   ng_ctx* ctx = new (std::nothrow) ng_ctx();
   if (!ctx) return NG_ERR_NOMEM;
   ctx->device = device;
@@ -86,6 +122,7 @@ extern "C" int ng_ctx_create(int device, ng_ctx** out) {
 
 extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   if (!ctx) return;
+  ng::DeviceGuard dg(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->aux) (void)hipFree(ctx->aux);
   for (auto& r : ctx->recs) {

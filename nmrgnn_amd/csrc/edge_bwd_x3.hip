@@ -474,8 +474,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
 bool edge_bwd_x3_supported(int E, int64_t n_edges) { return E >= 1 && E <= 4 && n_edges * FH * 4 < ((int64_t)1 << 32); }
 
 bool edge_tape_blocked(int E, int64_t n_edges) {
-  const char* xm = getenv("NG_EDGE_BWD_MATH");
-  return edge_x3_enabled() && !(xm && std::string(xm) == "fp32") && edge_bwd_x3_supported(E, n_edges);
+  return edge_x3_enabled() && !sw().edge_bwd_math_fp32 && edge_bwd_x3_supported(E, n_edges);
 }
 
 size_t edge_bwd_x3_ws_bytes() { return (size_t)2 * 4 * 8 * 3 * 1024; }

@@ -32,21 +32,6 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   } while (0)
 
 namespace ng {
-// one-wave-per-SIMD backward kernel (edge_fused_bwd2.hip); partial layout as in edge_fused_bwd.hip
-int edge_fused_bwd2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
-                           const float* d_eff, const float* centers, float gap, const float* WpkT,
-                           const float* Wo, const float* z_save, const float* de, float* partial,
-                           int part_stride, int grid);
-}  // namespace ng
-
-namespace ng {
-// 32-edge-tile forward variant (edge_fused_fwd32.hip)
-int edge_fused_fwd32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
-                     const float* d_eff, const float* centers, float gap, const float* const* W,
-                     const float* const* b, float* e_out, float* z_save);
-}  // namespace ng
-
-namespace ng {
 // forward on the bf16 matrix pipe with three-way operand splitting (edge_fwd_x3.hip); NG_EDGE_MATH=bf16x3
 bool edge_x3_enabled();
 int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,

@@ -299,9 +299,6 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* const* b, float* e_out, float* z_save) {
   if (edge_x3_enabled()) return edge_x3_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
-  const char* v0 = getenv("NG_EDGE_FWD");   // "tm32": 32-edge tiles, 4 workgroups / CU (edge_fused_fwd32.hip)
-  if (v0 && std::string(v0) == "tm32")
-    return edge_fused_fwd32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
   float* Wpk = (float*)workspace(ctx, (pk_floats + FH) * 4);
@@ -316,17 +313,13 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.Wo = W[3]; a.bo = b[3];
   a.e_out = e_out; a.z_save = z_save; a.dummy = Wpk + pk_floats;
-  // default: 64-edge tiles, two 256-thread workgroups per CU (1.83 ms).  NG_EDGE_FWD=tm128: 128-edge tiles, one
-  // 512-thread workgroup per CU with both waves of a SIMD in the same phase (1.85 ms: no gain measured)
-  const bool tm64 = !(v0 && std::string(v0) == "tm128");
-  const int TMr = tm64 ? 64 : 128;
+  // 64-edge tiles, two 256-thread workgroups per CU
+  const int TMr = 64;
   const int64_t ntiles = cdiv(n_edges, TMr);
-  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * (tm64 ? 2 : 1));
+  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * 2);
   const size_t lds = (size_t)(2 * TMr * FLD + FH * FMAX_E + TMr + 4 * FH) * 4;
   ProfScope ps(ctx, st, "edge_fused_fwd");
-#define NG_FW1(EE, SV)                                                                              \
-  if (tm64) hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, SV, 64>), dim3(grid), dim3(256), lds, st, a); \
-  else hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, SV, 128>), dim3(grid), dim3(512), lds, st, a);
+#define NG_FW1(EE, SV) hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, SV, 64>), dim3(grid), dim3(256), lds, st, a);
 #define NG_FW(EE)                                                                                  \
   case EE:                                                                                         \
     if (z_save) { NG_FW1(EE, true) } else { NG_FW1(EE, false) }                                    \

@@ -384,9 +384,6 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.WpkT = WpkT; a.Wo = W[3]; a.z_save = z_save; a.de = de;
   a.partial = partial; a.part_stride = stride;
   const size_t lds = (size_t)(3 * FTM * FLD + FH * FMAX_E + FTM * FMAX_E + 2 * FTM + FH) * 4;
-  // NG_EDGE_BWD=v2 selects the one-wave-per-SIMD variant (edge_fused_bwd2.hip: no spills, 4 barriers per
-  // tile, but 56 % vs 62 % of the MFMA peak at the bench shape); default is the 8-wave kernel in this file
-  const char* ver = getenv("NG_EDGE_BWD");
   // default: split-operand kernel on the bf16 matrix pipe (edge_bwd_x3.hip); NG_EDGE_MATH=fp32 (both directions) or
   // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
   // tape_layout: what the forward that wrote z_save reported (ng_edge_tape_layout), -1 = decide as the forward would
@@ -397,10 +394,6 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
     int rc3 = edge_bwd_x3_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
                                  (char*)(partial + (size_t)grid * stride), partial, stride, grid, blocked ? 1 : 0);
     if (rc3) return rc3;
-  } else if (ver && std::string(ver) == "v2") {
-    int rc2 = edge_fused_bwd2_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, WpkT, W[3], z_save,
-                                     de, partial, stride, grid);
-    if (rc2) return rc2;
   } else {
     ProfScope ps(ctx, st, "edge_fused_bwd");
 #define NG_BW(EE)                                                                                   \

@@ -353,8 +353,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_x3_kernel(EdgeX3Args a) {
 
 // default for the edge forward; NG_EDGE_MATH=fp32 selects the f32-input MFMA kernels of edge_fused.hip
 bool edge_x3_enabled() {
-  const char* v = getenv("NG_EDGE_MATH");
-  return !(v && std::string(v) == "fp32");
+  return !sw().edge_math_fp32;
 }
 
 int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,

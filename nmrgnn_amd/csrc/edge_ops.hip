@@ -290,8 +290,7 @@ int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
 
 // NG_EDGE_PATH=layered forces the one-launch-per-layer path (A/B measurements, tests)
 static bool force_layered() {
-  const char* v = getenv("NG_EDGE_PATH");
-  return v && std::string(v) == "layered";
+  return sw().edge_layered;
 }
 
 }  // namespace ng

@@ -443,8 +443,7 @@ __global__ __launch_bounds__(512, 1) void fc_bwd_kernel(FcBwdArgs a) {
 }  // namespace
 
 bool fc_fused_supported(int F, int L) {
-  const char* v = getenv("NG_FC_PATH");
-  if (v && std::string(v) == "layered") return false;
+  if (sw().fc_layered) return false;
   return F == FC_F && L >= 2 && L <= FC_MAXL;
 }
 

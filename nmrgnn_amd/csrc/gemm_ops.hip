@@ -238,8 +238,7 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
 namespace ng {
 // shapes the register-resident tall-skinny kernels cover (tall_gemm.hip); NG_DENSE_PATH=generic disables
 bool tall_dense_ok(int k_in, int n_out) {
-  const char* v = getenv("NG_DENSE_PATH");
-  if (v && std::string(v) == "generic") return false;
+  if (sw().dense_generic) return false;
   if (k_in % 4 || n_out % 4 || k_in > 192 || n_out > 192) return false;
   const int kpad = (k_in + 63) / 64 * 64, npad = (n_out + 63) / 64 * 64;
   return tall_gemm_supported(kpad, npad);

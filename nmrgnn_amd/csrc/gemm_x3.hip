@@ -206,8 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
 }
 
 bool gemm_x3_fwd_ok(int64_t M, int K, int N) {
-  const char* v = getenv("NG_GEMM_MATH");
-  if (v && std::string(v) == "fp32") return false;
+  if (sw().gemm_math_fp32) return false;
   return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && M >= 4096 && (int64_t)N * K * 6 < ((int64_t)1 << 31);
 }
 
@@ -387,8 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
 }
 
 bool gemm_x3_dw_ok(int64_t M, int Kin, int Nout) {
-  const char* v = getenv("NG_GEMM_MATH");
-  if (v && std::string(v) == "fp32") return false;
+  if (sw().gemm_math_fp32) return false;
   return Kin % 128 == 0 && Nout % 128 == 0 && M >= 4096;
 }
 

@@ -176,8 +176,7 @@ __global__ __launch_bounds__(256) void embed_bwd_fast_kernel(int64_t N, int C, i
 
 // ---- host side --------------------------------------------------------------------------------------------
 static bool fast_enabled() {
-  const char* v = getenv("NG_HEAD_PATH");
-  return !(v && std::string(v) == "generic");
+  return !sw().head_generic;
 }
 
 bool head_fast_supported(int Fh, int C) {

@@ -181,8 +181,7 @@ extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, floa
   if (G == 0 || n == 0) return NG_OK;
   ProfScope ps(ctx, st, "knn_graph");
   const dim3 grid((unsigned)cdiv(n, 256), (unsigned)G), block(256);
-  const char* one = getenv("NG_KNN");      // NG_KNN=serial: one lane per query (the first kernel)
-  if (K <= 16 && !(one && std::string(one) == "serial"))
+  if (K <= 16 && !sw().knn_serial)      // NG_KNN=serial: one lane per query (the first kernel)
     hipLaunchKernelGGL(knn_kernel_s8<16>, dim3((unsigned)cdiv(n, 32), (unsigned)G), block, 0, st, n, K, scale, pos, nlist,
                        edges, inv_degree);
   else if (K <= 16)

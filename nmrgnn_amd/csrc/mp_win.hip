@@ -533,9 +533,7 @@ bool mp_win_supported(int F, int E, int K) {
 }
 
 bool mp_win_enabled(int F, int E, int K) {
-  if (!mp_win_supported(F, E, K)) return false;
-  const char* s = getenv("NG_MP_PATH");
-  return !s || !strcmp(s, "win");      // default forward path for F == 64 (NG_MP_PATH=split|fused|layered opt out)
+  return mp_win_supported(F, E, K) && !sw().mp_layered;      // default forward path for F == 64
 }
 
 int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,

@@ -678,4 +678,37 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
   return NG_OK;
 }
 
+// MPLayer backward for atom_feature_size == 64 on the window-resident kernels:
+//   edge kernel   dP = dH * act'(S) * v ;  dA = dP Wp^T (LDS) ;  de (+)= <dA, h[nlist]>
+//   node kernel   B = incoming-edge aggregate of dP (records) ;  dh = dH + B Wn ;  dw = h^T B
+bool mp_win_bwd_enabled(int F, int E, int K) { return mp_win_bwd_supported(F, E, K) && !sw().mp_layered; }
+
+int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h, const int32_t* nlist,
+               const float* e, const float* inv_degree, const float* w, const float* s_save, const int32_t* csc_ptr,
+               const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum, float* dw,
+               const float* csc_rec) {
+  const int KF = E * WF;
+  const size_t dw_scr = mp_win_node_scratch_floats(ctx, E);
+  // scratch: two packed weight images | dP [N,64] | records [N*K,4] (when the caller has none) | dw partials
+  const size_t rec_floats = csc_rec ? 0 : (size_t)N * K * 4;
+  float* ws = (float*)workspace(ctx, (size_t)(2 * KF * WF + N * WF + rec_floats + dw_scr + 64) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* WfragT = ws;
+  float* WfragN = WfragT + KF * WF;
+  float* dP = WfragN + KF * WF;
+  float* rec = dP + N * WF;
+  float* scr = rec + rec_floats;
+  float* dummy = scr + dw_scr;
+  int rc = mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // both weight images in one launch
+  if (rc) return rc;
+  rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum, dummy);
+  if (rc) return rc;
+  if (!csc_rec) {
+    rc = mp_win_records(ctx, st, N, K, E, csc_ptr, csc_edge, e, rec);
+    if (rc) return rc;
+    csc_rec = rec;
+  }
+  return mp_win_bwd_node(ctx, st, N, E, h, dP, csc_ptr, csc_rec, WfragN, dh_out, dh_in, dw, scr, dummy);
+}
+
 }  // namespace ng

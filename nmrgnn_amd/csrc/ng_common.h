@@ -33,6 +33,36 @@ struct ng_ctx {
 
 namespace ng {
 
+// Process-wide path switches, parsed from the environment ONCE (first use) instead of a getenv + string compare
+// on every launch; ng_reload_env() re-reads them (tests and A/B tools flip variables inside one process).
+//   NG_EDGE_MATH=fp32      edge MLP forward+backward on f32-input MFMA (default: bf16 x3 split operands)
+//   NG_EDGE_BWD_MATH=fp32  only the edge backward on f32-input MFMA
+//   NG_GEMM_MATH=fp32      generic GEMMs on f32-input MFMA (default: split operands where the shape allows)
+//   NG_EDGE_PATH=layered   one launch per edge-MLP layer (any H / Le)
+//   NG_MP_PATH=layered     aggregate -> A[N,E*F] -> GEMM for every width (default: window kernels at F == 64)
+//   NG_FC_PATH=layered     one launch per FC layer
+//   NG_DENSE_PATH=generic  no register-resident tall-skinny kernels
+//   NG_HEAD_PATH=generic   the first head / embedding-gradient kernels
+//   NG_KNN=serial          one lane per query atom in the kNN graph kernel
+struct Switches {
+  bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
+  bool edge_layered = false, mp_layered = false, fc_layered = false;
+  bool dense_generic = false, head_generic = false, knn_serial = false;
+};
+const Switches& sw();
+
+// hipSetDevice(dev) for the lifetime of the object, previous device restored afterwards
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 inline int fail(ng_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   return code;

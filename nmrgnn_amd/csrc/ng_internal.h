@@ -41,20 +41,6 @@ int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float
 }  // namespace ng
 
 namespace ng {
-// fused MPLayer kernels (mp_fused.hip): atom_feature_size == 64, edge_feature_size <= 3
-bool mp_fused_enabled(int F, int E);
-int mp_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,
-                 const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
-                 const float* w, float* h_out, float* A_save, float* s_save);
-int mp_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
-                 const int32_t* nlist, const float* e, const float* inv_degree, const float* w,
-                 const float* A_save, const float* s_save, const int32_t* csc_ptr,
-                 const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
-                 float* dw);
-
-// MPLayer weight fragment packing (mp_fused.hip): mode 0 forward Wp, 1 back-to-nodes Wq, 2 dA = dP Wp^T
-int mp_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out);
-
 // tall-skinny dense products with register-resident weights (tall_gemm.hip)
 struct TallArgs {
   int64_t N;
@@ -108,23 +94,13 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
                     float* dh_in, float* dw, float* scratch, float* dummy);
 
-// split MPLayer path for atom_feature_size == 64 (mp_split.hip): XCD-aware gather kernels + tall GEMMs
-bool mp_split_enabled(int F, int E);
-int mp_split_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual,
-                 const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
-                 const float* w, float* h_out, float* A_save, float* s_save);
-int mp_split_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
-                 const int32_t* nlist, const float* e, const float* inv_degree, const float* w,
-                 const float* A_save, const float* s_save, const int32_t* csc_ptr,
-                 const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum,
-                 float* dw, const float* csc_rec = nullptr);
+// window-resident MPLayer backward, both kernels (mp_win_bwd.hip)
+bool mp_win_bwd_enabled(int F, int E, int K);
+int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h, const int32_t* nlist,
+               const float* e, const float* inv_degree, const float* w, const float* s_save, const int32_t* csc_ptr,
+               const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de, int de_accum, float* dw,
+               const float* csc_rec);
 
-// LDS-window neighbour aggregation (mp_window.hip)
-bool aggregate_window_supported(int F, int E);
-int aggregate_window(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* src,
-                     const int32_t* nlist, const float* e, float* A);
-int aggregate_window_csc(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* src,
-                         const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, float* B);
 // bandwidth-shaped head / embedding kernels (head_ops.hip); NG_HEAD_PATH=generic selects the old ones
 bool head_fast_supported(int Fh, int C);
 bool head_fwd_fast_supported(int Fh, int C);

@@ -148,14 +148,6 @@ static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
              "aggregate: F in {16,32,64,128,256,512,1024}");
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "aggregate: edge_feature_size <= 8");
   if (N == 0) return NG_OK;
-  {
-    // NG_AGG_PATH=window selects the LDS-window kernel of mp_window.hip.  Measured at the bench shape it
-    // LOSES to the XCD-aware global-gather kernel below (87 us vs 36 us): with the tiles of a molecule on
-    // one XCD the gathered rows are L2 hits anyway, and the high-occupancy kernel hides their latency.
-    const char* v = getenv("NG_AGG_PATH");
-    if (v && std::string(v) == "window" && aggregate_window_supported(F, E))
-      return aggregate_window(ctx, st, N, K, F, E, h, nlist, e, A);
-  }
   ProfScope ps(ctx, st, "mp_aggregate");
   const int apb = 256 / (F / 4);
   const size_t lds = (size_t)apb * K * (1 + E) * 4;
@@ -670,7 +662,7 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   if (!ctx) return NG_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, (E * F) % 8 == 0, "mp_layer: (E*F) % 8");
-  // F == 64: NG_MP_PATH = split (default) | fused | layered  — see mp_split.hip for the comparison
+  // F == 64: window-resident kernel (mp_win.hip); NG_MP_PATH=layered opts out
   if (N > 0 && mp_win_enabled(F, E, K)) {
     // the window kernel never materialises the aggregate; a caller that asks for it gets a separate pass
     if (A_save) {
@@ -679,12 +671,6 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
     }
     return mp_win_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, s_save);
   }
-  if (N > 0 && mp_split_enabled(F, E))
-    return mp_split_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, A_save,
-                        s_save);
-  if (N > 0 && mp_fused_enabled(F, E))
-    return mp_fused_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, A_save,
-                        s_save);
   const int64_t KF = (int64_t)E * F;
   // scratch: Wp [KF*F] (+ A [N*KF] when the caller does not keep it)
   const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;
@@ -703,8 +689,7 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
 }
 
 extern "C" int ng_mp_layer_wants_aggregate(int F, int E, int K) {
-  (void)K;
-  if (mp_split_enabled(F, E)) return 0;      // dw comes from h^T B (incoming-edge aggregate of dP)
+  if (mp_win_bwd_enabled(F, E, K)) return 0;      // dw comes from h^T B (incoming-edge aggregate of dP)
   return 1;
 }
 
@@ -744,14 +729,9 @@ extern "C" int ng_mp_layer_bwd_rec(ng_ctx* ctx, void* stream, int64_t N, int K, 
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
              "mp_layer_bwd: F in {16,32,64,128,256}");
   NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "mp_layer_bwd: edge_feature_size <= 8");
-  if (N > 0 && mp_split_enabled(F, E))
-    return mp_split_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
-                        csc_edge, dh_out, dh_in, de, de_accum, dw, csc_rec);
-  if (N > 0 && mp_fused_enabled(F, E)) {
-    NG_REQUIRE(ctx, A_save, "mp_layer_bwd: the fused path needs the aggregate saved by the forward pass");
-    return mp_fused_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, A_save, s_save, csc_ptr,
-                        csc_edge, dh_out, dh_in, de, de_accum, dw);
-  }
+  if (N > 0 && mp_win_bwd_enabled(F, E, K))
+    return mp_win_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, s_save, csc_ptr, csc_edge, dh_out, dh_in, de,
+                      de_accum, dw, csc_rec);
   const int64_t KF = (int64_t)E * F;
   const float* S = s_save;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);

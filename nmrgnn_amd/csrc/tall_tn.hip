@@ -141,8 +141,7 @@ __global__ __launch_bounds__(256, 2) void tall_tn_kernel(TnArgs a) {
 }
 
 bool tall_tn_supported(int ka, int kb) {
-  const char* v = getenv("NG_DENSE_PATH");
-  if (v && std::string(v) == "generic") return false;
+  if (sw().dense_generic) return false;
   const int kap = (ka + 63) / 64 * 64;
   return ka % 4 == 0 && kb % 4 == 0 && kb <= 64 && (kap == 64 || kap == 128 || kap == 192);
 }

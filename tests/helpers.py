@@ -91,3 +91,60 @@ def load_savedmodel_case(tag):
                 peaks64=z[f"{tag}:peaks64"], peaks32=z[f"{tag}:peaks32"], e64=z[f"{tag}:e64"],
                 h_mp64_rows16=z[f"{tag}:h_mp64_rows16"], train_xi=z[f"{tag}:train_xi"], train_keep=keep,
                 train_peaks64=z[f"{tag}:train_peaks64"], train_peaks32=z[f"{tag}:train_peaks32"])
+
+
+# ---- full-batch oracle gradients, graph by graph (graphs are independent, so the batch gradient is the
+#      sum of the per-graph gradients; each worker runs the float64 oracle on its share of graphs) ----
+def _oracle_chunk(args):
+    import os
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import nmrgnn_oracle as O
+    (atoms, nlist, edges, inv, ptr, g0, g1, sd, ohp, dpe, std, avg, xi, mask) = args
+    peaks = []
+    total = None
+    for g in range(g0, g1):
+        a, b = int(ptr[g]), int(ptr[g + 1])
+        pk, gr = O.gnn_forward_backward(
+            (atoms[a:b], nlist[a:b] - a, edges[a:b], inv[a:b]), sd, ohp, dpe[a:b], std, avg,
+            training=xi is not None, noise=None if xi is None else xi[a:b],
+            dropout_mask=None if mask is None else mask[a:b])
+        peaks.append(pk)
+        if total is None:
+            total = {k: np.array(v, np.float64) for k, v in gr.items()}
+        else:
+            for k, v in gr.items():
+                total[k] += v
+    return g0, np.concatenate(peaks), total
+
+
+def oracle_batch_forward_backward(b, sd, ohp, dpeaks, std=None, avg=None, xi=None, mask=None, workers=None):
+    """(peaks[N], {name: gradient}) of the float64 oracle over EVERY graph of batch dict ``b`` (needs
+    graph_ptr; nlist holds global indices).  Spawned worker processes (no fork: the parent may hold a
+    HIP context)."""
+    import multiprocessing as mp
+    import os
+    ptr = np.asarray(b["graph_ptr"], np.int64)
+    G = len(ptr) - 1
+    if workers is None:
+        workers = max(1, min(32, (os.cpu_count() or 1) // 2, G))
+    per = -(-G // (workers * 4))
+    jobs = []
+    for g0 in range(0, G, per):
+        g1 = min(G, g0 + per)
+        a, z = int(ptr[g0]), int(ptr[g1])
+        sub_ptr = ptr[g0:g1 + 1] - a
+        jobs.append((b["atoms"][a:z], np.asarray(b["nlist"][a:z], np.int64) - a, b["edges"][a:z],
+                     b["inv_degree"][a:z], sub_ptr, 0, g1 - g0, sd, ohp, np.asarray(dpeaks)[a:z], std, avg,
+                     None if xi is None else xi[a:z], None if mask is None else mask[a:z]))
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_oracle_chunk, jobs)
+    peaks = np.concatenate([r[1] for r in res])
+    total = None
+    for _, _, gr in res:
+        if total is None:
+            total = {k: v.copy() for k, v in gr.items()}
+        else:
+            for k, v in gr.items():
+                total[k] += v
+    return peaks, total

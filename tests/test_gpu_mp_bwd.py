@@ -44,14 +44,14 @@ def make_case(kind, N, K, E, rng):
 
 @pytest.mark.parametrize("kind,N,K,E,act", [("local", 1000, 16, 3, 1), ("hub", 1500, 16, 3, 1), ("wide", 700, 16, 3, 1),
                                             ("local", 333, 8, 2, 0), ("hub", 300, 16, 1, 1), ("local", 31, 16, 3, 1)])
-@pytest.mark.parametrize("path", ["default", "split"])
+@pytest.mark.parametrize("path", ["default", "layered"])
 def test_mp_layer_bwd_vs_numpy(gpu_device, monkeypatch, path, kind, N, K, E, act):
     import torch
     from nmrgnn_amd import _lib
     from nmrgnn_amd._lib import ptr
     from nmrgnn_amd.graph import GraphBatch
-    if path == "split":
-        monkeypatch.setenv("NG_MP_BWD", "split")
+    if path == "layered":
+        monkeypatch.setenv("NG_MP_PATH", "layered")
     rng = np.random.default_rng(N + 7 * K + E)
     F = 64
     nl, e = make_case(kind, N, K, E, rng)

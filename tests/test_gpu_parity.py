@@ -236,6 +236,42 @@ def test_full_size_fused_equals_layered_and_batch_invariance(gpu_device, monkeyp
         assert np.max(np.abs(part - ref)) < PEAK_ATOL
 
 
+def test_full_size_gradients_match_oracle(gpu_device):
+    """BASELINE configs[2] at its full size (512 x 256 atoms, F=64): peaks AND every gradient tensor of
+    the fused training step against the float64 oracle run over ALL 512 graphs (graphs are independent,
+    so the batch gradient is the sum of per-graph oracle gradients; tests/helpers.py runs them in worker
+    processes), with the GPU's own noise / dropout draws fed to the oracle."""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from helpers import oracle_batch_forward_backward
+    hp = make_hp(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
+    b = synth.make_batch(512, 256, 16, 10, 0.05, seed=42)
+    eng = Engine(hp, 10, device=gpu_device, seed=1234)
+    sd = randomize_biases(eng, scale=0.05)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"],
+                    device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=7)
+    mask = eng.dropout_mask(N * 32, seed=8)
+    # the loss gradient of the bench step: NameLoss s=1 on the batch's labels (1/G per graph)
+    peaks = eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
+    loss, dpe = eng.loss_l2(gb, torch.from_numpy(b["y"]).to(gpu_device), torch.from_numpy(b["w"]).to(gpu_device),
+                            peaks)
+    eng.backward(dpe)
+    pk = peaks.cpu().numpy()
+    grads = eng.params.grads_dict()
+    ref_pk, ref_g = oracle_batch_forward_backward(
+        b, sd, hp_to_oracle(hp), dpe.cpu().numpy().astype(np.float64),
+        xi=xi.cpu().numpy().reshape(N, K).astype(np.float64),
+        mask=(mask.cpu().numpy().reshape(N, 32) > 0).astype(np.float64), workers=16)
+    assert np.max(np.abs(pk - ref_pk)) < PEAK_ATOL
+    errs = {k: rel_err(grads[k], g) for k, g in ref_g.items()}
+    print("full-size gradient rel. errors:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < GRAD_RTOL, errs
+
+
 def test_empty_and_tiny_graphs(gpu_device):
     from nmrgnn_amd.engine import Engine
     from nmrgnn_amd.graph import GraphBatch
