@@ -152,6 +152,36 @@ int ng_mp_layer_bwd_rec(ng_ctx*, void* stream, int64_t N, int K, int F, int E, i
                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out,
                     float* dh_in, float* de, int de_accum, float* dw, const float* csc_rec);
 
+/* ---- CSR (variable-degree) form of the neighbour lists, SURVEY 8(b) ------------------------------------------
+ * The reference's padded [N,K] tuple (nmrgnn/library.py:106-117) with the edges == 0 slots dropped — they contribute
+ * exactly 0 through the edge mask (nmrgnn/model.py:251,261):
+ *   row_ptr [N+1]  row i owns the entries p in [row_ptr[i], row_ptr[i+1])
+ *   col     [nnz]  neighbour atom (batch-global index)          dist [nnz] distance
+ * The edge path runs on the flat list: ng_edge_mlp_fwd(n_edges = nnz, d_src = dist, ...) -> e [nnz,E].
+ * Same contract as ng_mp_aggregate / ng_mp_layer_fwd / ng_mp_layer_bwd (layers.py:26-46, model.py:165-167); on lists
+ * that differ only by dropped zero-weight slots the results equal the padded generic path (NG_MP_PATH=layered) bit for
+ * bit.  row_of [nnz] = row of entry p;  csc_ptr [N+1] / csc_edge [nnz] = entries grouped by col (ascending p inside a
+ * group), the incoming-edge lists of the deterministic backward scatter. */
+int ng_mp_aggregate_csr(ng_ctx*, void* stream, int64_t N, int F, int E, const float* h,
+                        const int32_t* row_ptr, const int32_t* col, const float* e, float* A);
+int ng_mp_layer_fwd_csr(ng_ctx*, void* stream, int64_t N, int64_t nnz, int F, int E, int act, int residual,
+                        const float* h, const int32_t* row_ptr, const int32_t* col, const float* e,
+                        const float* inv_degree, const float* w, float* h_out, float* A_save, float* s_save);
+int ng_mp_layer_bwd_csr(ng_ctx*, void* stream, int64_t N, int64_t nnz, int F, int E, int act, const float* h,
+                        const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
+                        const float* inv_degree, const float* w, const float* A_save, const float* s_save,
+                        const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in,
+                        float* de, int de_accum, float* dw);
+
+/* Distance-cutoff graph builder (BASELINE configs[4], "variable degree"; the counterpart of ng_knn_graph for the CSR
+ * form, in front of nmrgnn/library.py:106-117): every OTHER atom of the same frame closer than `cutoff` (Angstrom).
+ *   ng_cutoff_count: deg [G*n] neighbours per atom  ->  the caller's exclusive prefix sum is row_ptr [G*n+1]
+ *   ng_cutoff_fill : col [nnz] batch-global (frame*n + j), ascending j inside a row; dist [nnz] = distance*scale;
+ *                    inv_degree [G*n] = 1/#(local neighbour index > 0), 0 when none (library.py:115-116) */
+int ng_cutoff_count(ng_ctx*, void* stream, int G, int n, float cutoff, const float* pos, int32_t* deg);
+int ng_cutoff_fill(ng_ctx*, void* stream, int G, int n, float cutoff, float scale, const float* pos,
+                   const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree);
+
 /* ---- graph front end: K nearest neighbours per atom, per frame --------------------------------
  * Replaces the neighbour search behind nmrgnn.universe2graph (nmrgnn/library.py:106-117, external
  * nmrdata.parse_universe) and the per-frame graph construction of eval-struct (main.py:236-243).

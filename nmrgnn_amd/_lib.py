@@ -55,6 +55,13 @@ SIGNATURES = {
     "ng_mp_layer_bwd_rec": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp]),
     "ng_mp_edge_records": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "ng_mp_aggregate_csr": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "ng_mp_layer_fwd_csr": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp]),
+    "ng_mp_layer_bwd_csr": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "ng_cutoff_count": (_int, [_vp, _vp, _int, _int, _f, _vp, _vp]),
+    "ng_cutoff_fill": (_int, [_vp, _vp, _int, _int, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ng_dense_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ng_dense_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp]),

@@ -1,0 +1,388 @@
+// MPLayer over CSR (variable-degree) neighbour lists, and the distance-cutoff graph builder that produces them.
+//
+// The reference feeds padded [N,K] lists (nmrgnn/library.py:106-117) whose padded slots carry edges == 0 and, through
+// the edge mask (nmrgnn/model.py:251,261), contribute exactly 0 to the contraction of nmrgnn/layers.py:39-40.  Dropping
+// them gives the CSR form of SURVEY §8(b):  row i owns the entries p in [row_ptr[i], row_ptr[i+1]),  col[p] = neighbour
+// atom,  dist[p] = distance;  edge features e[nnz][E] come from ng_edge_mlp_fwd on the flat dist array.
+//
+//   forward    A[i][n][:]  = sum_{p in row i} e[p][n] * h[col[p]][:]           (gather, this file)
+//              h'          = act(v * A Wp) (+ h)                               (GEMM, gemm_ops / gemm_x3)
+//   backward   dP = dH*act'(S)*v ; dw = A^T dP ; dA = dP Wp^T                  (GEMMs)
+//              de[p][n]   (+)= <dA[row(p)][n][:], h[col[p]][:]>                (gather-dot, this file)
+//              dh[t][:]    = dH[t][:] + sum_{q in csc[t]} sum_n e[p_q][n] dA[row(p_q)][n][:]   (pull scatter, this file)
+//
+// The kernels take the row extent either from row_ptr or, when row_ptr == nullptr, as the fixed stride K (row i =
+// [i*K, (i+1)*K)): the padded layout is the special case, which is also how edge_feature_size > 8 is served for
+// padded lists.  Edge features are processed in chunks of at most 8 (EC) so that edge_feature_size = 64
+// (nmrgnn/model.py:23) runs through the same code.  Summation order inside a row is the entry order, so on lists that
+// differ only by dropped zero-weight slots the CSR and the padded generic paths agree bit for bit.
+#include <algorithm>
+
+#include "mfma_gemm.cuh"
+#include "ng_internal.h"
+
+namespace ng {
+
+namespace {
+
+struct RowRange {
+  const int32_t* row_ptr;   // [N+1] or nullptr
+  int K;                    // fixed stride when row_ptr == nullptr
+  __device__ __forceinline__ void get(int64_t i, int64_t& p0, int64_t& p1) const {
+    if (row_ptr) { p0 = row_ptr[i]; p1 = row_ptr[i + 1]; }
+    else { p0 = i * K; p1 = p0 + K; }
+  }
+};
+
+// A[i][n0+n][:] = sum_p e[p][n0+n] * h[col[p]][:]     F/4 lanes per atom, 8 row gathers in flight per lane
+template <int EC>
+__global__ __launch_bounds__(256) void csr_aggregate_kernel(int64_t N, int F, int E, int n0, RowRange rr,
+                                                            const float* __restrict__ h,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ e, float* __restrict__ A) {
+  const int c4n = F / 4;
+  const int apb = 256 / c4n;
+  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
+  const int64_t i = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;   // contiguous atom ranges per XCD (one L2)
+  if (i >= N) return;
+  int64_t p0, p1;
+  rr.get(i, p0, p1);
+  float4 acc[EC];
+#pragma unroll
+  for (int n = 0; n < EC; ++n) acc[n] = f4zero();
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  for (int64_t q0 = p0; q0 < p1; q0 += 8) {
+    float4 hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t p = q0 + u < p1 ? q0 + u : p1 - 1;
+      hv[u] = h4[(int64_t)col[p] * c4n + c4];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (q0 + u < p1) {
+        const float* ep = e + (q0 + u) * E + n0;
+#pragma unroll
+        for (int n = 0; n < EC; ++n) {
+          const float ev = ep[n];
+          acc[n].x += ev * hv[u].x; acc[n].y += ev * hv[u].y;
+          acc[n].z += ev * hv[u].z; acc[n].w += ev * hv[u].w;
+        }
+      }
+    }
+  }
+  float4* A4 = reinterpret_cast<float4*>(A);
+#pragma unroll
+  for (int n = 0; n < EC; ++n) A4[(i * E + n0 + n) * c4n + c4] = acc[n];
+}
+
+// de[p][n0+n] (+)= sum_l dA[i][n0+n][l] * h[col[p]][l]   for the entries p of row i
+template <int EC>
+__global__ __launch_bounds__(256) void csr_edge_grad_kernel(int64_t N, int F, int E, int n0, RowRange rr,
+                                                            const float* __restrict__ h,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ dA, float* __restrict__ de,
+                                                            int accumulate) {
+  const int c4n = F / 4;   // power of two <= 64: the lanes of an atom sit inside one wave
+  const int apb = 256 / c4n;
+  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
+  const int64_t i = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;
+  const bool live = i < N;
+  const int64_t ii = live ? i : 0;
+  int64_t p0, p1;
+  rr.get(ii, p0, p1);
+  if (!live) p1 = p0;
+  // every lane of a wave must take part in the shuffles: iterate to the longest row of the wave's atoms
+  int len = (int)(p1 - p0), maxlen = len;
+  for (int off = 32; off >= c4n; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  float4 g[EC];
+#pragma unroll
+  for (int n = 0; n < EC; ++n) g[n] = dA4[(ii * E + n0 + n) * c4n + c4];
+  for (int j = 0; j < maxlen; ++j) {
+    const bool has = j < len;
+    const int64_t p = has ? p0 + j : (len > 0 ? p0 : 0);
+    const float4 hv = (has || len > 0) ? h4[(int64_t)col[p] * c4n + c4] : f4zero();
+    float part[EC];
+#pragma unroll
+    for (int n = 0; n < EC; ++n) part[n] = g[n].x * hv.x + g[n].y * hv.y + g[n].z * hv.z + g[n].w * hv.w;
+    for (int off = c4n >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int n = 0; n < EC; ++n) part[n] += __shfl_xor(part[n], off, 64);
+    }
+    if (has && c4 == 0) {
+#pragma unroll
+      for (int n = 0; n < EC; ++n) {
+        const int64_t o = p * E + n0 + n;
+        de[o] = accumulate ? de[o] + part[n] : part[n];
+      }
+    }
+  }
+}
+
+// dh_in[t][:] = base + sum_{q in csc[t]} sum_n e[eid][n0+n] * dA[row(eid)][n0+n][:]
+//   base = dh_out[t] for the first feature chunk, dh_in[t] (running sum) for the following ones
+template <int EC>
+__global__ __launch_bounds__(256) void csr_scatter_pull_kernel(int64_t N, int F, int E, int n0, int K,
+                                                               const int32_t* __restrict__ row_of,
+                                                               const int32_t* __restrict__ csc_ptr,
+                                                               const int32_t* __restrict__ csc_edge,
+                                                               const float* __restrict__ e,
+                                                               const float* __restrict__ dA,
+                                                               const float* __restrict__ base,
+                                                               float* __restrict__ dh_in) {
+  const int c4n = F / 4;
+  const int apb = 256 / c4n;
+  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
+  const int64_t t = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;
+  if (t >= N) return;
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  float4 acc = reinterpret_cast<const float4*>(base)[t * c4n + c4];
+  const int q0 = csc_ptr[t], q1 = csc_ptr[t + 1];
+  for (int q = q0; q < q1; ++q) {
+    const int eid = csc_edge[q];
+    const int64_t src = row_of ? row_of[eid] : eid / K;
+    const float* ep = e + (int64_t)eid * E + n0;
+#pragma unroll
+    for (int n = 0; n < EC; ++n) {
+      const float ev = ep[n];
+      const float4 v = dA4[(src * E + n0 + n) * c4n + c4];
+      acc.x += ev * v.x; acc.y += ev * v.y; acc.z += ev * v.z; acc.w += ev * v.w;
+    }
+  }
+  reinterpret_cast<float4*>(dh_in)[t * c4n + c4] = acc;
+}
+
+#define NG_EC_SWITCH(EC, CALL)   \
+  switch (EC) {                  \
+    case 1: { CALL(1) } break;   \
+    case 2: { CALL(2) } break;   \
+    case 3: { CALL(3) } break;   \
+    case 4: { CALL(4) } break;   \
+    case 5: { CALL(5) } break;   \
+    case 6: { CALL(6) } break;   \
+    case 7: { CALL(7) } break;   \
+    default: { CALL(8) } break;  \
+  }
+
+bool csr_shape_ok(int F) { return F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0; }
+
+}  // namespace
+
+int csr_aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* row_ptr,
+                  const int32_t* col, const float* e, float* A) {
+  NG_REQUIRE(ctx, csr_shape_ok(F), "mp (csr): F in {16,32,64,128,256}");
+  NG_REQUIRE(ctx, E >= 1 && E <= 64, "mp (csr): edge_feature_size in [1,64]");
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, st, "mp_aggregate_csr");
+  const int apb = 256 / (F / 4);
+  const dim3 grid((unsigned)cdiv(N, apb));
+  const RowRange rr{row_ptr, K};
+  for (int n0 = 0; n0 < E; n0 += 8) {
+    const int ec = std::min(8, E - n0);
+#define CALL(EE) hipLaunchKernelGGL((csr_aggregate_kernel<EE>), grid, dim3(256), 0, st, N, F, E, n0, rr, h, col, e, A);
+    NG_EC_SWITCH(ec, CALL)
+#undef CALL
+  }
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+int csr_edge_grad(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* row_ptr,
+                  const int32_t* col, const float* dA, float* de, int accumulate) {
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, st, "mp_edge_grad_csr");
+  const int apb = 256 / (F / 4);
+  const dim3 grid((unsigned)cdiv(N, apb));
+  const RowRange rr{row_ptr, K};
+  for (int n0 = 0; n0 < E; n0 += 8) {
+    const int ec = std::min(8, E - n0);
+#define CALL(EE) \
+  hipLaunchKernelGGL((csr_edge_grad_kernel<EE>), grid, dim3(256), 0, st, N, F, E, n0, rr, h, col, dA, de, accumulate);
+    NG_EC_SWITCH(ec, CALL)
+#undef CALL
+  }
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+int csr_scatter_pull(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const int32_t* row_of,
+                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, const float* dA,
+                     const float* dh_out, float* dh_in) {
+  if (N == 0) return NG_OK;
+  ProfScope ps(ctx, st, "mp_scatter_pull_csr");
+  const int apb = 256 / (F / 4);
+  const dim3 grid((unsigned)cdiv(N, apb));
+  for (int n0 = 0; n0 < E; n0 += 8) {
+    const int ec = std::min(8, E - n0);
+    const float* base = n0 == 0 ? dh_out : dh_in;
+#define CALL(EE)                                                                                              \
+  hipLaunchKernelGGL((csr_scatter_pull_kernel<EE>), grid, dim3(256), 0, st, N, F, E, n0, K, row_of, csc_ptr, \
+                     csc_edge, e, dA, base, dh_in);
+    NG_EC_SWITCH(ec, CALL)
+#undef CALL
+  }
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+// generic MPLayer forward over (row_ptr | K) lists: repack w, aggregate, GEMM with the epilogue of layers.py:42 + model.py:167
+int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, int residual, const float* h,
+                   const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
+                   float* h_out, float* A_save, float* s_save) {
+  const int64_t KF = (int64_t)E * F;
+  float* ws = (float*)workspace(ctx, (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* Wp = ws;
+  float* A = A_save ? A_save : ws + KF * F;
+  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  if (rc) return rc;
+  rc = csr_aggregate(ctx, st, N, K, F, E, h, row_ptr, col, e, A);
+  if (rc) return rc;
+  return dense_fwd(ctx, st, N, (int)KF, F, act, A, Wp, nullptr, inv_degree, residual ? h : nullptr, h_out, s_save,
+                   "mp_update_fwd");
+}
+
+int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, const float* h,
+                   const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
+                   const float* inv_degree, const float* w, const float* A_save, const float* s_save,
+                   const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de,
+                   int de_accum, float* dw) {
+  const int64_t KF = (int64_t)E * F;
+  const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
+  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr + (A_save ? 0 : N * KF)) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float* Wp = ws;
+  float* dA = ws + KF * F;
+  float* scr = dA + N * KF;
+  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  if (rc) return rc;
+  if (!A_save) {   // the caller did not keep the forward aggregate: rebuild it
+    float* Ar = scr + dw_scr;
+    rc = csr_aggregate(ctx, st, N, K, F, E, h, row_ptr, col, e, Ar);
+    if (rc) return rc;
+    A_save = Ar;
+  }
+  rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, s_save, inv_degree, dw, nullptr, 1, F, E, scr, "mp_dw");
+  if (rc) return rc;
+  rc = dense_dx(ctx, st, N, (int)KF, F, act, dh_out, s_save, inv_degree, Wp, nullptr, dA, "mp_dA");
+  if (rc) return rc;
+  rc = csr_edge_grad(ctx, st, N, K, F, E, h, row_ptr, col, dA, de, de_accum);
+  if (rc) return rc;
+  return csr_scatter_pull(ctx, st, N, K, F, E, row_of, csc_ptr, csc_edge, e, dA, dh_out, dh_in);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Distance-cutoff graphs (BASELINE configs[4] "variable degree"): every OTHER atom of the same frame closer than
+// `cutoff` (Angstrom) is a neighbour; rows are written in ascending neighbour index ("CSR-sorted": consecutive
+// entries gather consecutive rows).  Two passes over LDS-tiled positions, one thread per query atom:
+//   count:  deg[row]                               -> the caller's exclusive scan gives row_ptr
+//   fill :  col (batch-global), dist*scale, inv_degree = 1/#(local neighbour index > 0)  (library.py:115-116)
+constexpr int CUT_TILE = 1024;
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float scale, const float* __restrict__ pos,
+                                                     int32_t* __restrict__ deg, const int32_t* __restrict__ row_ptr,
+                                                     int32_t* __restrict__ col, float* __restrict__ dist,
+                                                     float* __restrict__ inv_degree) {
+  __shared__ float sx[CUT_TILE], sy[CUT_TILE], sz[CUT_TILE];
+  const int frame = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* fp = pos + (int64_t)frame * n * 3;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (i < n) { qx = fp[3 * i]; qy = fp[3 * i + 1]; qz = fp[3 * i + 2]; }
+  const int64_t row = (int64_t)frame * n + i;
+  int cnt = 0, cnt_pos = 0;
+  int64_t out = 0;
+  if (FILL && i < n) out = row_ptr[row];
+  for (int t0 = 0; t0 < n; t0 += CUT_TILE) {
+    const int m = min(CUT_TILE, n - t0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < m; t += 256) {
+      sx[t] = fp[3 * (t0 + t)]; sy[t] = fp[3 * (t0 + t) + 1]; sz[t] = fp[3 * (t0 + t) + 2];
+    }
+    __syncthreads();
+    if (i < n) {
+      for (int t = 0; t < m; ++t) {
+        const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const int j = t0 + t;
+        if (d2 < cutoff2 && j != i) {
+          if (FILL) {
+            col[out + cnt] = frame * n + j;
+            dist[out + cnt] = sqrtf(d2) * scale;
+          }
+          ++cnt;
+          cnt_pos += j > 0 ? 1 : 0;
+        }
+      }
+    }
+  }
+  if (i >= n) return;
+  if (FILL) inv_degree[row] = cnt_pos > 0 ? 1.0f / (float)cnt_pos : 0.f;
+  else deg[row] = cnt;
+}
+
+}  // namespace ng
+
+using namespace ng;
+
+// ===================================================================================== C ABI
+extern "C" int ng_mp_aggregate_csr(ng_ctx* ctx, void* stream, int64_t N, int F, int E, const float* h,
+                                   const int32_t* row_ptr, const int32_t* col, const float* e, float* A) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, row_ptr && col, "ng_mp_aggregate_csr: row_ptr and col are required");
+  return csr_aggregate(ctx, (hipStream_t)stream, N, 0, F, E, h, row_ptr, col, e, A);
+}
+
+extern "C" int ng_mp_layer_fwd_csr(ng_ctx* ctx, void* stream, int64_t N, int64_t nnz, int F, int E, int act,
+                                   int residual, const float* h, const int32_t* row_ptr, const int32_t* col,
+                                   const float* e, const float* inv_degree, const float* w, float* h_out,
+                                   float* A_save, float* s_save) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, row_ptr && (col || nnz == 0), "ng_mp_layer_fwd_csr: row_ptr and col are required");
+  NG_REQUIRE(ctx, (E * F) % 8 == 0, "mp_layer: (E*F) % 8");
+  NG_REQUIRE(ctx, nnz >= 0 && nnz < ((int64_t)1 << 31), "mp_layer (csr): nnz must fit int32");
+  return mp_generic_fwd(ctx, (hipStream_t)stream, N, 0, F, E, act, residual, h, row_ptr, col, e, inv_degree, w, h_out,
+                        A_save, s_save);
+}
+
+extern "C" int ng_mp_layer_bwd_csr(ng_ctx* ctx, void* stream, int64_t N, int64_t nnz, int F, int E, int act,
+                                   const float* h, const int32_t* row_ptr, const int32_t* col, const int32_t* row_of,
+                                   const float* e, const float* inv_degree, const float* w, const float* A_save,
+                                   const float* s_save, const int32_t* csc_ptr, const int32_t* csc_edge,
+                                   const float* dh_out, float* dh_in, float* de, int de_accum, float* dw) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, row_ptr && (nnz == 0 || (col && row_of)), "ng_mp_layer_bwd_csr: row_ptr, col and row_of are required");
+  NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
+  NG_REQUIRE(ctx, nnz >= 0 && nnz < ((int64_t)1 << 31), "mp_layer (csr): nnz must fit int32");
+  return mp_generic_bwd(ctx, (hipStream_t)stream, N, 0, F, E, act, h, row_ptr, col, row_of, e, inv_degree, w, A_save,
+                        s_save, csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw);
+}
+
+extern "C" int ng_cutoff_count(ng_ctx* ctx, void* stream, int G, int n, float cutoff, const float* pos,
+                               int32_t* deg) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, G >= 0 && n >= 0 && cutoff > 0.f, "cutoff graph: sizes >= 0, cutoff > 0");
+  NG_REQUIRE(ctx, (int64_t)G * n < (int64_t)1 << 31 && G <= 65535, "cutoff graph: batch too large");
+  if (G == 0 || n == 0) return NG_OK;
+  ProfScope ps(ctx, (hipStream_t)stream, "cutoff_count");
+  hipLaunchKernelGGL((cutoff_kernel<false>), dim3((unsigned)cdiv(n, 256), (unsigned)G), dim3(256), 0,
+                     (hipStream_t)stream, n, cutoff * cutoff, 1.0f, pos, deg, nullptr, nullptr, nullptr, nullptr);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_cutoff_fill(ng_ctx* ctx, void* stream, int G, int n, float cutoff, float scale, const float* pos,
+                              const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, G >= 0 && n >= 0 && cutoff > 0.f, "cutoff graph: sizes >= 0, cutoff > 0");
+  NG_REQUIRE(ctx, (int64_t)G * n < (int64_t)1 << 31 && G <= 65535, "cutoff graph: batch too large");
+  if (G == 0 || n == 0) return NG_OK;
+  ProfScope ps(ctx, (hipStream_t)stream, "cutoff_fill");
+  hipLaunchKernelGGL((cutoff_kernel<true>), dim3((unsigned)cdiv(n, 256), (unsigned)G), dim3(256), 0,
+                     (hipStream_t)stream, n, cutoff * cutoff, scale, pos, nullptr, row_ptr, col, dist, inv_degree);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}

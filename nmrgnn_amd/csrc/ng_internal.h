@@ -38,6 +38,19 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
 // elementwise helpers (node_ops.hip)
 int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp);
 
+// generic MPLayer over CSR lists, or padded lists when row_ptr == nullptr (row i = [i*K, (i+1)*K)); any
+// edge_feature_size <= 64 (mp_csr.hip)
+int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, int residual, const float* h,
+                   const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
+                   float* h_out, float* A_save, float* s_save);
+int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, const float* h,
+                   const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
+                   const float* inv_degree, const float* w, const float* A_save, const float* s_save,
+                   const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de,
+                   int de_accum, float* dw);
+int csr_aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* row_ptr,
+                  const int32_t* col, const float* e, float* A);
+
 }  // namespace ng
 
 namespace ng {

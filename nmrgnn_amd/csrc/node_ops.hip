@@ -146,8 +146,9 @@ static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
                      const int32_t* nlist, const float* e, float* A) {
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 1024 && (256 % (F / 4)) == 0,
              "aggregate: F in {16,32,64,128,256,512,1024}");
-  NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "aggregate: edge_feature_size <= 8");
+  NG_REQUIRE(ctx, E >= 1 && E <= 64, "aggregate: edge_feature_size <= 64");
   if (N == 0) return NG_OK;
+  if (E > MAX_E) return csr_aggregate(ctx, st, N, K, F, E, h, nullptr, nlist, e, A);
   ProfScope ps(ctx, st, "mp_aggregate");
   const int apb = 256 / (F / 4);
   const size_t lds = (size_t)apb * K * (1 + E) * 4;
@@ -671,6 +672,8 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
     }
     return mp_win_fwd(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, w, h_out, s_save);
   }
+  if (E > MAX_E)   // edge_feature_size = 64 (model.py:23): feature-chunked kernels of mp_csr.hip, fixed stride K
+    return mp_generic_fwd(ctx, st, N, K, F, E, act, residual, h, nullptr, nlist, e, inv_degree, w, h_out, A_save, s_save);
   const int64_t KF = (int64_t)E * F;
   // scratch: Wp [KF*F] (+ A [N*KF] when the caller does not keep it)
   const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;
@@ -728,7 +731,10 @@ extern "C" int ng_mp_layer_bwd_rec(ng_ctx* ctx, void* stream, int64_t N, int K, 
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
              "mp_layer_bwd: F in {16,32,64,128,256}");
-  NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "mp_layer_bwd: edge_feature_size <= 8");
+  NG_REQUIRE(ctx, E >= 1 && E <= 64, "mp_layer_bwd: edge_feature_size <= 64");
+  if (E > MAX_E)
+    return mp_generic_bwd(ctx, st, N, K, F, E, act, h, nullptr, nlist, nullptr, e, inv_degree, w, A_save, s_save,
+                          csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw);
   if (N > 0 && mp_win_bwd_enabled(F, E, K))
     return mp_win_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, s_save, csc_ptr, csc_edge, dh_out, dh_in, de,
                       de_accum, dw, csc_rec);

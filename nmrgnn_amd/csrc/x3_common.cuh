@@ -14,10 +14,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// v_cvt_pk_bf16_f32 (round to nearest even) through the compiler's own conversion, NOT inline asm: the hazard
+// recognizer does not apply the MFMA-related wait states (XDL write -> VALU, SrcC read -> VALU write, ...) to
+// instructions hidden inside an asm statement, and once the scheduler interleaved the asm conversions with an MFMA
+// chain the edge forward kernel returned run-to-run different e (round 2: ~16 % of the edges off by up to 6e-6 in the
+// training variant; tools/dbg_det.py).  The vector fptrunc lowers to the same single instruction on gfx950.
+typedef float f32x2_cvt __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_cvt __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{lo, hi}, bf16x2_cvt));
 }
 
 // (x0, x1) -> packed bf16 pieces; piece p of x0 in the low half, of x1 in the high half

@@ -108,7 +108,7 @@ class Engine:
         N, K, F, E, H = batch.N, batch.K, self.F, self.E, self.H
         if batch.C != self.C:
             raise ValueError(f"atoms has {batch.C} element columns, model was built for {self.C}")
-        ne = N * K
+        ne = batch.n_edges
         d_src = batch.edges.reshape(-1)
         d_eff = d_src
         if training and self.sigma > 0:
@@ -134,12 +134,19 @@ class Engine:
         hs, As, Ss = [h0], [], []
         for l in range(self.L):
             hn = self._new(N, F)
-            A = self._new(N, E, F) if (training and lib.ng_mp_layer_wants_aggregate(F, E, K)) else None
             S = self._new(N, F) if (training and self.mp_act != 0) else None
-            self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
-                                         ptr(batch.nlist_c), ptr(e), ptr(batch.inv_degree),
-                                         ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A), ptr(S)),
-                     "ng_mp_layer_fwd")
+            if batch.is_csr:        # variable-degree lists: row_ptr / col instead of [N,K]
+                A = self._new(N, E, F) if training else None
+                self._ck(lib.ng_mp_layer_fwd_csr(h, st, N, ne, F, E, self.mp_act, 1, ptr(hs[-1]),
+                                                 ptr(batch.row_ptr), ptr(batch.nlist), ptr(e),
+                                                 ptr(batch.inv_degree), ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A),
+                                                 ptr(S)), "ng_mp_layer_fwd_csr")
+            else:
+                A = self._new(N, E, F) if (training and lib.ng_mp_layer_wants_aggregate(F, E, K)) else None
+                self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
+                                             ptr(batch.nlist_c), ptr(e), ptr(batch.inv_degree),
+                                             ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A), ptr(S)),
+                         "ng_mp_layer_fwd")
             hs.append(hn)
             As.append(A)
             Ss.append(S)
@@ -184,7 +191,7 @@ class Engine:
         b = tp.batch
         N, K, F, E, H = b.N, b.K, self.F, self.E, self.H
         Fh = F // 2
-        ne = N * K
+        ne = b.n_edges
         dpeaks = dpeaks.contiguous()
         dg = self._new(N, Fh)
         self._ck(lib.ng_head_bwd(h, st, N, Fh, self.C, ptr(tp.g), ptr(tp.drop_mask),
@@ -204,13 +211,22 @@ class Engine:
         de = self._new(ne, E)
         # incoming-edge records (source atom + edge features in CSC order): shared by all MP layers
         rec = None
-        if E <= 3:
+        if E <= 3 and not b.is_csr:
             rec = self._new(ne, 4)
             self._ck(lib.ng_mp_edge_records(h, st, N, K, E, ptr(csc_ptr), ptr(csc_edge), ptr(tp.e), ptr(rec)),
                      "ng_mp_edge_records")
         dh = dx
         for l in reversed(range(self.L)):
             dhn = self._new(N, F)
+            if b.is_csr:
+                self._ck(lib.ng_mp_layer_bwd_csr(h, st, N, ne, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.row_ptr),
+                                                 ptr(b.nlist), ptr(b.row_of), ptr(tp.e), ptr(b.inv_degree),
+                                                 ptr(P[f"mp/{l}/w"]), ptr(tp.A[l]), ptr(tp.S[l]), ptr(csc_ptr),
+                                                 ptr(csc_edge), ptr(dh), ptr(dhn), ptr(de),
+                                                 0 if l == self.L - 1 else 1, ptr(P.g(f"mp/{l}/w"))),
+                         "ng_mp_layer_bwd_csr")
+                dh = dhn
+                continue
             self._ck(lib.ng_mp_layer_bwd_rec(h, st, N, K, F, E, self.mp_act, ptr(tp.h[l]), ptr(b.nlist_c),
                                          ptr(tp.e), ptr(b.inv_degree), ptr(P[f"mp/{l}/w"]),
                                          ptr(tp.A[l]), ptr(tp.S[l]), ptr(csc_ptr), ptr(csc_edge),

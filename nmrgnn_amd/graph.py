@@ -6,6 +6,11 @@ The reference feeds ONE graph per model call as the 4-tuple
 graph, so any number of graphs can be concatenated along N with offset neighbour indices
 (SURVEY App. C KAT-6); that is how the engine batches molecules.
 
+Besides the reference's padded [N,K] lists a batch can hold the CSR form of SURVEY §8(b)
+(``GraphBatch.from_csr`` / ``to_csr`` / ``frames_to_batch_cutoff``): ``row_ptr`` [N+1], ``nlist`` = col [nnz],
+``edges`` = dist [nnz] — the padded lists with their ``edges == 0`` slots dropped, or a variable-degree
+(distance-cutoff) graph.  ``is_csr`` tells the engine which entry points to call.
+
 A GraphBatch additionally carries
   * ``graph_ptr`` [G+1]: atom ranges of the member graphs (loss is per graph, losses.py:37-39);
   * the transposed incoming-edge lists ``csc_ptr`` [N+1] / ``csc_edge`` [nnz] used by the
@@ -26,6 +31,9 @@ def _to_dev(x, dtype, device):
 
 
 class GraphBatch:
+    is_csr = False
+    row_ptr = None
+
     def __init__(self, atoms, nlist, edges, inv_degree, graph_ptr=None, device=None,
                  validate=True):
         if device is None:
@@ -59,12 +67,85 @@ class GraphBatch:
         own = torch.arange(self.N, dtype=torch.int32, device=self.device)[:, None]
         self.nlist_c = torch.where(self.edges > 0, self.nlist, own).contiguous()
 
+    # ------------------------------------------------------------------ CSR form
+    @classmethod
+    def from_csr(cls, atoms, row_ptr, col, dist, inv_degree=None, graph_ptr=None, device=None, validate=True):
+        """Variable-degree graph(s): row i owns the entries [row_ptr[i], row_ptr[i+1]) of ``col`` (neighbour
+        atom, batch-global) and ``dist`` (distance > 0).  ``inv_degree`` defaults to the reference's rule
+        1 / #(graph-local neighbour index > 0), 0 when that count is 0 (nmrgnn/library.py:115-116)."""
+        self = cls.__new__(cls)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.is_csr = True
+        self.atoms = _to_dev(atoms, torch.float32, self.device)
+        if self.atoms.dim() != 2:
+            raise ValueError("atoms must be [N,C]")
+        self.N, self.C = self.atoms.shape
+        self.row_ptr = _to_dev(row_ptr, torch.int32, self.device).reshape(-1)
+        self.nlist = _to_dev(col, torch.int32, self.device).reshape(-1)
+        self.edges = _to_dev(dist, torch.float32, self.device).reshape(-1)
+        self.nnz = int(self.nlist.shape[0])
+        self.K = 0
+        if self.row_ptr.shape[0] != self.N + 1 or self.edges.shape[0] != self.nnz:
+            raise ValueError("row_ptr must be [N+1]; col and dist must have the same length")
+        if graph_ptr is None:
+            graph_ptr = [0, self.N]
+        self.graph_ptr_host = np.asarray(graph_ptr, dtype=np.int32)
+        self.graph_ptr = torch.as_tensor(self.graph_ptr_host, device=self.device)
+        self.G = len(self.graph_ptr_host) - 1
+        if validate:
+            rp = self.row_ptr.to(torch.int64)
+            if int(rp[0]) != 0 or int(rp[-1]) != self.nnz or bool((rp[1:] < rp[:-1]).any()):
+                raise ValueError("row_ptr must start at 0, end at nnz and be non-decreasing")
+            if self.nnz:
+                lo, hi = int(self.nlist.min()), int(self.nlist.max())
+                if lo < 0 or hi >= self.N:
+                    raise ValueError(f"col entries must lie in [0,{self.N}); got [{lo},{hi}]")
+                if bool((self.edges <= 0).any()):
+                    raise ValueError("CSR distances must be > 0 (zero-distance slots are the padded form's mask)")
+        deg = (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+        self.row_of = torch.repeat_interleave(torch.arange(self.N, device=self.device, dtype=torch.int32),
+                                              deg).contiguous()
+        if inv_degree is None:
+            gp = torch.as_tensor(self.graph_ptr_host.astype(np.int64), device=self.device)
+            rows = self.row_of.to(torch.int64)
+            gid = torch.bucketize(rows, gp[1:], right=True)
+            local = self.nlist.to(torch.int64) - gp[gid]
+            cnt = torch.zeros(self.N, dtype=torch.float32, device=self.device)
+            cnt.index_add_(0, rows, (local > 0).to(torch.float32))
+            inv_degree = torch.where(cnt > 0, 1.0 / cnt.clamp(min=1.0), torch.zeros_like(cnt))
+        self.inv_degree = _to_dev(inv_degree, torch.float32, self.device).reshape(-1)
+        if self.inv_degree.shape[0] != self.N:
+            raise ValueError("inv_degree must be [N]")
+        self.nlist_c = self.nlist
+        self._csc = None
+        return self
+
+    def to_csr(self):
+        """the same graph(s) with the ``edges == 0`` slots dropped (entry order inside a row is kept)"""
+        if self.is_csr:
+            return self
+        keep = self.edges > 0
+        deg = keep.sum(dim=1)
+        row_ptr = torch.zeros(self.N + 1, dtype=torch.int64, device=self.device)
+        row_ptr[1:] = torch.cumsum(deg, 0)
+        return GraphBatch.from_csr(self.atoms, row_ptr.to(torch.int32), self.nlist[keep], self.edges[keep],
+                                   self.inv_degree, graph_ptr=self.graph_ptr_host, device=self.device, validate=False)
+
     @property
     def n_edges(self):
-        return self.N * self.K
+        return self.nnz if self.is_csr else self.N * self.K
 
     def csc(self):
         """incoming-edge lists for the backward scatter; built once per batch."""
+        if self._csc is None and self.is_csr:
+            tgt = self.nlist.to(torch.int64)
+            order = torch.argsort(tgt, stable=True)
+            counts = torch.bincount(tgt, minlength=self.N)
+            ptr = torch.zeros(self.N + 1, dtype=torch.int64, device=self.device)
+            ptr[1:] = torch.cumsum(counts, 0)
+            self._csc = (ptr.to(torch.int32).contiguous(), order.to(torch.int32).contiguous())
         if self._csc is None:
             N, K = self.N, self.K
             valid = (self.edges > 0).reshape(-1)
@@ -79,6 +160,8 @@ class GraphBatch:
         return self._csc
 
     def as_tuple(self):
+        if self.is_csr:
+            raise ValueError("a CSR batch has no (atoms, nlist, edges, inv_degree) tuple; see row_ptr / nlist / edges")
         return self.atoms, self.nlist, self.edges, self.inv_degree
 
 
@@ -128,3 +211,42 @@ def frames_to_batch(atoms, frames, neighbor_number=16, scale=0.1, device=None):
                                    ptr(inv)), "ng_knn_graph")
     ptrs = np.arange(G + 1, dtype=np.int64) * n
     return GraphBatch(at.repeat(G, 1), nlist, edges, inv, graph_ptr=ptrs, device=device, validate=False)
+
+
+def frames_to_batch_cutoff(atoms, frames, cutoff=4.0, scale=0.1, device=None):
+    """Distance-cutoff graphs of ``G`` trajectory frames, built on the GPU (ng_cutoff_count / ng_cutoff_fill) and
+    returned as one device-resident CSR GraphBatch: every other atom of the same frame closer than ``cutoff``
+    (Angstrom) is a neighbour, rows in ascending neighbour index, distances x ``scale`` (nm), inv_degree by the
+    reference's rule (library.py:115-116).  Variable degree: BASELINE configs[4]."""
+    import ctypes as C
+    from . import _lib
+    from ._lib import ptr
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    pos = _to_dev(np.asarray(frames, dtype=np.float32) if not isinstance(frames, torch.Tensor) else frames,
+                  torch.float32, device)
+    if pos.dim() == 2:
+        pos = pos[None]
+    G, n, _ = pos.shape
+    at = _to_dev(atoms, torch.float32, device)
+    if at.shape[0] != n:
+        raise ValueError(f"atoms has {at.shape[0]} rows but frames have {n} atoms")
+    ctx = _lib.get_context(device.index)
+    with torch.cuda.device(device):
+        st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        deg = torch.zeros(G * n, dtype=torch.int32, device=device)
+        ctx.check(ctx.lib.ng_cutoff_count(ctx.handle, st, G, n, float(cutoff), ptr(pos), ptr(deg)), "ng_cutoff_count")
+        row_ptr = torch.zeros(G * n + 1, dtype=torch.int64, device=device)
+        row_ptr[1:] = torch.cumsum(deg.to(torch.int64), 0)
+        nnz = int(row_ptr[-1])                      # the one host synchronisation: the list length sizes the buffers
+        if nnz >= 2 ** 31:
+            raise ValueError("cutoff graph: more than 2^31 edges in one batch")
+        row_ptr = row_ptr.to(torch.int32)
+        col = torch.empty(nnz, dtype=torch.int32, device=device)
+        dist = torch.empty(nnz, dtype=torch.float32, device=device)
+        inv = torch.empty(G * n, dtype=torch.float32, device=device)
+        ctx.check(ctx.lib.ng_cutoff_fill(ctx.handle, st, G, n, float(cutoff), float(scale), ptr(pos), ptr(row_ptr),
+                                         ptr(col), ptr(dist), ptr(inv)), "ng_cutoff_fill")
+    ptrs = np.arange(G + 1, dtype=np.int64) * n
+    return GraphBatch.from_csr(at.repeat(G, 1), row_ptr, col, dist, inv, graph_ptr=ptrs, device=device, validate=False)

@@ -7,7 +7,8 @@ import numpy as np
 
 
 def corr_coeff(x, y, w=None):
-    """nmrgnn/losses.py:4-15"""
+    """nmrgnn/losses.py:4-15.  Deliberate deviation: sum(w) == 0 gives r = 0 (finite loss) where the reference's
+    0/0 moments give NaN; ng_loss_name does the same."""
     x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
     w = np.ones_like(x) if w is None else np.asarray(w, np.float64)
     m = w.sum()

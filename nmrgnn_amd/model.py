@@ -41,6 +41,7 @@ class GNNModel:
         self._seed = seed
         self.engine = None
         self._pending_state = None
+        self._train_calls = 0         # training-mode calls so far: every one draws fresh noise / dropout
 
     # -- keras-like build: the number of elements comes from the first input (model.py:236-243)
     def build(self, num_elem):
@@ -63,11 +64,17 @@ class GNNModel:
         self.build(num_elem)
         return GraphBatch(atoms, nlist, edges, inv_degree, device=self.engine.device), on_device
 
-    def __call__(self, inputs, training=False):
+    def __call__(self, inputs, training=False, seed=None):
+        """``training=True`` applies GaussianNoise and Dropout with a FRESH draw per call, as Keras does
+        (model.py:253,266-267): the Philox key is derived from the model seed and a per-model call counter;
+        pass ``seed=`` to fix it."""
         batch, on_device = self._as_batch(inputs)
         if self.engine is None:
             self.build(batch.C)
-        peaks = self.engine.forward(batch, training=training)
+        if training and seed is None:
+            seed = ((int(self._seed) * 0x9E3779B97F4A7C15) ^ (self._train_calls * 1000003 + 0x632BE5AB)) & ((1 << 63) - 1)
+            self._train_calls += 1
+        peaks = self.engine.forward(batch, training=training, seed=seed or 0)
         if on_device:
             return peaks
         return peaks.cpu().numpy().view(Peaks)

@@ -45,6 +45,15 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, hi
 
 
+def shard_grad_weight(local_graphs: int, world: int, total_graphs=None) -> float:
+    """Factor for a rank's loss gradient BEFORE the summing all-reduce + 1/world scaling, so that the exchanged
+    gradient is the mean over ALL graphs: the local loss is a mean over local_graphs, hence
+    (1/world) * weight * g_local = (local_graphs/total_graphs) * g_local.  1.0 for equal shards."""
+    if total_graphs is None or world <= 1:
+        return 1.0
+    return local_graphs * world / float(total_graphs)
+
+
 class GradBuckets:
     """Splits the flat gradient into the (late) edge bucket and the (early) node bucket."""
 
@@ -57,6 +66,9 @@ class GradBuckets:
 
     def world(self):
         return dist.get_world_size() if dist.is_initialized() else 1
+
+    def rank(self):
+        return dist.get_rank() if dist.is_initialized() else 0
 
     def launch_node(self):
         if self.world() > 1 and self.node.numel():

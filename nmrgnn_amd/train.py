@@ -7,7 +7,7 @@ import torch
 
 from .engine import Engine
 from .graph import GraphBatch
-from .parallel import GradBuckets
+from .parallel import GradBuckets, shard_grad_weight
 
 
 class Trainer:
@@ -21,16 +21,25 @@ class Trainer:
         self.buckets = GradBuckets(P.grad, P.offsets[first_node])
         self.step_count = 0
 
-    def step(self, batch: GraphBatch, y: torch.Tensor, w: torch.Tensor, seed=None):
+    def step(self, batch: GraphBatch, y: torch.Tensor, w: torch.Tensor, seed=None, total_graphs=None):
+        """One optimiser step.  ``total_graphs``: number of graphs over ALL ranks this step (every rank can
+        compute it from ``parallel.shard_range``); needed only when the shards are uneven — the loss is a mean
+        over graphs, so a rank holding G_local of G_total graphs must weigh its gradient G_local/G_total, not
+        1/world.  Default: equal shards."""
         eng = self.engine
+        world, rank = self.buckets.world(), self.buckets.rank()
         if seed is None:
-            seed = 0x9E3779B97F4A7C15 ^ (self.step_count * 1000003)
+            # different noise / dropout draws on every rank and every step
+            seed = 0x9E3779B97F4A7C15 ^ (self.step_count * 1000003) ^ (rank * 0x5851F42D4C957F2D)
         seed &= (1 << 63) - 1
         peaks = eng.forward(batch, training=True, seed=seed)
         if self.loss_balance == 1.0:
             loss, dpred = eng.loss_l2(batch, y, w, peaks)
         else:
             loss, dpred = eng.loss_name(batch, y, w, peaks, self.loss_balance)
+        wgt = shard_grad_weight(batch.G, world, total_graphs)
+        if wgt != 1.0:
+            dpred.mul_(wgt)
         eng.backward(dpred, on_node_grads=self.buckets.launch_node)
         self.buckets.launch_edge()
         self.buckets.wait()

@@ -296,23 +296,6 @@ def amp_layer_forward(nodes, nlist, edges, inv_degree, wq, wk, wv, act=None):
     return _act(act)(reduced)
 
 
-def corr_coeff(x, y, w=None):
-    """nmrgnn/losses.py:4-15"""
-    if w is None:
-        w = np.ones_like(x)
-    m = np.sum(w)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        xm = np.sum(w * x) / m
-        ym = np.sum(w * y) / m
-        xm2 = np.sum(w * x ** 2) / m
-        ym2 = np.sum(w * y ** 2) / m
-        cov = np.sum(w * (x - xm) * (y - ym))
-        den = m * np.sqrt(np.clip((xm2 - xm ** 2) * (ym2 - ym ** 2), 0, 1e32))
-    if not np.isfinite(den) or den == 0:
-        return 0.0
-    return float(cov / den)
-
-
 def name_loss(y_true, y_pred, label_idx, s=1.0):
     """nmrgnn/losses.py:30-39 for ONE graph.  y_true[:,0]=label, [:,1]=name id, [:,-1]=weight."""
     y_true = np.asarray(y_true, np.float64)
@@ -347,7 +330,10 @@ def batch_loss_s1(y, w, pred, graph_ptr):
 
 
 def corr_coeff(x, y, w=None):
-    """losses.py:4-15 (weighted Pearson r in moment form, clipped variance product, divide_no_nan)."""
+    """losses.py:4-15 (weighted Pearson r in moment form, clipped variance product, divide_no_nan).
+    DELIBERATE DEVIATION: for sum(w) == 0 the reference's moments are 0/0 = NaN (divide_no_nan only guards the
+    final denominator) and its loss becomes NaN; here r = 0, i.e. such a graph contributes (1-s)*1 — the HIP
+    kernel ng_loss_name and nmrgnn_amd.losses.corr_coeff do the same."""
     x = np.asarray(x, np.float64)
     y = np.asarray(y, np.float64)
     w = np.ones_like(x) if w is None else np.asarray(w, np.float64)

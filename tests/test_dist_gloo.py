@@ -11,9 +11,9 @@ import torch.multiprocessing as mp
 
 from oracle import nmrgnn_oracle as O
 from nmrgnn_amd import synth
-from nmrgnn_amd.parallel import GradBuckets, shard_range
+from nmrgnn_amd.parallel import GradBuckets, shard_grad_weight, shard_range
 
-N_GRAPHS, N_ATOMS = 4, 12
+N_ATOMS = 12
 
 
 def _flat_grads(hp, p, b, lo, hi, n_graphs_total):
@@ -28,7 +28,7 @@ def _flat_grads(hp, p, b, lo, hi, n_graphs_total):
     return np.concatenate([grads[k].reshape(-1) for k in names]), names
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, N_GRAPHS):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,8 @@ def _worker(rank, world, port, out):
     b = synth.make_batch(N_GRAPHS, N_ATOMS, 4, 10, 0.1, seed=5)
     lo, hi = shard_range(N_GRAPHS, rank, world)
     flat, names = _flat_grads(hp, p, b, lo, hi, N_GRAPHS)
-    g = torch.tensor(flat)
+    # the rank's loss is a mean over ITS graphs: weigh it as the trainer does (uneven shards: 3 + 2 of 5)
+    g = torch.tensor(flat) * shard_grad_weight(hi - lo, world, N_GRAPHS)
     n_edge = sum(int(np.prod(s)) for k, s in O.param_shapes(hp, 10) if k.startswith("edge_fc/"))
     buckets = GradBuckets(g, n_edge)
     buckets.launch_node()
@@ -51,11 +52,15 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_allreduce_reproduces_full_batch_gradient():
+import pytest
+
+
+@pytest.mark.parametrize("N_GRAPHS", [4, 5])
+def test_two_rank_allreduce_reproduces_full_batch_gradient(N_GRAPHS):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, N_GRAPHS)) for r in range(2)]
     for pr in procs:
         pr.start()
     got = q.get(timeout=120)

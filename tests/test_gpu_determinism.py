@@ -1,0 +1,66 @@
+"""Run-to-run determinism: the engine uses no floating-point atomics and fixed-order reductions, so the same inputs
+must give bit-identical outputs and gradients every time.  (Round 2 found the training variant of the split-operand
+edge forward returning slightly different e from run to run: inline-asm bf16 conversions that the scheduler had moved
+into an MFMA chain without the hazard wait states — csrc/x3_common.cuh.  This test keeps that class of bug out.)"""
+import numpy as np
+import pytest
+
+from helpers import make_hp, randomize_biases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_edges", [3159, 100000, 1 << 20])
+@pytest.mark.parametrize("train", [False, True])
+def test_edge_forward_is_bitwise_reproducible(gpu_device, n_edges, train):
+    import torch
+    from nmrgnn_amd._lib import ptr, ptr_array
+    from nmrgnn_amd.engine import Engine
+    eng = Engine(make_hp(atom_feature_size=64), 10, device=gpu_device, seed=2)
+    randomize_biases(eng)
+    P = eng.params
+    W = [P[f"edge_fc/{t}/kernel"] for t in range(4)]
+    B = [P[f"edge_fc/{t}/bias"] for t in range(4)]
+    d = torch.from_numpy(np.random.default_rng(0).uniform(0.05, 0.5, n_edges).astype(np.float32)).to(gpu_device)
+
+    def run():
+        e = torch.empty(n_edges, 3, device=gpu_device)
+        z = torch.empty(3, n_edges, 128, device=gpu_device) if train else None
+        eng._ck(eng.lib.ng_edge_mlp_fwd(eng.ctx.handle, eng._st(), n_edges, 128, 3, 4, ptr(d), ptr(d), ptr(eng.centers),
+                                        eng.gap, ptr_array(W), ptr_array(B), ptr(e), ptr(z)), "edge fwd")
+        return e, z
+
+    e0, z0 = run()
+    for _ in range(10):
+        e1, z1 = run()
+        assert torch.equal(e0, e1)
+        if train:
+            assert torch.equal(z0, z1)
+
+
+@pytest.mark.parametrize("F", [64, 256])
+def test_training_step_is_bitwise_reproducible(gpu_device, F):
+    """forward(training) + backward on 64 graphs x 256 atoms, five times: identical peaks and gradients"""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    hp = make_hp(atom_feature_size=F)
+    b = synth.make_batch(64, 256, 16, 10, 0.05, seed=3)
+    eng = Engine(hp, 10, device=gpu_device, seed=9)
+    randomize_biases(eng)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=5)
+    mask = eng.dropout_mask(N * (F // 2), seed=6)
+    dpe = torch.from_numpy(np.random.default_rng(1).standard_normal(N).astype(np.float32)).to(gpu_device)
+    ref = None
+    for _ in range(5):
+        pk = eng.forward(gb, training=True, noise=xi, dropout_mask=mask).clone()
+        eng.backward(dpe)
+        cur = (pk, eng.params.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0])
+            assert torch.equal(cur[1], ref[1])
