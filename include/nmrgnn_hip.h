@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 1
+#define NG_ABI_VERSION 2
 
 enum {
   NG_OK = 0,
@@ -79,11 +79,13 @@ int ng_rbf_expand(ng_ctx*, void* stream, int64_t n, int H, const float* d_src, c
  *   d_eff  [n_edges]  distances fed to the RBF (= d_src, or d_src + sigma*xi when training)
  *   centers[H], gap   RBF grid (layers.py:126-129)
  *   W[t] [in,out], b[t] [out]  host arrays (length Le) of device pointers, Keras Dense layout
+ *   act    activation of the hidden layers = hypers fc_activation (model.py:35-36,123): NG_ACT_SOFTPLUS runs the fused
+ *          kernels (H = 128, Le = 4, E <= 8); other codes, other shapes and E up to 256 (E % 4 == 0) the layered path
  *   e_out  [n_edges,E]
  *   z_save [Le-1, n_edges, H] softplus outputs of the hidden layers (NULL for inference): the tape handed to
  *          ng_edge_mlp_bwd; its element order inside a layer is given by ng_edge_tape_layout()
  */
-int ng_edge_mlp_fwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
+int ng_edge_mlp_fwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le, int act,
                     const float* d_src, const float* d_eff, const float* centers, float gap,
                     const float* const* W, const float* const* b, float* e_out, float* z_save);
 /* Element order of a z_save layer for this shape (same footprint either way; depends on NG_EDGE_* switches, so ask
@@ -92,15 +94,15 @@ int ng_edge_mlp_fwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le
  *   1: inside every FULL group of 32 consecutive edges the 32 x 128 block is stored in the kernels' register layout:
  *      edge r (0..31), feature 32*bo + 8*q + 4*hf + j  ->  float ((bo*4 + q)*64 + hf*32 + r)*4 + j of the group's
  *      4096; a last partial group is row-major.  (Both kernels then move whole contiguous KBs per wave.) */
-int ng_edge_tape_layout(int H, int E, int Le, int64_t n_edges);
+int ng_edge_tape_layout(int H, int E, int Le, int act, int64_t n_edges);
 /* de [n_edges,E] upstream gradient; writes dW[t], db[t] (overwrites).
  * ng_edge_mlp_bwd_tape: tape_layout = the value ng_edge_tape_layout() returned when the forward wrote z_save (the
  * layout then no longer depends on the switches in force at backward time); ng_edge_mlp_bwd == tape_layout -1 (ask again). */
-int ng_edge_mlp_bwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
+int ng_edge_mlp_bwd(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le, int act,
                     const float* d_src, const float* d_eff, const float* centers, float gap,
                     const float* const* W, const float* z_save, const float* de,
                     float* const* dW, float* const* db);
-int ng_edge_mlp_bwd_tape(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le,
+int ng_edge_mlp_bwd_tape(ng_ctx*, void* stream, int64_t n_edges, int H, int E, int Le, int act,
                          const float* d_src, const float* d_eff, const float* centers, float gap,
                          const float* const* W, const float* z_save, const float* de,
                          float* const* dW, float* const* db, int tape_layout);

@@ -12,8 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NMRGNN_HIP_LIB: another build of the same library (A/B measurements of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("NMRGNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libnmrgnn_hip.so")
 
-NG_ACT_NONE, NG_ACT_SOFTPLUS = 0, 1
-ACT_CODES = {None: NG_ACT_NONE, "linear": NG_ACT_NONE, "softplus": NG_ACT_SOFTPLUS}
+NG_ACT_NONE, NG_ACT_SOFTPLUS, NG_ACT_RELU, NG_ACT_TANH = 0, 1, 2, 3
+ACT_CODES = {None: NG_ACT_NONE, "linear": NG_ACT_NONE, "softplus": NG_ACT_SOFTPLUS, "relu": NG_ACT_RELU,
+             "tanh": NG_ACT_TANH}
 
 _c_float_p = C.POINTER(C.c_float)
 _c_int32_p = C.POINTER(C.c_int32)
@@ -38,12 +39,12 @@ SIGNATURES = {
     "ng_dropout_mask": (_int, [_vp, _vp, _u64, _u64, _f, _vp, _i64]),
     "ng_add_scaled": (_int, [_vp, _vp, _i64, _vp, _vp, _f, _vp]),
     "ng_rbf_expand": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _f, _vp]),
-    "ng_edge_mlp_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _f,
+    "ng_edge_mlp_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
-    "ng_edge_tape_layout": (_int, [_int, _int, _int, _i64]),
-    "ng_edge_mlp_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _f,
+    "ng_edge_tape_layout": (_int, [_int, _int, _int, _int, _i64]),
+    "ng_edge_mlp_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
-    "ng_edge_mlp_bwd_tape": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _f,
+    "ng_edge_mlp_bwd_tape": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                     C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _int]),
     "ng_embed_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "ng_embed_bwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
@@ -101,7 +102,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 1:
+        if lib.ng_abi_version() != 2:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -214,7 +214,15 @@ int edge_out_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, int E, con
   return NG_OK;
 }
 
-int edge_mlp_fwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, int E, int Le,
+// e *= (d_src > 0)   (model.py:261) for the wide output layer, whose GEMM cannot mask rows that carry a bias
+__global__ void mask_rows_kernel(int64_t n_edges, int E, const float* __restrict__ d_src, const float* __restrict__ x,
+                                 float* __restrict__ out) {
+  const int64_t total = n_edges * E;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+    out[t] = d_src[t / E] > 0.f ? x[t] : 0.f;
+}
+
+int edge_mlp_fwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, int E, int Le, int act,
                          const float* d_src, const float* d_eff, const float* centers, float gap,
                          const float* const* W, const float* const* b, float* e_out,
                          float* z_save) {
@@ -233,21 +241,31 @@ int edge_mlp_fwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
   const float* x = X0;
   for (int t = 0; t < Le - 1; ++t) {
     float* y = z_save ? z_save + (int64_t)t * tile : ws + (int64_t)(1 + (t & 1)) * tile;
-    int rc = dense_fwd(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, x, W[t], b[t], nullptr, nullptr, y,
+    int rc = dense_fwd(ctx, st, n_edges, H, H, act, x, W[t], b[t], nullptr, nullptr, y,
                        nullptr, "edge_dense_fwd");
     if (rc) return rc;
     x = y;
   }
+  if (E > MAX_E) {   // edge_feature_size = 64 (model.py:23): plain GEMM, then the row mask
+    int rc = dense_fwd(ctx, st, n_edges, H, E, NG_ACT_NONE, x, W[Le - 1], b[Le - 1], nullptr, nullptr, e_out, nullptr,
+                       "edge_out_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mask_rows_kernel, ew_grid(n_edges * E), dim3(256), 0, st, n_edges, E, d_src, e_out, e_out);
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
   return edge_out_fwd(ctx, st, n_edges, H, E, x, W[Le - 1], b[Le - 1], d_src, e_out);
 }
 
-int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, int E, int Le,
+int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, int E, int Le, int act,
                          const float* d_src, const float* d_eff, const float* centers, float gap,
                          const float* const* W, const float* z_save, const float* de,
                          float* const* dW, float* const* db) {
   const int64_t tile = n_edges * H;
   const int64_t nb = edge_out_bwd_blocks(n_edges);
-  const size_t out_scr = (size_t)(nb + 1) * ((size_t)H * E + E);
+  const bool wide = E > MAX_E;
+  const size_t out_scr = wide ? dense_dw_scratch_floats(ctx, n_edges, H, E, true) + (size_t)n_edges * E
+                              : (size_t)(nb + 1) * ((size_t)H * E + E);
   const size_t dw_scr = dense_dw_scratch_floats(ctx, n_edges, H, H, true);
   const size_t scr = std::max(out_scr, dw_scr);
   // scratch: X0, dZ ping, dZ pong, reduction scratch
@@ -258,8 +276,19 @@ int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
   float* dz1 = ws + 2 * tile;
   float* scratch = ws + 3 * tile;
   const float* z_last = z_save + (int64_t)(Le - 2) * tile;
-  int rc = edge_out_bwd(ctx, st, n_edges, H, E, z_last, W[Le - 1], d_src, de, dz0, dW[Le - 1],
-                        db[Le - 1], scratch);
+  int rc;
+  if (wide) {   // dE = m * de ; dWo = Z^T dE, dbo = colsum dE ; dZ = dE Wo^T   (plain GEMMs)
+    float* dE = scratch + dense_dw_scratch_floats(ctx, n_edges, H, E, true);
+    hipLaunchKernelGGL(mask_rows_kernel, ew_grid(n_edges * E), dim3(256), 0, st, n_edges, E, d_src, de, dE);
+    NG_HIP(ctx, hipGetLastError());
+    rc = dense_dw(ctx, st, n_edges, H, E, NG_ACT_NONE, z_last, dE, nullptr, nullptr, dW[Le - 1], db[Le - 1], 0, 0, 0,
+                  scratch, "edge_out_bwd");
+    if (rc) return rc;
+    rc = dense_dx(ctx, st, n_edges, H, E, NG_ACT_NONE, dE, nullptr, nullptr, W[Le - 1], nullptr, dz0, "edge_out_bwd");
+  } else {
+    rc = edge_out_bwd(ctx, st, n_edges, H, E, z_last, W[Le - 1], d_src, de, dz0, dW[Le - 1],
+                      db[Le - 1], scratch);
+  }
   if (rc) return rc;
   float* dz = dz0;
   float* dz_next = dz1;
@@ -275,11 +304,11 @@ int edge_mlp_bwd_layered(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int H, in
       NG_HIP(ctx, hipGetLastError());
       x_in = X0;
     }
-    rc = dense_dw(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, x_in, dz, s_t, nullptr, dW[t], db[t], 0, 0,
+    rc = dense_dw(ctx, st, n_edges, H, H, act, x_in, dz, s_t, nullptr, dW[t], db[t], 0, 0,
                   0, scratch, "edge_dense_dw");
     if (rc) return rc;
     if (t > 0) {
-      rc = dense_dx(ctx, st, n_edges, H, H, NG_ACT_SOFTPLUS, dz, s_t, nullptr, W[t], nullptr, dz_next,
+      rc = dense_dx(ctx, st, n_edges, H, H, act, dz, s_t, nullptr, W[t], nullptr, dz_next,
                     "edge_dense_dx");
       if (rc) return rc;
       std::swap(dz, dz_next);
@@ -309,35 +338,46 @@ extern "C" int ng_rbf_expand(ng_ctx* ctx, void* stream, int64_t n, int H, const 
   return NG_OK;
 }
 
-extern "C" int ng_edge_mlp_fwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
+// the fused kernels (edge_fused*.hip, edge_*_x3.hip) hard-wire softplus hidden layers and edge_feature_size <= 8;
+// fc_activation = relu (model.py:35-36) and edge_feature_size = 64 (model.py:23) run the layered path
+static bool use_fused(int H, int E, int Le, int act) {
+  return act == NG_ACT_SOFTPLUS && edge_fused_supported(H, E, Le) && !force_layered();
+}
+
+static int check_edge_shape(ng_ctx* ctx, int H, int E, int Le, int act) {
+  NG_REQUIRE(ctx, H % 16 == 0 && H <= 512, "edge_mlp: edge_hidden_size % 16 == 0, <= 512");
+  NG_REQUIRE(ctx, E >= 1 && (E <= MAX_E || (E % 4 == 0 && E <= 256)), "edge_mlp: edge_feature_size <= 8, or a multiple of 4 up to 256");
+  NG_REQUIRE(ctx, Le >= 2, "edge_mlp: edge_fc_layers >= 2");
+  NG_REQUIRE(ctx, act == NG_ACT_SOFTPLUS || act == NG_ACT_RELU || act == NG_ACT_TANH || act == NG_ACT_NONE,
+             "edge_mlp: unknown activation code");
+  return NG_OK;
+}
+
+extern "C" int ng_edge_mlp_fwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le, int act,
                                const float* d_src, const float* d_eff, const float* centers,
                                float gap, const float* const* W, const float* const* b,
                                float* e_out, float* z_save) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, H % 16 == 0 && H <= 512, "edge_mlp: edge_hidden_size % 16 == 0, <= 512");
-  NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "edge_mlp: edge_feature_size <= 8");
-  NG_REQUIRE(ctx, Le >= 2, "edge_mlp: edge_fc_layers >= 2");
+  if (int rc = check_edge_shape(ctx, H, E, Le, act)) return rc;
   NG_REQUIRE(ctx, gap > 0.f, "edge_mlp: rbf gap > 0");
   if (n_edges == 0) return NG_OK;
-  if (edge_fused_supported(H, E, Le) && !force_layered())
+  if (use_fused(H, E, Le, act))
     return edge_fused_fwd(ctx, (hipStream_t)stream, n_edges, E, d_src, d_eff, centers, gap, W, b,
                           e_out, z_save);
-  return edge_mlp_fwd_layered(ctx, (hipStream_t)stream, n_edges, H, E, Le, d_src, d_eff, centers,
+  return edge_mlp_fwd_layered(ctx, (hipStream_t)stream, n_edges, H, E, Le, act, d_src, d_eff, centers,
                               gap, W, b, e_out, z_save);
 }
 
-extern "C" int ng_edge_tape_layout(int H, int E, int Le, int64_t n_edges) {
-  return edge_fused_supported(H, E, Le) && !force_layered() && edge_tape_blocked(E, n_edges) ? 1 : 0;
+extern "C" int ng_edge_tape_layout(int H, int E, int Le, int act, int64_t n_edges) {
+  return use_fused(H, E, Le, act) && edge_tape_blocked(E, n_edges) ? 1 : 0;
 }
 
-extern "C" int ng_edge_mlp_bwd_tape(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
+extern "C" int ng_edge_mlp_bwd_tape(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le, int act,
                                     const float* d_src, const float* d_eff, const float* centers,
                                     float gap, const float* const* W, const float* z_save,
                                     const float* de, float* const* dW, float* const* db, int tape_layout) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, H % 16 == 0 && H <= 512, "edge_mlp: edge_hidden_size % 16 == 0, <= 512");
-  NG_REQUIRE(ctx, E >= 1 && E <= MAX_E, "edge_mlp: edge_feature_size <= 8");
-  NG_REQUIRE(ctx, Le >= 2, "edge_mlp: edge_fc_layers >= 2");
+  if (int rc = check_edge_shape(ctx, H, E, Le, act)) return rc;
   NG_REQUIRE(ctx, z_save, "edge_mlp_bwd: saved activations required");
   hipStream_t st = (hipStream_t)stream;
   if (n_edges == 0) {
@@ -348,16 +388,16 @@ extern "C" int ng_edge_mlp_bwd_tape(ng_ctx* ctx, void* stream, int64_t n_edges, 
     }
     return NG_OK;
   }
-  if (edge_fused_supported(H, E, Le) && !force_layered())
+  if (use_fused(H, E, Le, act))
     return edge_fused_bwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de, dW, db, tape_layout);
   NG_REQUIRE(ctx, tape_layout != 1, "edge_mlp_bwd: a blocked tape needs the fused edge path");
-  return edge_mlp_bwd_layered(ctx, st, n_edges, H, E, Le, d_src, d_eff, centers, gap, W, z_save, de,
+  return edge_mlp_bwd_layered(ctx, st, n_edges, H, E, Le, act, d_src, d_eff, centers, gap, W, z_save, de,
                               dW, db);
 }
 
-extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le,
+extern "C" int ng_edge_mlp_bwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H, int E, int Le, int act,
                                const float* d_src, const float* d_eff, const float* centers,
                                float gap, const float* const* W, const float* z_save,
                                const float* de, float* const* dW, float* const* db) {
-  return ng_edge_mlp_bwd_tape(ctx, stream, n_edges, H, E, Le, d_src, d_eff, centers, gap, W, z_save, de, dW, db, -1);
+  return ng_edge_mlp_bwd_tape(ctx, stream, n_edges, H, E, Le, act, d_src, d_eff, centers, gap, W, z_save, de, dW, db, -1);
 }

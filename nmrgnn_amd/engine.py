@@ -57,9 +57,8 @@ class Engine:
         self.Lf = hp.get('fc_layers')
         self.sigma = float(hp.get('noise'))
         self.use_dropout = bool(hp.get('dropout'))
-        if hp.get('fc_activation') != 'softplus':
-            # the edge MLP hidden activation is fixed to softplus in the kernels
-            raise NotImplementedError("fc_activation other than 'softplus' is not supported yet")
+        if hp.get('fc_activation') not in ACT or hp.get('mp_activation') not in ACT:
+            raise ValueError(f"unsupported activation {hp.get('fc_activation')!r} / {hp.get('mp_activation')!r}")
         self.fc_act = ACT[hp.get('fc_activation')]
         self.mp_act = ACT[hp.get('mp_activation')]
         self.params = ParamStore(hp, self.C, self.device, seed=seed)
@@ -121,11 +120,11 @@ class Engine:
         z_save = self._new(self.Le - 1, ne, H) if training else None
         # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
         # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
-        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, ne)) if training else 0
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if training else 0
         e = self._new(ne, E)
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, ptr(d_src), ptr(d_eff),
+        self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff),
                                      ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
                                      ptr(e), ptr(z_save)), "ng_edge_mlp_fwd")
         h0 = self._new(N, F)
@@ -240,7 +239,7 @@ class Engine:
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, ne, H, E, self.Le, ptr(b.edges), ptr(tp.d_eff),
+        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, ne, H, E, self.Le, self.fc_act, ptr(b.edges), ptr(tp.d_eff),
                                           ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
                                           ptr(de), ptr_array(dW), ptr_array(dB), tp.z_layout), "ng_edge_mlp_bwd")
         self.tape = None

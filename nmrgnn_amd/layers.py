@@ -48,6 +48,35 @@ def _glorot(shape, dev, gen):
     return ((torch.rand(*shape, generator=gen) * 2 - 1) * lim).to(dev)
 
 
+def get_regularizer(spec):
+    """tf.keras.regularizers.get for the cases a weight regulariser can take without Keras: None, a callable
+    (w -> scalar), 'l1' / 'l2' / 'l1_l2' (Keras default factor 0.01), or a Keras-style config dict
+    {'class_name': 'L1L2', 'config': {'l1': .., 'l2': ..}}.  Anything else raises, as Keras does."""
+    if spec is None or callable(spec):
+        return spec
+    l1 = l2 = 0.0
+    if isinstance(spec, str):
+        name = spec.lower()
+        if name not in ("l1", "l2", "l1_l2"):
+            raise ValueError(f"Could not interpret regularizer identifier: {spec!r}")
+        l1 = 0.01 if name in ("l1", "l1_l2") else 0.0
+        l2 = 0.01 if name in ("l2", "l1_l2") else 0.0
+    elif isinstance(spec, dict):
+        cfg = spec.get("config", spec)
+        l1, l2 = float(cfg.get("l1", 0.0) or 0.0), float(cfg.get("l2", 0.0) or 0.0)
+    else:
+        raise ValueError(f"Could not interpret regularizer identifier: {spec!r}")
+
+    def reg(w):
+        out = 0.0
+        if l1:
+            out = out + l1 * w.abs().sum()
+        if l2:
+            out = out + l2 * (w * w).sum()
+        return out
+    return reg
+
+
 class _Layer:
     _seed = 0
 
@@ -98,7 +127,9 @@ class MPLayer(_Layer):
         if activation not in ACT:
             raise ValueError(f"unsupported activation {activation!r}")
         self.activation, self.name = activation, name
-        self.mpl_regularizer = kernel_regularizer   # accepted for signature parity; not applied
+        # layers.py:9,44-45: every call adds regularizer(w) to the layer's losses (keras add_loss)
+        self.mpl_regularizer = get_regularizer(kernel_regularizer)
+        self.losses = []
         self.w = None
 
     def get_config(self):
@@ -123,6 +154,8 @@ class MPLayer(_Layer):
                                           1 if residual else 0, ptr(nodes), ptr(nlist), ptr(edges),
                                           ptr(inv), ptr(self.w), ptr(out), None, None),
                   "ng_mp_layer_fwd")
+        if self.mpl_regularizer is not None:          # layers.py:44-45
+            self.losses = [self.mpl_regularizer(self.w)]
         return out
 
 

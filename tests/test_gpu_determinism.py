@@ -26,7 +26,7 @@ def test_edge_forward_is_bitwise_reproducible(gpu_device, n_edges, train):
     def run():
         e = torch.empty(n_edges, 3, device=gpu_device)
         z = torch.empty(3, n_edges, 128, device=gpu_device) if train else None
-        eng._ck(eng.lib.ng_edge_mlp_fwd(eng.ctx.handle, eng._st(), n_edges, 128, 3, 4, ptr(d), ptr(d), ptr(eng.centers),
+        eng._ck(eng.lib.ng_edge_mlp_fwd(eng.ctx.handle, eng._st(), n_edges, 128, 3, 4, 1, ptr(d), ptr(d), ptr(eng.centers),
                                         eng.gap, ptr_array(W), ptr_array(B), ptr(e), ptr(z)), "edge fwd")
         return e, z
 

@@ -42,7 +42,7 @@ def tape_perm(n):
 
 def tape_layout(E, n):
     from nmrgnn_amd import _lib
-    return int(_lib.get_context(0).lib.ng_edge_tape_layout(H, E, 4, n))
+    return int(_lib.get_context(0).lib.ng_edge_tape_layout(H, E, 4, 1, n))
 
 
 def run_gpu(dev, d_src, d_eff, centers, gap, Ws, bs, E, save):
@@ -57,7 +57,7 @@ def run_gpu(dev, d_src, d_eff, centers, gap, Ws, bs, E, save):
     z = torch.full((3, n, H), 7.0, device=dev) if save else None
     ctx = _lib.get_context(0)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    ctx.check(ctx.lib.ng_edge_mlp_fwd(ctx.handle, st, n, H, E, 4, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
+    ctx.check(ctx.lib.ng_edge_mlp_fwd(ctx.handle, st, n, H, E, 4, 1, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
                                       ptr_array(tb), ptr(e), ptr(z)), "ng_edge_mlp_fwd")
     torch.cuda.synchronize()
     zz = None
@@ -142,7 +142,7 @@ def run_gpu_bwd(dev, d_src, d_eff, centers, gap, Ws, zs, de, E):
     db = [torch.full((H,), 7.0, device=dev) for _ in range(3)] + [torch.full((E,), 7.0, device=dev)]
     ctx = _lib.get_context(0)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    ctx.check(ctx.lib.ng_edge_mlp_bwd(ctx.handle, st, n, H, E, 4, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
+    ctx.check(ctx.lib.ng_edge_mlp_bwd(ctx.handle, st, n, H, E, 4, 1, ptr(td), ptr(te), ptr(tc), float(gap), ptr_array(tW),
                                       ptr(tz), ptr(tde), ptr_array(dW), ptr_array(db)), "ng_edge_mlp_bwd")
     torch.cuda.synchronize()
     return [w.cpu().numpy().astype(np.float64) for w in dW], [b.cpu().numpy().astype(np.float64) for b in db]

@@ -18,6 +18,15 @@ CONFIGS = [
     dict(atom_feature_size=256, edge_feature_size=3, edge_hidden_size=128),  # bundled-model arch
     dict(atom_feature_size=128, edge_feature_size=8, edge_hidden_size=64, mp_layers=1,
          fc_layers=2, edge_fc_layers=2),
+    # the other choices of the reference's hyper-parameter space (nmrgnn/model.py:23,33-36)
+    dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, fc_activation='relu',
+         mp_activation='tanh'),
+    dict(atom_feature_size=128, edge_feature_size=8, edge_hidden_size=128, fc_activation='relu',
+         mp_activation='relu', mp_layers=2),
+    dict(atom_feature_size=32, edge_feature_size=64, edge_hidden_size=64, mp_layers=2, fc_layers=2,
+         edge_fc_layers=3),
+    dict(atom_feature_size=256, edge_feature_size=64, edge_hidden_size=128, mp_layers=1, fc_layers=2,
+         edge_fc_layers=2, fc_activation='relu'),
 ]
 
 

@@ -15,7 +15,7 @@ def run(ne, train, d):
     st = eng._st()
     e = torch.empty(ne, 3, device=dev)
     z = torch.empty(3, ne, 128, device=dev) if train else None
-    eng._ck(lib.ng_edge_mlp_fwd(h, st, ne, 128, 3, 4, ptr(d), ptr(d), ptr(eng.centers), eng.gap, ptr_array(W), ptr_array(B), ptr(e), ptr(z)), "f")
+    eng._ck(lib.ng_edge_mlp_fwd(h, st, ne, 128, 3, 4, 1, ptr(d), ptr(d), ptr(eng.centers), eng.gap, ptr_array(W), ptr_array(B), ptr(e), ptr(z)), "f")
     return e, z
 rng = np.random.default_rng(0)
 for ne in (3159, 3904, 100000, 2097152):
