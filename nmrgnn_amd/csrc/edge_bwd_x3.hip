@@ -67,7 +67,8 @@ struct EdgeBwdX3Args {
   float neg_inv_gap_log2e;
   const char* wt_img;   // [2 layers (W2, W3)][4 k-slabs][8 k-steps][3 pieces][1 KB]
   const float* Wo;      // [128][E]
-  const float* z_save;  // [3][n_edges][128]
+  const float* z_save;  // [3][z_layer_stride / 128 edges][128], first edge of THIS launch's segment
+  int64_t z_layer_stride;  // floats between the layers of the tape (= total edges * 128; a launch covers one segment)
   const float* de;      // [n_edges][E]
   float* partial;       // [grid][part_stride], layout of edge_fused_bwd.hip
   int part_stride;
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
   // one buffer resource per array (offsets are 32-bit: n_edges * 512 B < 4 GB, checked by the host)
   const unsigned zbytes = (unsigned)(a.n_edges * FH * 4);
   const __amdgpu_buffer_rsrc_t rsZ1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save), 0, zbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsZ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + a.n_edges * FH), 0, zbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsZ3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + 2 * a.n_edges * FH), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + a.z_layer_stride), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + 2 * a.z_layer_stride), 0, zbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_src), 0, (unsigned)(a.n_edges * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsDn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_eff), 0, (unsigned)(a.n_edges * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsDe = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.de), 0, (unsigned)(a.n_edges * a.E * 4), 0x00020000);
@@ -471,7 +472,13 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
 }
 
-bool edge_bwd_x3_supported(int E, int64_t n_edges) { return E >= 1 && E <= 4 && n_edges * FH * 4 < ((int64_t)1 << 32); }
+// Buffer offsets inside the kernel are 32-bit (one resource per array, 512 B of tape per edge), so one LAUNCH covers
+// at most BX_SEG_EDGES edges; longer edge lists run as several launches over consecutive segments (a multiple of the
+// 64-edge tile and of the 32-edge tape group), each with its own rows of the partial buffer.
+constexpr int64_t BX_SEG_EDGES = ((int64_t)1 << 23) - 256;
+int edge_bwd_x3_segments(int64_t n_edges) { return (int)std::max<int64_t>(1, cdiv(n_edges, BX_SEG_EDGES)); }
+
+bool edge_bwd_x3_supported(int E, int64_t n_edges) { (void)n_edges; return E >= 1 && E <= 4; }
 
 bool edge_tape_blocked(int E, int64_t n_edges) {
   return edge_x3_enabled() && !sw().edge_bwd_math_fp32 && edge_bwd_x3_supported(E, n_edges);
@@ -479,17 +486,20 @@ bool edge_tape_blocked(int E, int64_t n_edges) {
 
 size_t edge_bwd_x3_ws_bytes() { return (size_t)2 * 4 * 8 * 3 * 1024; }
 
-// wt_img: edge_bwd_x3_ws_bytes() of scratch; partial / stride / grid as in edge_fused_bwd()
+// wt_img: edge_bwd_x3_ws_bytes() of scratch; partial: [edge_bwd_x3_segments(n_edges) * grid][part_stride]
 int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
                        char* wt_img, float* partial, int part_stride, int grid, int tape_blocked) {
   hipLaunchKernelGGL(x3_pack_wt_kernel, dim3(16), dim3(256), 0, st, W[1], W[2], (unsigned*)wt_img);
   NG_HIP(ctx, hipGetLastError());
+  const int nseg = edge_bwd_x3_segments(n_edges);
+  for (int sg = 0; sg < nseg; ++sg) {
+  const int64_t e0 = (int64_t)sg * BX_SEG_EDGES;
   EdgeBwdX3Args a;
-  a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
+  a.n_edges = std::min<int64_t>(BX_SEG_EDGES, n_edges - e0); a.d_src = d_src + e0; a.d_eff = d_eff + e0; a.centers = centers;
   a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
-  a.wt_img = wt_img; a.Wo = W[3]; a.z_save = z_save; a.de = de;
-  a.partial = partial; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;
+  a.wt_img = wt_img; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH; a.de = de + e0 * E;
+  a.partial = partial + (size_t)sg * grid * part_stride; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;
   a.stamps = nullptr;
 #ifdef BX_STAMP
   static unsigned long long* dbg = nullptr;
@@ -499,6 +509,7 @@ int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
   ProfScope ps(ctx, st, "edge_bwd_x3");
   hipLaunchKernelGGL(edge_bwd_x3_kernel, dim3(grid), dim3(BX_THREADS), BX_LDS_BYTES, st, a);
   NG_HIP(ctx, hipGetLastError());
+  if (sg + 1 < nseg) continue;
 #ifdef BX_STAMP
   {
     static int calls = 0;
@@ -516,6 +527,7 @@ int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     }
   }
 #endif
+  }
   return NG_OK;
 }
 

@@ -42,6 +42,7 @@ int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
 namespace ng {
 // backward on the bf16 matrix pipe with split operands (edge_bwd_x3.hip); partial layout of edge_fused_bwd.hip
 bool edge_bwd_x3_supported(int E, int64_t n_edges);
+int edge_bwd_x3_segments(int64_t n_edges);
 // Layout of the saved-activation tape z_save[Le-1][n_edges][128] between the edge forward and backward:
 // false: row-major.  true (both directions run the split-operand kernels): inside every FULL group of 32 consecutive
 // edges the 32 x 128 block is stored in the kernels' register layout, float index ((bo*4 + q)*64 + hf*32 + r)*4 + j for

@@ -371,7 +371,8 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
   const size_t pk_floats = (size_t)3 * FH * FH;
-  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)grid * stride) * 4 + edge_bwd_x3_ws_bytes());
+  const int nseg = edge_bwd_x3_segments(n_edges);      // launches of the split-operand kernel (1 below 8.4 M edges)
+  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)nseg * grid * stride) * 4 + edge_bwd_x3_ws_bytes());
   if (!ws) return NG_ERR_NOMEM;
   float* Wpk = ws;
   float* WpkT = ws + pk_floats;
@@ -390,10 +391,12 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   // now.  A blocked tape can only be read by the split-operand kernel; that kernel reads row-major tapes as well.
   const bool blocked = tape_layout < 0 ? edge_tape_blocked(E, n_edges) : tape_layout == 1;
   if (blocked && !edge_bwd_x3_supported(E, n_edges)) return fail(ctx, NG_ERR_INVALID, "edge_mlp_bwd: blocked tape for an unsupported shape");
+  int n_part = grid;
   if (blocked || edge_tape_blocked(E, n_edges)) {
     int rc3 = edge_bwd_x3_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
-                                 (char*)(partial + (size_t)grid * stride), partial, stride, grid, blocked ? 1 : 0);
+                                 (char*)(partial + (size_t)nseg * grid * stride), partial, stride, grid, blocked ? 1 : 0);
     if (rc3) return rc3;
+    n_part = nseg * grid;
   } else {
     ProfScope ps(ctx, st, "edge_fused_bwd");
 #define NG_BW(EE)                                                                                   \
@@ -410,7 +413,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
     for (int l = 0; l < 3; ++l) { o.dW[l] = dW[l]; o.db[l] = db[l]; }
     o.dWo = dW[3]; o.dbo = db[3];
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((unsigned)cdiv(bwd_part_floats(E), 64)), dim3(1024), 0, st,
-                       partial, grid, stride, E, o);
+                       partial, n_part, stride, E, o);
     NG_HIP(ctx, hipGetLastError());
   }
   return NG_OK;

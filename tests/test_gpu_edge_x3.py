@@ -191,3 +191,56 @@ def test_edge_backward_split_vs_float64(gpu_device, monkeypatch, n, E):
             err = {mth: np.abs(o[k][l] - ref).max() / scale for mth, o in out.items()}
             assert err["bf16x3"] < 1e-6, (name, l, err)                 # ~16 fp32 roundings of the term scale
             assert err["bf16x3"] < 4.0 * err["fp32"] + 1e-7, (name, l, err)
+
+
+def test_edge_backward_beyond_one_launch_segment(gpu_device):
+    """Edge lists longer than 2^23 - 256 edges (the 32-bit buffer offsets of one split-operand launch: the 1-GPU point
+    of a 4096-graph strong-scaling run has 16.8 M edges) run as several launches of the SAME kernel.  Size-independent
+    property: the weight gradients are sums over edges, so the gradients of the whole list equal the sum of the
+    gradients of its two halves (each below the segment size), and the tape layout stays blocked."""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr, ptr_array
+    dev = gpu_device
+    n = (1 << 23) + 70001                       # 2 segments, ragged last tile and last 32-group
+    E = 3
+    assert tape_layout(E, n) == 1
+    g = torch.Generator(device="cpu").manual_seed(1)
+    d = (torch.rand(n, generator=g) * 0.45 + 0.05)
+    d[torch.rand(n, generator=g) < 0.1] = 0.0
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    centers = np.linspace(0.005, 0.2, H).astype(np.float32)
+    gap = float(centers[1] - centers[0])
+    Ws = [t(rng.standard_normal((H, H)) * 0.15) for _ in range(3)] + [t(rng.standard_normal((H, E)) * 0.2)]
+    bs = [t(rng.standard_normal(H) * 0.1) for _ in range(3)] + [t(rng.standard_normal(E) * 0.1)]
+    td, tc = d.to(dev), t(centers)
+    tde = torch.randn(n, E, generator=g).to(dev)
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def fwd_bwd(lo, hi):
+        m = hi - lo
+        e = torch.empty(m, E, device=dev)
+        z = torch.empty(3, m, H, device=dev)
+        dd, de = td[lo:hi].contiguous(), tde[lo:hi].contiguous()
+        ctx.check(ctx.lib.ng_edge_mlp_fwd(ctx.handle, st, m, H, E, 4, 1, ptr(dd), ptr(dd), ptr(tc), gap, ptr_array(Ws),
+                                          ptr_array(bs), ptr(e), ptr(z)), "fwd")
+        dW = [torch.empty(H, H, device=dev) for _ in range(3)] + [torch.empty(H, E, device=dev)]
+        db = [torch.empty(H, device=dev) for _ in range(3)] + [torch.empty(E, device=dev)]
+        ctx.check(ctx.lib.ng_edge_mlp_bwd(ctx.handle, st, m, H, E, 4, 1, ptr(dd), ptr(dd), ptr(tc), gap, ptr_array(Ws),
+                                          ptr(z), ptr(de), ptr_array(dW), ptr_array(db)), "bwd")
+        torch.cuda.synchronize()
+        return e, [w.double() for w in dW], [b.double() for b in db]
+
+    cut = 4 * 1024 * 1024 + 96                    # a multiple of 32: both halves keep whole tape groups
+    e_all, dW_all, db_all = fwd_bwd(0, n)
+    e_a, dW_a, db_a = fwd_bwd(0, cut)
+    e_b, dW_b, db_b = fwd_bwd(cut, n)
+    assert torch.equal(e_all[:cut], e_a) and torch.equal(e_all[cut:], e_b)          # per-edge results do not move
+    for l in range(4):
+        for whole, a, b in ((dW_all[l], dW_a[l], dW_b[l]), (db_all[l], db_a[l], db_b[l])):
+            ref = a + b
+            scale = max(float(a.abs().max() + b.abs().max()), 1e-6)
+            # fp32 accumulation over 8.5 M edges in a different partition (512 instead of 2 x 256 partial sums)
+            assert float((whole - ref).abs().max()) / scale < 2e-5, l
