@@ -1,14 +1,18 @@
 #!/usr/bin/env python
 """bench.py — atoms/s (fwd+bwd+Adam) of the nmrgnn message-passing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong --total-graphs G]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Without a torchrun environment `--gpus N` (N > 1) re-executes itself under torch.distributed.run on 127.0.0.1 with N
+ranks; a world size different from --gpus, or a backend other than nccl (= RCCL), is an error, not a warning.
 
 Workload (BASELINE.json configs[2]/[3]): per GPU 512 synthetic graphs x 256 atoms
 (N = 131,072 atom rows), K = 16 neighbours, F = 64, E = 3, H = 128, 4 MP / 4 edge-FC / 4 FC layers,
 fp32, noise + dropout on, weighted-MSE NameLoss (s = 1), Adam(lr 1e-4).  One "step" = forward +
 loss + backward + gradient all-reduce (N > 1) + Adam over one batch already resident in HBM.
-Weak scaling: per-GPU work is fixed; ranks hold different graphs (seed 42 + rank).
+Weak scaling (default): per-GPU work is fixed; ranks hold different graphs (seed 42 + rank).
+Strong scaling (--scaling strong --total-graphs 4096, the north star's 8-GPU configuration): the total is fixed and
+rank r holds the contiguous shard parallel.shard_range(total, r, world) of the same 4096 graphs.
 
 Prints ONE JSON line on rank 0 with `value` = whole-job atoms/s, plus
   roofline     — dominant kernel: algorithmic flops per launch / its mean launch duration
@@ -16,6 +20,8 @@ Prints ONE JSON line on rank 0 with `value` = whole-job atoms/s, plus
   roofline_all — the same for every profiled kernel (HBM-bound ones against 8 TB/s)
   cpu_baseline — the reference's op order restated in torch-CPU fp32 (oracle/torch_ref.py; TensorFlow
                  is not installed) timed on this box's host cores on a bounded sample of the workload.
+  f256         — the same step at the reference's DEFAULT width (atom_feature_size 256) with its own roofline row
+  configs4     — whole-protein inference (7lgi, 100 jittered frames, GPU graph build + model, F = 256)
 """
 import argparse
 import json
@@ -183,15 +189,142 @@ def cpu_baseline(hp_dict, sample_graphs, seed, budget_s=20.0):
             "ms_per_step": med * 1e3}
 
 
+# kernels whose generic GEMM runs on the bf16 pipe with split operands when the shape allows (gemm_x3.hip)
+X3_GEMM_TAGS = {"mp_update_fwd", "mp_dw", "mp_dA", "dense_fwd", "dense_dx", "dense_dw", "edge_dense_fwd",
+                "edge_dense_dx", "edge_dense_dw"}
+# kernel tag -> the source files whose content decides whether a committed PMC number still describes it
+KERNEL_SOURCES = {
+    "edge_fwd_x3": ["edge_fwd_x3.hip", "x3_common.cuh"], "edge_bwd_x3": ["edge_bwd_x3.hip", "x3_common.cuh"],
+    "edge_fused_fwd": ["edge_fused.hip"], "edge_fused_bwd": ["edge_fused_bwd.hip"],
+    "mp_win_fwd": ["mp_win.hip"], "mp_win_bwd_edge": ["mp_win_bwd.hip"], "mp_win_bwd_node": ["mp_win_bwd.hip"],
+    "fc_fused_fwd": ["fc_fused.hip"], "fc_fused_bwd": ["fc_fused.hip"],
+}
+
+
+def source_digest(kernel):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES.get(kernel, []):
+        with open(os.path.join(ROOT, "nmrgnn_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_lookup(kernel):
+    """(traffic bytes per launch, matrix-pipe busy share, note) from the rocprofv3 PMC passes committed under
+    profiles/ (tools/pmc_traffic.sh, tools/pmc_mfma.sh).  The files carry the digest of the kernel sources they were
+    collected on; a number whose kernel has changed since is NOT printed."""
+    traffic = busy = None
+    notes = []
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        meta = pmc.get("_meta", {})
+        ent = pmc.get(kernel)
+        if ent:
+            if meta.get("source_digest", {}).get(kernel) == source_digest(kernel):
+                # FETCH_SIZE doubled as the MI355X guide prescribes for wide coalesced reads on gfx950
+                traffic = 2.0 * ent["FETCH_SIZE_KB"] * 1024 + ent["WRITE_SIZE_KB"] * 1024
+                notes.append(f"traffic: profiles/pmc_traffic.json @ {meta.get('commit', '?')}")
+            else:
+                notes.append("traffic: committed PMC pass predates the current kernel source (stale, not shown)")
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_mfma.json")) as f:
+            pm = json.load(f)
+        meta = pm.get("_meta", {})
+        if meta.get("source_digest", {}).get(kernel) == source_digest(kernel):
+            for kname, v in pm.items():
+                if kname != "_meta" and kernel + "_kernel" in kname and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+                    busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+                    notes.append(f"mfma_pipe_busy: profiles/pmc_mfma.json @ {meta.get('commit', '?')}")
+        elif kernel in meta.get("source_digest", {}):
+            notes.append("mfma_pipe_busy: committed PMC pass predates the current kernel source (stale, not shown)")
+    except Exception:
+        pass
+    return traffic, busy, "; ".join(notes) or None
+
+
+def roofline_rows(prof, psteps, work, x3_gemm):
+    rows = []
+    for name, (tot_ms, cnt) in prof.items():
+        avg_ms = tot_ms / max(cnt, 1)
+        row = {"kernel": name, "launches_per_step": cnt / psteps, "avg_ms": avg_ms, "ms_per_step": tot_ms / psteps}
+        if name in work and avg_ms > 0:
+            bound, fl, by = work[name]
+            if bound == "mfma":
+                ach = fl / (avg_ms * 1e-3) / 1e12
+                on_x3 = name in X3_KERNELS or (x3_gemm and name in X3_GEMM_TAGS)
+                peak = PEAK_MFMA_BF16_TFLOPS / 6.0 if on_x3 else PEAK_MFMA_F32_TFLOPS
+                row.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
+                if on_x3:
+                    row["peak_note"] = "fp32-equivalent: bf16 dense peak 2516.6 / 6 piece products"
+            else:
+                ach = by / (avg_ms * 1e-3) / 1e9
+                row.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def profiled_steps(eng, step_fn, psteps):
+    eng.ctx.prof_reset()
+    eng.ctx.prof_enable(True)
+    for _ in range(psteps):
+        step_fn()
+    torch.cuda.synchronize()
+    prof = eng.ctx.prof_read()
+    eng.ctx.prof_enable(False)
+    eng.ctx.prof_reset()
+    return prof
+
+
+def event_timed(step_fn, n):
+    """per-step durations (ms) from hipEvents on the launch stream (the engine launches on torch's current stream)"""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    evs[0].record()
+    for i in range(n):
+        step_fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graphs", type=int, default=GRAPHS_PER_GPU, help="graphs per GPU")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--graphs", type=int, default=GRAPHS_PER_GPU, help="graphs per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--total-graphs", type=int, default=4096, help="graphs over all GPUs (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inference / fp32 / F=256 / configs[4] legs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
 
     from nmrgnn_amd import _lib, parallel, synth
     from nmrgnn_amd.engine import Engine
@@ -201,21 +334,52 @@ def main():
 
     world, rank, local = parallel.init_distributed()
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    backend = dist.get_backend() if world > 1 else None
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
+        if backend != "nccl" and os.environ.get("NMRGNN_DIST_BACKEND") != backend:
+            print(f"bench.py: torch.distributed backend is {backend!r}, expected 'nccl' (RCCL)", file=sys.stderr)
+            sys.exit(2)
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
+        sys.exit(2)
     local = local % torch.cuda.device_count()      # (ranks may share a GPU only in the gloo smoke test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     hp = declare_gnn_space(HyperParameters(**ARCH))
     eng = Engine(hp, NUM_ELEM, device=dev, seed=1234)          # same weights on every rank
-    b = synth.make_batch(args.graphs, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM, 0.05, seed=42 + rank)
-    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"],
-                    device=dev)
+    if args.scaling == "strong":
+        # the SAME total_graphs graphs whatever the world size; this rank's contiguous shard
+        lo, hi = parallel.shard_range(args.total_graphs, rank, world)
+        full = synth.make_batch(args.total_graphs, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM, 0.05, seed=42)
+        a, z = lo * ATOMS_PER_GRAPH, hi * ATOMS_PER_GRAPH
+        b = dict(atoms=full["atoms"][a:z], nlist=full["nlist"][a:z] - a, edges=full["edges"][a:z],
+                 inv_degree=full["inv_degree"][a:z], graph_ptr=full["graph_ptr"][lo:hi + 1] - a, y=full["y"][a:z],
+                 w=full["w"][a:z])
+        total_graphs = args.total_graphs
+        del full
+    else:
+        b = synth.make_batch(args.graphs, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM, 0.05, seed=42 + rank)
+        total_graphs = args.graphs * world
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=dev)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter() - t0
+    t0 = time.perf_counter()
     gb.csc()
+    torch.cuda.synchronize()
+    t_csc = time.perf_counter() - t0
     y = torch.from_numpy(b["y"]).to(dev)
     w = torch.from_numpy(b["w"]).to(dev)
     tr = Trainer(eng, lr=1e-4)
+    tr.measure_comm = world > 1
+
+    def step():
+        return tr.step(gb, y, w, total_graphs=total_graphs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,32 +388,52 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        loss = tr.step(gb, y, w)
+        loss = step()
+    tr.comm_exposed_ms()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.step(gb, y, w)
+        loss = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    rank_ms = [elapsed_local / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
+    comm_ms = tr.comm_exposed_ms()
     ms_per_step = elapsed / args.steps * 1e3
-    atoms_total = gb.N * world
+    atoms_local = gb.N
+    atoms_total = total_graphs * ATOMS_PER_GRAPH
     value = atoms_total * args.steps / elapsed
     final_loss = float(loss.cpu())
+    # hipEvent per-step times (median over the timed steps), after the contract's wall-clock bracket
+    ev_ms = event_timed(step, args.steps)
+    barrier()
 
     out = {
         "metric": "atoms/s (fwd+bwd) on 256-atom/16-neighbor synthetic graphs",
         "value": value, "unit": "atoms/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[2]: training step (fwd+loss+bwd+Adam) on {args.graphs} "
-                               f"graphs x {ATOMS_PER_GRAPH} atoms per GPU, K={K_NEIGH}, F=64, E=3, "
-                               f"H=128, 4 MP / 4 edge-FC / 4 FC layers, noise+dropout on",
-                   "atoms_per_gpu": gb.N, "edges_per_gpu": gb.N * K_NEIGH,
-                   "parallelism": f"graph-parallel dp{world}", "params": eng.params.count()},
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"configs[2]/[3]: training step (fwd+loss+bwd+all-reduce+Adam) on "
+                                + (f"{args.total_graphs} graphs in total" if args.scaling == "strong"
+                                   else f"{args.graphs} graphs per GPU")
+                                + f" x {ATOMS_PER_GRAPH} atoms, K={K_NEIGH}, F=64, E=3, H=128, 4 MP / 4 edge-FC / 4 FC "
+                                  f"layers, noise+dropout on"),
+                   "atoms_total": atoms_total, "atoms_this_rank": atoms_local, "edges_this_rank": gb.n_edges,
+                   "parallelism": f"graph-parallel dp{world}", "params": eng.params.count(),
+                   "backend": backend},
+        "ms_per_step_hipevent_median": float(np.median(ev_ms)),
+        "ms_per_step_hipevent_min": float(np.min(ev_ms)),
+        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+        "allreduce_exposed_ms": comm_ms,
+        "preprocess_ms": {"h2d_and_lists": t_h2d * 1e3, "incoming_edge_lists_csc": t_csc * 1e3,
+                          "note": "per-batch graph preprocessing outside the timed step (the batch is resident); "
+                                  "a real epoch pays it once per batch"},
         "loss": final_loss,
         "matrix_math": ("edge MLP forward and backward: bf16 MFMA on fp32 operands split exactly into 3 bf16 pieces, "
                         "6 piece products per multiply, fp32 accumulate (fp32-level error, tests/test_gpu_edge_x3.py); "
@@ -259,107 +443,94 @@ def main():
 
     # ---- per-kernel hipEvent pass (same step, events bracketed inside the C library).  EVERY rank runs the
     # steps — they contain the gradient all-reduce, a collective — only rank 0 reads the events.
-    prof = None
     psteps = min(args.steps, 5)
     if not args.no_profile:
         torch.cuda.synchronize()
         if rank == 0:
-            eng.ctx.prof_reset()
-            eng.ctx.prof_enable(True)
-        for _ in range(psteps):
-            tr.step(gb, y, w)
-        torch.cuda.synchronize()
+            prof = profiled_steps(eng, step, psteps)
+        else:
+            for _ in range(psteps):
+                step()
+            torch.cuda.synchronize()
+            prof = None
         if rank == 0:
-            prof = eng.ctx.prof_read()
-            eng.ctx.prof_enable(False)
-            eng.ctx.prof_reset()
-    if rank == 0 and prof is not None:
-        work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM)
-        rows = []
-        for name, (tot_ms, cnt) in prof.items():
-            avg_ms = tot_ms / max(cnt, 1)
-            row = {"kernel": name, "launches_per_step": cnt / psteps, "avg_ms": avg_ms,
-                   "ms_per_step": tot_ms / psteps}
-            if name in work and avg_ms > 0:
-                bound, fl, by = work[name]
-                if bound == "mfma":
-                    ach = fl / (avg_ms * 1e-3) / 1e12
-                    peak = PEAK_MFMA_BF16_TFLOPS / 6.0 if name in X3_KERNELS else PEAK_MFMA_F32_TFLOPS
-                    row.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
-                    if name in X3_KERNELS:
-                        row["peak_note"] = "fp32-equivalent: bf16 dense peak 2516.6 / 6 piece products"
-                else:
-                    ach = by / (avg_ms * 1e-3) / 1e9
-                    row.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
-                               frac=ach / PEAK_HBM_GBS)
-            rows.append(row)
-        rows.sort(key=lambda r: -r["ms_per_step"])
-        out["roofline_all"] = rows
-        dom = next((r for r in rows if "bound" in r), None)
-        if dom is not None:
-            # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (separate
-            # --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled as the
-            # MI355X guide prescribes for wide coalesced reads on gfx950); null when not collected
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    pmc = json.load(f).get(dom["kernel"])
-                if pmc:
-                    traffic = 2.0 * pmc["FETCH_SIZE_KB"] * 1024 + pmc["WRITE_SIZE_KB"] * 1024
-            except Exception:
-                pass
-            # matrix-pipe utilisation of the same kernel from the PMC pass (tools/pmc_mfma.sh -> profiles/pmc_mfma.json):
-            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD * SIMDs); null when not collected
-            mfma_busy = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_mfma.json")) as f:
-                    for kname, v in json.load(f).items():
-                        if dom["kernel"] + "_kernel" in kname and v.get("GRBM_GUI_ACTIVE", 0) > 0:
-                            mfma_busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
-            except Exception:
-                pass
-            alg = work[dom["kernel"]]
-            out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"],
-                               "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                               "frac": dom["frac"], "traffic": traffic, "mfma_pipe_busy": mfma_busy,
-                               "algorithmic_bytes": alg[2], "algorithmic_flops": alg[1],
-                               "avg_launch_ms": dom["avg_ms"]}
-        out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
+            work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM)
+            rows = roofline_rows(prof, psteps, work, x3_gemm=False)
+            out["roofline_all"] = rows
+            dom = next((r for r in rows if "bound" in r), None)
+            if dom is not None:
+                traffic, mfma_busy, note = pmc_lookup(dom["kernel"])
+                alg = work[dom["kernel"]]
+                out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
+                                   "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic,
+                                   "mfma_pipe_busy": mfma_busy, "pmc_note": note, "algorithmic_bytes": alg[2],
+                                   "algorithmic_flops": alg[1], "avg_launch_ms": dom["avg_ms"]}
+            out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
 
+    extras = rank == 0 and world == 1 and not args.no_extras
     # ---- configs[1]: the same batch, inference only (no noise / dropout / tape), reported beside the headline
-    if rank == 0 and world == 1:
+    if extras:
         for _ in range(2):
             eng.forward(gb)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         isteps = max(5, args.steps // 2)
-        for _ in range(isteps):
-            eng.forward(gb)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / isteps
-        out["inference"] = {"workload": "configs[1]: forward only on the same batch", "value": gb.N / dt,
-                            "unit": "atoms/s", "ms_per_step": dt * 1e3, "steps": isteps}
+        ms = event_timed(lambda: eng.forward(gb), isteps)
+        out["inference"] = {"workload": "configs[1]: forward only on the same batch", "value": gb.N / (np.median(ms) * 1e-3),
+                            "unit": "atoms/s", "ms_per_step": float(np.median(ms)), "steps": isteps}
 
-    # ---- the same step with the f32-input MFMA edge forward (NG_EDGE_MATH=fp32), for comparison
-    if rank == 0 and world == 1 and os.environ.get("NG_EDGE_MATH", "") != "fp32":
+    # ---- the same step with the f32-input MFMA edge kernels (NG_EDGE_MATH=fp32), for comparison
+    if extras and os.environ.get("NG_EDGE_MATH", "") != "fp32":
         keep = os.environ.get("NG_EDGE_MATH")
         os.environ["NG_EDGE_MATH"] = "fp32"
         _lib.reload_env()
         for _ in range(2):
-            tr.step(gb, y, w)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+            step()
         fsteps = max(5, args.steps // 2)
-        for _ in range(fsteps):
-            tr.step(gb, y, w)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / fsteps
-        out["fp32_mfma_only"] = {"value": gb.N / dt, "unit": "atoms/s", "ms_per_step": dt * 1e3, "steps": fsteps}
+        ms = event_timed(step, fsteps)
+        out["fp32_mfma_only"] = {"value": gb.N / (np.median(ms) * 1e-3), "unit": "atoms/s",
+                                 "ms_per_step": float(np.median(ms)), "steps": fsteps}
         if keep is None:
             del os.environ["NG_EDGE_MATH"]
         else:
             os.environ["NG_EDGE_MATH"] = keep
         _lib.reload_env()
+
+    # ---- the reference's DEFAULT width (atom_feature_size = 256, model.py:22): same batch, same step
+    if extras:
+        try:
+            arch256 = dict(ARCH, atom_feature_size=256)
+            eng2 = Engine(declare_gnn_space(HyperParameters(**arch256)), NUM_ELEM, device=dev, seed=1234)
+            tr2 = Trainer(eng2, lr=1e-4)
+            step2 = lambda: tr2.step(gb, y, w)
+            for _ in range(3):
+                step2()
+            fsteps = max(5, args.steps // 5)
+            ms = event_timed(step2, fsteps)
+            blk = {"workload": "the same batch and step at atom_feature_size = 256 (reference default architecture, "
+                               "1,070,477 parameters)", "value": gb.N / (np.median(ms) * 1e-3), "unit": "atoms/s",
+                   "ms_per_step": float(np.median(ms)), "steps": fsteps}
+            if not args.no_profile:
+                prof2 = profiled_steps(eng2, step2, 3)
+                rows2 = roofline_rows(prof2, 3, kernel_work(gb.N, K_NEIGH, 256, 3, 128, 4, 4, 4, NUM_ELEM),
+                                      x3_gemm=os.environ.get("NG_GEMM_MATH", "") != "fp32")
+                blk["roofline_all"] = rows2
+                dom2 = next((r for r in rows2 if "bound" in r), None)
+                if dom2 is not None:
+                    blk["roofline"] = {k: dom2[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms")}
+            ms = event_timed(lambda: eng2.forward(gb), 5)
+            blk["inference_ms_per_step"] = float(np.median(ms))
+            blk["inference_value"] = gb.N / (np.median(ms) * 1e-3)
+            out["f256"] = blk
+            del eng2, tr2
+        except Exception as ex:
+            out["f256"] = {"error": repr(ex)}
+
+    # ---- configs[4]: whole-protein inference, 100-frame synthetic trajectory of 7lgi (frame 0 + N(0, 0.3 A), seed 7),
+    # GPU graph build + model at the baseline architecture, kNN (padded) and distance-cutoff (CSR) lists
+    if extras:
+        try:
+            out["configs4"] = whole_protein_leg(dev)
+        except Exception as ex:
+            out["configs4"] = {"error": repr(ex)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -372,6 +543,41 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def whole_protein_leg(dev):
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import frames_to_batch, frames_to_batch_cutoff
+    from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
+    from nmrgnn_amd.structure import atoms_onehot, read_pdb
+    s = read_pdb(os.path.join(ROOT, "tests", "data", "7lgi.pdb.gz"))
+    rng = np.random.default_rng(7)
+    frames = np.stack([s.frames[0] + rng.normal(0, 0.3, s.frames[0].shape).astype(np.float32) for _ in range(100)])
+    atoms = atoms_onehot(s.elements)
+    n = atoms.shape[0]
+    eng = Engine(declare_gnn_space(HyperParameters()), atoms.shape[1], device=dev, seed=1234)
+    pos = torch.from_numpy(frames).to(dev)
+    at = torch.from_numpy(atoms).to(dev)
+    res = {"workload": f"7lgi: {n} atoms x 100 jittered frames, atom_feature_size 256, graph build on the GPU + "
+                       f"model forward, positions resident in HBM", "unit": "atoms/s"}
+    for tag, build in (("knn16_padded", lambda p: frames_to_batch(at, p, 16, device=dev)),
+                       ("cutoff_3.5A_csr", lambda p: frames_to_batch_cutoff(at, p, 3.5, device=dev))):
+        for fpb in (50, 1):
+            def run():
+                for b0 in range(0, 100, fpb):
+                    eng.forward(build(pos[b0:b0 + fpb]))
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[f"{tag}_{fpb}_frames_per_call"] = {"value": 100 * n / dt, "ms_per_100_frames": dt * 1e3,
+                                                   "ms_per_frame": dt * 10.0}
+    gc = frames_to_batch_cutoff(at, pos[:1], 3.5, device=dev)
+    deg = (gc.row_ptr[1:] - gc.row_ptr[:-1]).cpu().numpy()
+    res["cutoff_degree"] = {"min": int(deg.min()), "median": float(np.median(deg)), "max": int(deg.max())}
+    return res
 
 
 if __name__ == "__main__":

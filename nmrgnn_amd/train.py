@@ -20,6 +20,10 @@ class Trainer:
         first_node = next(k for k in P.offsets if not k.startswith("edge_fc/"))
         self.buckets = GradBuckets(P.grad, P.offsets[first_node])
         self.step_count = 0
+        # measure_comm = True: two events per step around the wait for the gradient all-reduces on the compute stream
+        # (the time the collectives are EXPOSED, i.e. not hidden under the edge-MLP backward); comm_exposed_ms() reads them
+        self.measure_comm = False
+        self._comm_events = []
 
     def step(self, batch: GraphBatch, y: torch.Tensor, w: torch.Tensor, seed=None, total_graphs=None):
         """One optimiser step.  ``total_graphs``: number of graphs over ALL ranks this step (every rank can
@@ -42,7 +46,23 @@ class Trainer:
             dpred.mul_(wgt)
         eng.backward(dpred, on_node_grads=self.buckets.launch_node)
         self.buckets.launch_edge()
-        self.buckets.wait()
+        if self.measure_comm and world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.buckets.wait()
+            e1.record()
+            self._comm_events.append((e0, e1))
+        else:
+            self.buckets.wait()
         eng.adam_step(lr=self.lr, grad_scale=self.buckets.grad_scale())
         self.step_count += 1
         return loss
+
+    def comm_exposed_ms(self):
+        """mean stall of the compute stream at the all-reduce wait over the steps measured so far (resets)"""
+        if not self._comm_events:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._comm_events]
+        self._comm_events = []
+        return sum(ms) / len(ms)

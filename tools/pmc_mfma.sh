@@ -9,7 +9,7 @@ for SET in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   P=$((P+1)); OUT=gpurun_out/pmc_mfma_$P; rm -rf "$OUT"
   rocprofv3 --pmc $SET --output-format csv -d "$OUT" -o t -- \
-      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/pmc_mfma_$P.log 2>&1
+      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > gpurun_out/pmc_mfma_$P.log 2>&1
 done
 python - <<'PY'
 import csv, glob, json, collections
@@ -36,7 +36,13 @@ for k, d in val.items():
             e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / (dur[k] / n)
     res[k] = e
 keep = {k: v for k, v in res.items() if v.get("GRBM_GUI_ACTIVE", 0) > 20000}
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+keep["_meta"] = {"commit": os.environ.get("COMMIT", "unknown"), "tool": "tools/pmc_mfma.sh",
+                 "source_digest": {k: bench.source_digest(k) for k in bench.KERNEL_SOURCES}}
 json.dump(keep, open("gpurun_out/pmc_mfma.json", "w"), indent=1)
+keep.pop("_meta")
 for k, v in sorted(keep.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:12]:
     print(k[:60], {a: round(b, 2) for a, b in v.items()})
 PY

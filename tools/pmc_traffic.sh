@@ -5,16 +5,14 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=gpurun_out/pmc_${C}; rm -rf "$OUT"
   rocprofv3 --pmc $C --output-format csv -d "$OUT" -o t -- \
-      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/pmc_${C}.log 2>&1
+      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > gpurun_out/pmc_${C}.log 2>&1
 done
 python - <<'PY'
 import csv, glob, json, collections
 res = collections.defaultdict(dict)
-names = {"edge_fused_bwd_kernel": "edge_fused_bwd", "edge_fused_bwd2_kernel": "edge_fused_bwd",
-         "edge_fused_fwd_kernel": "edge_fused_fwd", "edge_fwd_x3_kernel<2>": "edge_fwd_x3", "edge_fwd_x3_kernel<1>": "edge_fwd_x3_rowmajor", "edge_fwd_x3_kernel<0>": "edge_fwd_x3_inference", "edge_bwd_x3_kernel": "edge_bwd_x3", "split_agg_kernel": "mp_aggregate",
-         "split_agg_csc2_kernel": "mp_aggregate_csc", "split_edge_grad2_kernel": "mp_edge_grad",
-         "tall_tn_kernel<192": "mp_dw", "tall_gemm_kernel<192, 64, false>": "mp_update_fwd|mp_dh",
-         "tall_gemm_kernel<64, 192, true>": "mp_dA", "mp_win_fwd_kernel": "mp_win_fwd",
+names = {"edge_fused_bwd_kernel": "edge_fused_bwd",
+         "edge_fused_fwd_kernel": "edge_fused_fwd", "edge_fwd_x3_kernel<2>": "edge_fwd_x3", "edge_fwd_x3_kernel<1>": "edge_fwd_x3_rowmajor", "edge_fwd_x3_kernel<0>": "edge_fwd_x3_inference", "edge_bwd_x3_kernel": "edge_bwd_x3",
+         "mp_win_fwd_kernel": "mp_win_fwd",
          "mp_win_bwd_edge_kernel": "mp_win_bwd_edge", "mp_win_bwd_node_kernel": "mp_win_bwd_node",
          "fc_fwd_kernel": "fc_fused_fwd", "fc_bwd_kernel": "fc_fused_bwd"}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -32,6 +30,11 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             if pat in k:
                 for s in short.split("|"):
                     res[s][C + "_KB"] = tot[k] / cnt[k]
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+res["_meta"] = {"commit": os.environ.get("COMMIT", "unknown"), "tool": "tools/pmc_traffic.sh",
+                "source_digest": {k: bench.source_digest(k) for k in bench.KERNEL_SOURCES}}
 json.dump(res, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_${TAG}
 rm -rf "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- \
-    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile > gpurun_out/bench_${TAG}.log 2>&1
+    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-extras > gpurun_out/bench_${TAG}.log 2>&1
 find "$OUT" -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 head -25 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200
 grep '"metric"' gpurun_out/bench_${TAG}.log | cut -c1-250
