@@ -170,10 +170,11 @@ struct DwPlan {
 static DwPlan dw_plan(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
   DwPlan p;
   p.big_n = Nout > 64;
-  const int BMo = 128, BNo = p.big_n ? 128 : 64;
+  const bool t256 = gemm_x3_dw8_ok(M, Kin, Nout);       // 256 x 256 tiles, one workgroup per CU
+  const int BMo = t256 ? 256 : 128, BNo = t256 ? 256 : (p.big_n ? 128 : 64);
   const int64_t tiles = cdiv(Kin, BMo) * cdiv(Nout, BNo);
-  // split the contraction (rows) so that ~2 workgroups per CU are in flight
-  int64_t nz = cdiv((int64_t)2 * ctx->num_cu, tiles);
+  // split the contraction (rows) so that ~2 workgroups per CU (one for the 256-tiles) are in flight
+  int64_t nz = cdiv((int64_t)(t256 ? 1 : 2) * ctx->num_cu, tiles);
   const int64_t max_z = std::max<int64_t>(cdiv(M, 32), 1);
   nz = std::max<int64_t>(std::min(nz, max_z), 1);
   p.k_chunk = std::max<int64_t>(cdiv(cdiv(M, nz), 32) * 32, 32);

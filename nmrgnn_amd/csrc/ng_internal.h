@@ -24,6 +24,7 @@ bool gemm_x3_fwd_ok(int64_t M, int K, int N);
 int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag);
 bool gemm_x3_dw_ok(int64_t M, int Kin, int Nout);
+bool gemm_x3_dw8_ok(int64_t M, int Kin, int Nout);      // 256 x 256 output tiles, one 8-wave workgroup per CU
 int gemm_x3_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
                const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const char* tag);
 int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,

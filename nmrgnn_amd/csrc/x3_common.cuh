@@ -49,4 +49,17 @@ __device__ __forceinline__ f32x16 mma6(const u32x4 (&a)[3], const u32x4 (&b)[3],
   return acc;
 }
 
+// the same six piece products for TWO accumulators that share the B triple (a0 / a1: two A triples); the two chains
+// alternate, so consecutive MFMAs never depend on each other (a chain of dependent 32x32x16 MFMAs issues slower than
+// the pipe's 32-cycle cadence: SQ_WAIT_INST_ANY 41-49 % in the GEMM that used mma6 per accumulator)
+__device__ __forceinline__ void mma6_2a(const u32x4 (&a0)[3], const u32x4 (&a1)[3], const u32x4 (&b)[3], f32x16& acc0,
+                                        f32x16& acc1) {
+  acc0 = mfma_bf16(a0[2], b[0], acc0); acc1 = mfma_bf16(a1[2], b[0], acc1);
+  acc0 = mfma_bf16(a0[0], b[2], acc0); acc1 = mfma_bf16(a1[0], b[2], acc1);
+  acc0 = mfma_bf16(a0[1], b[1], acc0); acc1 = mfma_bf16(a1[1], b[1], acc1);
+  acc0 = mfma_bf16(a0[1], b[0], acc0); acc1 = mfma_bf16(a1[1], b[0], acc1);
+  acc0 = mfma_bf16(a0[0], b[1], acc0); acc1 = mfma_bf16(a1[0], b[1], acc1);
+  acc0 = mfma_bf16(a0[0], b[0], acc0); acc1 = mfma_bf16(a1[0], b[0], acc1);
+}
+
 }  // namespace ng

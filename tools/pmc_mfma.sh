@@ -30,7 +30,7 @@ for k, d in val.items():
     e = {c: v / max(1, len(cnt[(k, c)])) for c, v in d.items()}
     n = max(1, len(cnt[(k, "GRBM_GUI_ACTIVE")]))
     if e.get("GRBM_GUI_ACTIVE", 0) > 0:
-        e["mfma_util_pct"] = 100.0 * e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (e["GRBM_GUI_ACTIVE"] * 1024)
+        e["mfma_util_pct"] = 100.0 * e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / (e["GRBM_GUI_ACTIVE"] / 8.0)   # GRBM counts per XCD
         if dur[k] > 0:
             e["dur_us"] = dur[k] / n / 1e3
             e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / (dur[k] / n)
