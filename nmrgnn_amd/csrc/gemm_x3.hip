@@ -104,6 +104,8 @@ __device__ __forceinline__ void gx_epilogue_block(const GxArgs& a, const f32x16 
         v[j][q].z = act_apply(a.act, v[j][q].z); v[j][q].w = act_apply(a.act, v[j][q].w);
       }
   }
+  // plain stores: the next kernel reads these outputs out of L2 / the Infinity Cache (non-temporal stores measured
+  // 1.2-1.3x slower end to end at the default width)
   if (a.S) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)

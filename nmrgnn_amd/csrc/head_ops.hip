@@ -180,7 +180,7 @@ static bool fast_enabled() {
 }
 
 bool head_fast_supported(int Fh, int C) {
-  if (!(fast_enabled() && (Fh == 32 || Fh == 64) && C >= 1 && C <= HC_MAX)) return false;
+  if (!(fast_enabled() && (Fh == 32 || Fh == 64 || Fh == 128) && C >= 1 && C <= HC_MAX)) return false;
   return (size_t)(256 / (Fh / 4)) * (Fh * C + C) * 4 <= 96 * 1024;     // LDS of the backward's final sum
 }
 
@@ -226,6 +226,7 @@ int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   hipLaunchKernelGGL((head_bwd_fast_kernel<L, CM>), dim3(nb), dim3(256), lds, st, N, C, rows, g, mask, Wout, \
                      atoms, pstd, dpeaks, dg, partial)
   if (lpr == 8) { if (C <= 16) NG_HB(8, 16); else NG_HB(8, 32); }
+  else if (lpr == 32) { if (C <= 16) NG_HB(32, 16); else NG_HB(32, 32); }     // fc output 128: the default width
   else { if (C <= 16) NG_HB(16, 16); else NG_HB(16, 32); }
 #undef NG_HB
   ReduceSegs sg{};

@@ -71,9 +71,11 @@ __global__ __launch_bounds__(256) void csr_aggregate_kernel(int64_t N, int F, in
       }
     }
   }
-  float4* A4 = reinterpret_cast<float4*>(A);
+  typedef float nt4 __attribute__((ext_vector_type(4)));     // written once, read by a later kernel
+  nt4* A4 = reinterpret_cast<nt4*>(A);
 #pragma unroll
-  for (int n = 0; n < EC; ++n) A4[(i * E + n0 + n) * c4n + c4] = acc[n];
+  for (int n = 0; n < EC; ++n)
+    __builtin_nontemporal_store(nt4{acc[n].x, acc[n].y, acc[n].z, acc[n].w}, A4 + (i * E + n0 + n) * c4n + c4);
 }
 
 // de[p][n0+n] (+)= sum_l dA[i][n0+n][l] * h[col[p]][l]   for the entries p of row i

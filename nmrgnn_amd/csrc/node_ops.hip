@@ -137,9 +137,13 @@ __global__ __launch_bounds__(256) void aggregate_kernel(int64_t N, int K, int F,
       }
     }
   }
-  float4* A4 = reinterpret_cast<float4*>(A);
+  // A is written once and read by a later kernel: non-temporal, so that it does not push the gathered h rows (which
+  // every tile of the molecule re-reads) out of the XCD's L2
+  typedef float nt4 __attribute__((ext_vector_type(4)));
+  nt4* A4 = reinterpret_cast<nt4*>(A);
 #pragma unroll
-  for (int n = 0; n < E; ++n) A4[((i0 + a) * E + n) * c4n + c4] = acc[n];
+  for (int n = 0; n < E; ++n)
+    __builtin_nontemporal_store(nt4{acc[n].x, acc[n].y, acc[n].z, acc[n].w}, A4 + ((i0 + a) * E + n) * c4n + c4);
 }
 
 static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h,

@@ -17,6 +17,8 @@ ctx = _lib.get_context(0)
 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 g = torch.Generator(device=dev).manual_seed(0)
 e = torch.randn(N, K, E, device=dev, generator=g) * (gb.edges > 0)[..., None]
+import json
+out = {"workload": "ng_mp_aggregate on the bench batch: 512 graphs x 256 atoms, K=16, E=3", "rows": []}
 for F in (64, 256):
     h = torch.randn(N, F, device=dev, generator=g)
     A = torch.empty(N, E, F, device=dev)
@@ -29,5 +31,10 @@ for F in (64, 256):
     t1.record(); torch.cuda.synchronize()
     us = t0.elapsed_time(t1) / 20 * 1e3
     by = 4.0 * N * (F + K + K * E + F * E)
+    out["rows"].append({"F": F, "us": us, "algorithmic_MB": by / 1e6, "GBps": by / us / 1e3, "frac_of_8TBps": by / us / 1e3 / 8000,
+                        "gathered_MB_through_L2": 4.0 * N * K * F / 1e6})
     print("F=%d: %.1f us, %.0f MB algorithmic -> %.0f GB/s = %.0f %% of 8 TB/s (%.0f %% of the ~6.3 TB/s achievable)" % (
         F, us, by / 1e6, by / us / 1e3, by / us / 1e3 / 80, by / us / 1e3 / 63))
+
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/aggbench.json", "w"), indent=1)
