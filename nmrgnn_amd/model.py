@@ -54,6 +54,18 @@ class GNNModel:
         if self._pending_state is not None:
             self.engine.params.load_state_dict(self._pending_state)
             self._pending_state = None
+        self._restore_adam()
+
+    def _restore_adam(self):
+        pend = getattr(self, "_pending_adam", None)
+        if pend is None or self.engine is None:
+            return
+        m, v, t = pend
+        if m.shape[0] == self.engine.adam_m.shape[0]:
+            self.engine.adam_m.copy_(torch.from_numpy(m))
+            self.engine.adam_v.copy_(torch.from_numpy(v))
+            self.engine.adam_t = t
+        self._pending_adam = None
 
     def _as_batch(self, inputs):
         if isinstance(inputs, GraphBatch):
@@ -105,11 +117,20 @@ class GNNModel:
         return {'hypers': self.hypers.as_dict(), 'peak_standards': self.peak_standards}
 
     def save(self, path):
-        """own flat format: <path>/weights.npz + <path>/config.json (names follow the Keras variable tree)"""
+        """own flat format: <path>/weights.npz + <path>/config.json (names follow the Keras variable tree).
+        weights.npz also carries the Adam state (``__adam_m`` / ``__adam_v`` flat buffers, ``__adam_t``) once a
+        step has been taken, so training resumes where it stopped (the reference's checkpoints hold the Adam
+        slots too, main.py:63-68).  The TensorFlow bundle written beside it holds the WEIGHT tensors under the
+        reference's variable keys — it is what ``load_model`` reads back and what a TF-side reader can pick tensors
+        from by key; it is not a complete Keras SavedModel (no object graph, no saved_model.pb)."""
         self._need_engine()
         os.makedirs(path, exist_ok=True)
-        np.savez(os.path.join(path, "weights.npz"), **{k.replace("/", "."): v for k, v in
-                                                        self.engine.params.state_dict().items()})
+        arrays = {k.replace("/", "."): v for k, v in self.engine.params.state_dict().items()}
+        if self.engine.adam_t > 0:
+            arrays["__adam_m"] = self.engine.adam_m.cpu().numpy()
+            arrays["__adam_v"] = self.engine.adam_v.cpu().numpy()
+            arrays["__adam_t"] = np.asarray(self.engine.adam_t, np.int64)
+        np.savez(os.path.join(path, "weights.npz"), **arrays)
         cfg = {"hypers": self.hypers.as_dict(), "num_elem": self.engine.C,
                "peak_standards": {str(k): list(v) for k, v in self.peak_standards.items()}}
         with open(os.path.join(path, "config.json"), "w") as f:
@@ -131,7 +152,10 @@ class GNNModel:
             return
         f = path if path.endswith(".npz") else os.path.join(path, "weights.npz")
         z = np.load(f)
-        self.set_weights({k.replace(".", "/"): z[k] for k in z.files})
+        self.set_weights({k.replace(".", "/"): z[k] for k in z.files if not k.startswith("__adam_")})
+        if "__adam_t" in z.files:
+            self._pending_adam = (z["__adam_m"], z["__adam_v"], int(z["__adam_t"]))
+            self._restore_adam()
 
 
 def build_GNNModel(hp=None, metrics=True, loss_balance=1.0, device=None):

@@ -89,7 +89,15 @@ def test_end_to_end_108M_and_trajectory(gpu_device, tmp_path):
     sd = model.get_weights()
     ohp = O.hypers(**model.hypers.as_dict())
     ref = O.gnn_forward(g, sd, ohp, model.peak_std[:10], model.peak_avg[:10])
-    assert np.max(np.abs(np.asarray(peaks) - ref)) < 1e-3      # std up to 50.9 scales the 1e-4 budget
+    # The head output is multiplied by the real peak_std (N: 50.94): 1e-4 on the STANDARDISED prediction is the north
+    # star's budget at std = 1; on the de-standardised N shifts float32 itself stops at ~6e-4 — the reference's own
+    # traced graph evaluated in float32 sits 5.7e-4 from its float64 value on this protein (tests/test_gpu_savedmodel.py
+    # holds the per-element comparison against the reference graph; measured there: C 1.3e-4, N 6.3e-4, H 1.0e-4).
+    err = np.abs(np.asarray(peaks) - ref)
+    std = np.asarray(model.peak_std[:10])[np.argmax(g[0], axis=1)]
+    assert np.max(err[std > 0] / std[std > 0]) < 5e-5
+    assert np.max(err[std == 0]) == 0.0
+    assert np.max(err) < 1e-3
     conf = None
     try:
         conf = nmrgnn_amd.check_peaks(g[0], peaks)
@@ -210,3 +218,42 @@ def test_gpu_knn_eight_lane_kernel_equals_serial_kernel(gpu_device, monkeypatch,
         out[mode] = (gb.nlist.cpu().numpy(), gb.edges.cpu().numpy(), gb.inv_degree.cpu().numpy())
     for a, b in zip(out["serial"], out["lanes8"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_save_and_load_resume_training_with_adam_state(gpu_device, tmp_path):
+    """model.save keeps the Adam slots and step count (as the reference's checkpoints do, main.py:63-68): three steps ==
+    two steps + save + load into a fresh model + one step, bit for bit (explicit seeds)"""
+    import torch
+    import nmrgnn_amd
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.graph import GraphBatch
+    from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
+    from nmrgnn_amd.model import GNNModel
+    from nmrgnn_amd.standards import load_standards
+    from nmrgnn_amd.train import Trainer
+    hp = declare_gnn_space(HyperParameters(atom_feature_size=64))
+    b = synth.make_batch(6, 40, 16, 10, 0.1, seed=3)
+
+    def fresh():
+        m = GNNModel(hp, load_standards(), device=gpu_device, seed=5)
+        m.build(10)
+        return m
+
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    y, w = torch.from_numpy(b["y"]).to(gpu_device), torch.from_numpy(b["w"]).to(gpu_device)
+    m1 = fresh()
+    t1 = Trainer(m1.engine, lr=1e-3)
+    for s in range(3):
+        t1.step(gb, y, w, seed=100 + s)
+    ref = m1.engine.params.flat.clone()
+    m2 = fresh()
+    t2 = Trainer(m2.engine, lr=1e-3)
+    for s in range(2):
+        t2.step(gb, y, w, seed=100 + s)
+    m2.save(str(tmp_path / "ckpt"))
+    m3 = nmrgnn_amd.load_model(str(tmp_path / "ckpt"), device=gpu_device)
+    assert m3.engine.adam_t == 2
+    t3 = Trainer(m3.engine, lr=1e-3)
+    t3.step(gb, y, w, seed=102)
+    assert torch.equal(m3.engine.params.flat, ref)
