@@ -6,15 +6,15 @@ This file is a float64 NumPy *restatement* of the reference algorithm
 the product package.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it.
 
-PARITY STATUS: **parity unpinned by the reference's own runtime.**
-The reference is TensorFlow/Keras code whose imports (tensorflow, kerastuner,
-nmrdata, MDAnalysis) are absent here and whose weight shard is missing, and its
-test-suite holds shape assertions only for this path (tests/test_nmrgnn.py:18-108,
-197-223).  What *is* pinned: the analytic known-answer tests derived from the
-reference's own test inputs (tests/test_nmrgnn.py:20-31) and the constants
-decoded from the reference's bundled SavedModel graph (RBF centres, gap,
-peak std/avg, noise sigma, dropout scale; see tests/golden/savedmodel_constants.json
-and tests/golden/make_savedmodel_constants.py).
+PARITY STATUS: pinned to the reference's own traced graph.  The reference is TensorFlow/Keras code whose
+imports (tensorflow, kerastuner, nmrdata, MDAnalysis) are absent here and whose weight shard is missing, but
+its bundled SavedModel holds the traced graph of GNNModel.call: tests/golden/make_savedmodel_exec.py executes
+that graph op by op in NumPy (training=False and training=True functions, seeded weights) and commits the
+outputs as tests/golden/golden_savedmodel.npz; tests/test_savedmodel_golden.py holds this oracle to those
+numbers at 1e-9.  Also pinned: the analytic known-answer tests derived from the reference's own test inputs
+(tests/test_nmrgnn.py:20-31) and the constants decoded from the same SavedModel (RBF centres, gap, peak
+std/avg, noise sigma, dropout scale; tests/golden/savedmodel_constants.json).  NOT pinned: the graph
+front end (universe2graph conventions live in the external nmrdata package).
 
 Every function cites the reference file:line it restates.
 All arrays are NumPy; ``dtype`` defaults to float64 (the "truth"), and float32

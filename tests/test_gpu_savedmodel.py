@@ -8,12 +8,13 @@ shift is 2e-6 on the standardised output after 12 float32 layers.  The fixture r
 evaluation of the reference's own graph (NumPy summation order) already sits 1.7e-4 (F=64 case) and
 5.7e-4 (F=256, 108M.pdb) away from its float64 value.  The test therefore asserts
   * 5e-5 on the STANDARDISED prediction ((peaks-avg)/std, the quantity the network computes; half the
-    1e-4 budget of the north star at std = 1; measured: <= 1.7e-5), and
+    1e-4 budget of the north star at std = 1; measured: <= 2.4e-5), and
   * on the de-standardised shifts, per element: max error <= max(1e-4, 4 x the error of the
     reference's own float32 evaluation of the same graph) — both are samples of float32 rounding noise
     of the same scale (measured: 0.4x - 3.3x),
 and prints the measured per-element errors (C = 2, N = 3, H = 4).  Measured on MI355X, 108M.pdb, F=256:
-C 1.3e-4, N 6.3e-4, H 1.0e-4 against 1.6e-4 / 5.7e-4 / 1.2e-4 for the reference graph in float32.
+C 1.7e-4, N 6.3e-4, H 1.0e-4 against 1.6e-4 / 5.7e-4 / 1.2e-4 for the reference graph in float32
+(profiles/r02_savedmodel_errors.txt).
 """
 import numpy as np
 import pytest
@@ -93,5 +94,7 @@ def test_strict_fp32_mfma_has_the_same_error(gpu_device, monkeypatch, math):
     strict = eng.forward(gb, training=False).cpu().numpy().astype(np.float64)
     e_def = np.abs(base - c["peaks64"]).max()
     e_strict = np.abs(strict - c["peaks64"]).max()
-    print(f"[pdb108m] default (split bf16x3) max err {e_def:.3e}; strict f32-MFMA max err {e_strict:.3e}")
+    print(f"[pdb108m] default (split bf16x3) max err {e_def:.3e}; strict f32-MFMA max err {e_strict:.3e}; "
+          f"max |default - strict| {np.abs(base - strict).max():.3e}")
+    assert not np.array_equal(base, strict)        # the switch really selected other kernels
     assert e_def <= 4 * e_strict + 1e-5

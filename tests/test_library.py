@@ -92,7 +92,7 @@ def test_end_to_end_108M_and_trajectory(gpu_device, tmp_path):
     # The head output is multiplied by the real peak_std (N: 50.94): 1e-4 on the STANDARDISED prediction is the north
     # star's budget at std = 1; on the de-standardised N shifts float32 itself stops at ~6e-4 — the reference's own
     # traced graph evaluated in float32 sits 5.7e-4 from its float64 value on this protein (tests/test_gpu_savedmodel.py
-    # holds the per-element comparison against the reference graph; measured there: C 1.3e-4, N 6.3e-4, H 1.0e-4).
+    # holds the per-element comparison against the reference graph; measured there: C 1.7e-4, N 6.3e-4, H 1.0e-4).
     err = np.abs(np.asarray(peaks) - ref)
     std = np.asarray(model.peak_std[:10])[np.argmax(g[0], axis=1)]
     assert np.max(err[std > 0] / std[std > 0]) < 5e-5
