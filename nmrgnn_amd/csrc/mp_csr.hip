@@ -156,6 +156,146 @@ __global__ __launch_bounds__(256) void csr_scatter_pull_kernel(int64_t N, int F,
   reinterpret_cast<float4*>(dh_in)[t * c4n + c4] = acc;
 }
 
+// ---- wide-lane forms for F >= 128 (the reference's default width): LPA = F/16 lanes per atom, each lane owns four
+// float4 of the row (float4 index c + LPA t, t = 0..3, so a load instruction still covers LPA x 16 contiguous bytes).
+// The per-edge dot products are reduced over 8 or 16 lanes on the DPP network (3-4 VALU adds) instead of over 64 lanes
+// with six ds_bpermute shuffles each (37.7 M LDS operations per launch, 67 % of the wave cycles parked at F = 256),
+// and four rows are gathered before the first is consumed.
+template <int CTRL>
+__device__ __forceinline__ float csr_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int LPA>
+__device__ __forceinline__ float csr_group_sum(float v) {     // sum over aligned groups of LPA lanes, valid in every lane
+  if (LPA == 16) {
+    v = csr_dpp_add<0x128>(v);     // row_ror:8
+    v = csr_dpp_add<0x124>(v);     // row_ror:4
+    v = csr_dpp_add<0x122>(v);     // row_ror:2
+    v = csr_dpp_add<0x121>(v);     // row_ror:1
+  } else {
+    v = csr_dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = csr_dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = csr_dpp_add<0x141>(v);     // row_half_mirror
+  }
+  return v;
+}
+
+template <int EC, int LPA>
+__global__ __launch_bounds__(256) void csr_edge_grad_wide_kernel(int64_t N, int E, RowRange rr,
+                                                                 const float* __restrict__ h,
+                                                                 const int32_t* __restrict__ col,
+                                                                 const float* __restrict__ dA, float* __restrict__ de,
+                                                                 int accumulate) {
+  constexpr int C4N = 4 * LPA, APB = 256 / LPA;
+  const int a = threadIdx.x / LPA, c = threadIdx.x % LPA;
+  const int64_t i = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * APB + a;
+  const bool live = i < N;
+  const int64_t ii = live ? i : 0;
+  int64_t p0, p1;
+  rr.get(ii, p0, p1);
+  if (!live) p1 = p0;
+  const int len = (int)(p1 - p0);
+  int maxlen = len;                               // DPP rows are shared: every lane of the wave walks the longest row
+  for (int off = 32; off >= LPA; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  float4 g[EC][4];
+#pragma unroll
+  for (int n = 0; n < EC; ++n)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[n][t] = dA4[(ii * E + n) * C4N + c + LPA * t];
+  for (int j0 = 0; j0 < maxlen; j0 += 4) {
+    float4 hv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = len > 0 ? p0 + min(j0 + u, len - 1) : 0;
+      const int64_t r = len > 0 ? (int64_t)col[p] : 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) hv[u][t] = h4[r * C4N + c + LPA * t];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float mine = 0.f;
+#pragma unroll
+      for (int n = 0; n < EC; ++n) {
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          part += g[n][t].x * hv[u][t].x + g[n][t].y * hv[u][t].y + g[n][t].z * hv[u][t].z + g[n][t].w * hv[u][t].w;
+        part = csr_group_sum<LPA>(part);
+        if (c == n) mine = part;                  // lane n of the atom's group stores feature n: EC adjacent floats
+      }
+      if (j0 + u < len && c < EC) {
+        const int64_t o = (p0 + j0 + u) * E + c;
+        de[o] = accumulate ? de[o] + mine : mine;
+      }
+    }
+  }
+}
+
+// rec (optional, E <= 3): per incoming-edge entry {source row (int bits), e0, e1, e2} — one 16-byte load instead of
+// the index chain csc_edge -> row_of -> e
+template <int EC, int LPA>
+__global__ __launch_bounds__(256) void csr_scatter_pull_wide_kernel(int64_t N, int E, int K,
+                                                                    const int32_t* __restrict__ row_of,
+                                                                    const int32_t* __restrict__ csc_ptr,
+                                                                    const int32_t* __restrict__ csc_edge,
+                                                                    const float* __restrict__ e,
+                                                                    const float4* __restrict__ rec,
+                                                                    const float* __restrict__ dA,
+                                                                    const float* __restrict__ base,
+                                                                    float* __restrict__ dh_in) {
+  constexpr int C4N = 4 * LPA, APB = 256 / LPA;
+  const int a = threadIdx.x / LPA, c = threadIdx.x % LPA;
+  const int64_t t = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * APB + a;
+  if (t >= N) return;
+  const float4* dA4 = reinterpret_cast<const float4*>(dA);
+  float4 acc[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) acc[tt] = reinterpret_cast<const float4*>(base)[t * C4N + c + LPA * tt];
+  const int q0 = csc_ptr[t], q1 = csc_ptr[t + 1];
+  for (int q = q0; q < q1; q += 2) {
+    float ev[2][EC];
+    float4 v[2][EC][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qq = min(q + u, q1 - 1);
+      int64_t src;
+      if (rec) {
+        const float4 r = rec[qq];
+        src = __float_as_int(r.x);
+        const float rv[3] = {r.y, r.z, r.w};
+#pragma unroll
+        for (int n = 0; n < EC; ++n) ev[u][n] = n < 3 ? rv[n < 3 ? n : 0] : 0.f;
+      } else {
+        const int eid = csc_edge[qq];
+        src = row_of ? row_of[eid] : eid / K;
+#pragma unroll
+        for (int n = 0; n < EC; ++n) ev[u][n] = e[(int64_t)eid * E + n];
+      }
+      if (q + u >= q1) {
+#pragma unroll
+        for (int n = 0; n < EC; ++n) ev[u][n] = 0.f;
+      }
+#pragma unroll
+      for (int n = 0; n < EC; ++n)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) v[u][n][tt] = dA4[(src * E + n) * C4N + c + LPA * tt];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int n = 0; n < EC; ++n)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          acc[tt].x += ev[u][n] * v[u][n][tt].x; acc[tt].y += ev[u][n] * v[u][n][tt].y;
+          acc[tt].z += ev[u][n] * v[u][n][tt].z; acc[tt].w += ev[u][n] * v[u][n][tt].w;
+        }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) reinterpret_cast<float4*>(dh_in)[t * C4N + c + LPA * tt] = acc[tt];
+}
+
 #define NG_EC_SWITCH(EC, CALL)   \
   switch (EC) {                  \
     case 1: { CALL(1) } break;   \
@@ -194,10 +334,21 @@ int csr_aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, c
 int csr_edge_grad(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* row_ptr,
                   const int32_t* col, const float* dA, float* de, int accumulate) {
   if (N == 0) return NG_OK;
-  ProfScope ps(ctx, st, "mp_edge_grad_csr");
+  ProfScope ps(ctx, st, "mp_edge_grad");
+  const RowRange rr{row_ptr, K};
+  if ((F == 128 || F == 256) && E <= 4) {          // wide-lane form: DPP reductions over F/16 lanes
+    const int lpa = F / 16;
+    const dim3 gridw((unsigned)cdiv(N, 256 / lpa));
+#define CALLW(EE)                                                                                                  \
+  if (lpa == 16) hipLaunchKernelGGL((csr_edge_grad_wide_kernel<EE, 16>), gridw, dim3(256), 0, st, N, E, rr, h, col, dA, de, accumulate); \
+  else hipLaunchKernelGGL((csr_edge_grad_wide_kernel<EE, 8>), gridw, dim3(256), 0, st, N, E, rr, h, col, dA, de, accumulate);
+    switch (E) { case 1: { CALLW(1) } break; case 2: { CALLW(2) } break; case 3: { CALLW(3) } break; default: { CALLW(4) } break; }
+#undef CALLW
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
   const int apb = 256 / (F / 4);
   const dim3 grid((unsigned)cdiv(N, apb));
-  const RowRange rr{row_ptr, K};
   for (int n0 = 0; n0 < E; n0 += 8) {
     const int ec = std::min(8, E - n0);
 #define CALL(EE) \
@@ -210,10 +361,22 @@ int csr_edge_grad(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, c
 }
 
 int csr_scatter_pull(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const int32_t* row_of,
-                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, const float* dA,
+                     const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, const float* rec, const float* dA,
                      const float* dh_out, float* dh_in) {
   if (N == 0) return NG_OK;
-  ProfScope ps(ctx, st, "mp_scatter_pull_csr");
+  ProfScope ps(ctx, st, "mp_scatter_pull");
+  if ((F == 128 || F == 256) && E <= 4) {
+    const int lpa = F / 16;
+    const dim3 gridw((unsigned)cdiv(N, 256 / lpa));
+    const float4* rec4 = E <= 3 ? reinterpret_cast<const float4*>(rec) : nullptr;
+#define CALLW(EE)                                                                                                   \
+  if (lpa == 16) hipLaunchKernelGGL((csr_scatter_pull_wide_kernel<EE, 16>), gridw, dim3(256), 0, st, N, E, K, row_of, csc_ptr, csc_edge, e, rec4, dA, dh_out, dh_in); \
+  else hipLaunchKernelGGL((csr_scatter_pull_wide_kernel<EE, 8>), gridw, dim3(256), 0, st, N, E, K, row_of, csc_ptr, csc_edge, e, rec4, dA, dh_out, dh_in);
+    switch (E) { case 1: { CALLW(1) } break; case 2: { CALLW(2) } break; case 3: { CALLW(3) } break; default: { CALLW(4) } break; }
+#undef CALLW
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
   const int apb = 256 / (F / 4);
   const dim3 grid((unsigned)cdiv(N, apb));
   for (int n0 = 0; n0 < E; n0 += 8) {
@@ -250,7 +413,7 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
                    const float* inv_degree, const float* w, const float* A_save, const float* s_save,
                    const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de,
-                   int de_accum, float* dw) {
+                   int de_accum, float* dw, const float* csc_rec) {
   const int64_t KF = (int64_t)E * F;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr + (A_save ? 0 : N * KF)) * 4);
@@ -272,7 +435,7 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
   if (rc) return rc;
   rc = csr_edge_grad(ctx, st, N, K, F, E, h, row_ptr, col, dA, de, de_accum);
   if (rc) return rc;
-  return csr_scatter_pull(ctx, st, N, K, F, E, row_of, csc_ptr, csc_edge, e, dA, dh_out, dh_in);
+  return csr_scatter_pull(ctx, st, N, K, F, E, row_of, csc_ptr, csc_edge, e, csc_rec, dA, dh_out, dh_in);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -360,7 +523,7 @@ extern "C" int ng_mp_layer_bwd_csr(ng_ctx* ctx, void* stream, int64_t N, int64_t
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
   NG_REQUIRE(ctx, nnz >= 0 && nnz < ((int64_t)1 << 31), "mp_layer (csr): nnz must fit int32");
   return mp_generic_bwd(ctx, (hipStream_t)stream, N, 0, F, E, act, h, row_ptr, col, row_of, e, inv_degree, w, A_save,
-                        s_save, csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw);
+                        s_save, csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw, nullptr);
 }
 
 extern "C" int ng_cutoff_count(ng_ctx* ctx, void* stream, int G, int n, float cutoff, const float* pos,

@@ -48,7 +48,7 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
                    const float* inv_degree, const float* w, const float* A_save, const float* s_save,
                    const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de,
-                   int de_accum, float* dw);
+                   int de_accum, float* dw, const float* csc_rec = nullptr);
 int csr_aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* row_ptr,
                   const int32_t* col, const float* e, float* A);
 

@@ -187,76 +187,6 @@ int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float
   return NG_OK;
 }
 
-// de[i][j][n] (+)= sum_l dA[i][n][l] * h[nlist[i][j]][l]
-template <int E>
-__global__ __launch_bounds__(256) void edge_grad_kernel(int64_t N, int K, int F,
-                                                        const float* __restrict__ h,
-                                                        const int32_t* __restrict__ nlist,
-                                                        const float* __restrict__ dA,
-                                                        float* __restrict__ de, int accumulate) {
-  const int c4n = F / 4;  // power of two, <= 64: an atom's lanes sit inside one wave
-  const int apb = 256 / c4n;
-  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
-  const int64_t i = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;   // XCD-aware (see aggregate_kernel)
-  const bool live = i < N;
-  const int64_t ii = live ? i : 0;
-  const float4* dA4 = reinterpret_cast<const float4*>(dA);
-  const float4* h4 = reinterpret_cast<const float4*>(h);
-  float4 g[E];
-#pragma unroll
-  for (int n = 0; n < E; ++n) g[n] = dA4[(ii * E + n) * c4n + c4];
-  for (int j = 0; j < K; ++j) {
-    const int idx = nlist[ii * K + j];
-    const float4 hv = h4[(int64_t)idx * c4n + c4];
-    float part[E];
-#pragma unroll
-    for (int n = 0; n < E; ++n)
-      part[n] = g[n].x * hv.x + g[n].y * hv.y + g[n].z * hv.z + g[n].w * hv.w;
-    for (int off = c4n >> 1; off > 0; off >>= 1) {
-#pragma unroll
-      for (int n = 0; n < E; ++n) part[n] += __shfl_xor(part[n], off, 64);
-    }
-    if (live && c4 == 0) {
-#pragma unroll
-      for (int n = 0; n < E; ++n) {
-        const int64_t o = (i * K + j) * E + n;
-        de[o] = accumulate ? de[o] + part[n] : part[n];
-      }
-    }
-  }
-}
-
-// dh_in[t][l] = dh_out[t][l] + sum_{p in csc[t]} sum_n e[p][n] * dA[p / K][n][l]
-// (deterministic "pull" form of the scatter-add  dh[nlist[i][j]] += sum_n e_ijn dA_iln)
-template <int E>
-__global__ __launch_bounds__(256) void scatter_pull_kernel(int64_t N, int K, int F,
-                                                           const int32_t* __restrict__ csc_ptr,
-                                                           const int32_t* __restrict__ csc_edge,
-                                                           const float* __restrict__ e,
-                                                           const float* __restrict__ dA,
-                                                           const float* __restrict__ dh_out,
-                                                           float* __restrict__ dh_in) {
-  const int c4n = F / 4;
-  const int apb = 256 / c4n;
-  const int a = threadIdx.x / c4n, c4 = threadIdx.x % c4n;
-  const int64_t t = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * apb + a;   // XCD-aware (see aggregate_kernel)
-  if (t >= N) return;
-  const float4* dA4 = reinterpret_cast<const float4*>(dA);
-  float4 acc = reinterpret_cast<const float4*>(dh_out)[t * c4n + c4];
-  const int p0 = csc_ptr[t], p1 = csc_ptr[t + 1];
-  for (int p = p0; p < p1; ++p) {
-    const int eid = csc_edge[p];
-    const int64_t src = eid / K;
-#pragma unroll
-    for (int n = 0; n < E; ++n) {
-      const float ev = e[(int64_t)eid * E + n];
-      const float4 v = dA4[(src * E + n) * c4n + c4];
-      acc.x += ev * v.x; acc.y += ev * v.y; acc.z += ev * v.z; acc.w += ev * v.w;
-    }
-  }
-  reinterpret_cast<float4*>(dh_in)[t * c4n + c4] = acc;
-}
-
 // ------------------------------------------------------------------------------------ head
 // peaks[i] = sum_c atoms[i,c] * ((g*mask)[i,:] @ Wout[:,c] + bout[c]) * std[c] + atoms[i,c]*avg[c]
 __global__ __launch_bounds__(256) void head_fwd_kernel(int64_t N, int Fh, int C,
@@ -736,61 +666,12 @@ extern "C" int ng_mp_layer_bwd_rec(ng_ctx* ctx, void* stream, int64_t N, int K, 
   NG_REQUIRE(ctx, F % 4 == 0 && F >= 16 && F <= 256 && (256 % (F / 4)) == 0,
              "mp_layer_bwd: F in {16,32,64,128,256}");
   NG_REQUIRE(ctx, E >= 1 && E <= 64, "mp_layer_bwd: edge_feature_size <= 64");
-  if (E > MAX_E)
-    return mp_generic_bwd(ctx, st, N, K, F, E, act, h, nullptr, nlist, nullptr, e, inv_degree, w, A_save, s_save,
-                          csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw);
   if (N > 0 && mp_win_bwd_enabled(F, E, K))
     return mp_win_bwd(ctx, st, N, K, E, act, h, nlist, e, inv_degree, w, s_save, csc_ptr, csc_edge, dh_out, dh_in, de,
                       de_accum, dw, csc_rec);
-  const int64_t KF = (int64_t)E * F;
-  const float* S = s_save;
-  const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
-  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr + (A_save ? 0 : N * KF)) * 4);
-  if (!ws) return NG_ERR_NOMEM;
-  float* Wp = ws;
-  float* dA = ws + KF * F;
-  float* scr = dA + N * KF;
-  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
-  if (rc) return rc;
-  if (!A_save) {   // the caller did not keep the forward aggregate: rebuild it
-    float* Ar = scr + dw_scr;
-    rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, Ar);
-    if (rc) return rc;
-    A_save = Ar;
-  }
-  // dw[l][m][n] = sum_i A[i][(n,l)] dP[i][m],   dP = dh_out * act'(P) * inv
-  rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, S, inv_degree, dw, nullptr, 1, F, E, scr,
-                "mp_dw");
-  if (rc) return rc;
-  // dA[i][(n,l)] = sum_m dP[i][m] Wp[(n,l)][m]
-  rc = dense_dx(ctx, st, N, (int)KF, F, act, dh_out, S, inv_degree, Wp, nullptr, dA, "mp_dA");
-  if (rc) return rc;
-  if (N == 0) return NG_OK;
-  const int apb = 256 / (F / 4);
-  const dim3 grid((unsigned)cdiv(N, apb));
-  {
-    ProfScope ps(ctx, st, "mp_edge_grad");
-#define NG_EG(EE)                                                                                \
-  case EE:                                                                                       \
-    hipLaunchKernelGGL((edge_grad_kernel<EE>), grid, dim3(256), 0, st, N, K, F, h, nlist, dA, de, \
-                       de_accum);                                                                \
-    break;
-    switch (E) { NG_EG(1) NG_EG(2) NG_EG(3) NG_EG(4) NG_EG(5) NG_EG(6) NG_EG(7) NG_EG(8) }
-#undef NG_EG
-    NG_HIP(ctx, hipGetLastError());
-  }
-  {
-    ProfScope ps(ctx, st, "mp_scatter_pull");
-#define NG_SP(EE)                                                                                 \
-  case EE:                                                                                        \
-    hipLaunchKernelGGL((scatter_pull_kernel<EE>), grid, dim3(256), 0, st, N, K, F, csc_ptr,       \
-                       csc_edge, e, dA, dh_out, dh_in);                                           \
-    break;
-    switch (E) { NG_SP(1) NG_SP(2) NG_SP(3) NG_SP(4) NG_SP(5) NG_SP(6) NG_SP(7) NG_SP(8) }
-#undef NG_SP
-    NG_HIP(ctx, hipGetLastError());
-  }
-  return NG_OK;
+  // generic path (any F / E / K): the kernels of mp_csr.hip with the fixed stride K in place of row_ptr
+  return mp_generic_bwd(ctx, st, N, K, F, E, act, h, nullptr, nlist, nullptr, e, inv_degree, w, A_save, s_save, csc_ptr,
+                        csc_edge, dh_out, dh_in, de, de_accum, dw, E <= 3 ? csc_rec : nullptr);
 }
 
 extern "C" int ng_head_fwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, const float* g,
