@@ -392,6 +392,26 @@ int csr_scatter_pull(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
   return NG_OK;
 }
 
+// dP[i][m] = dH[i][m] * act'(S[i][m]) * v[i]   (SURVEY App. B), formed ONCE per layer: the dA GEMM, the three k-tiles of
+// the dw GEMM and (before) their loaders each recomputed it from dH and S — a third of the dw GEMM's 1.2 GB of reads
+__global__ void mp_dp_kernel(int64_t N, int F, int act, const float* __restrict__ dH, const float* __restrict__ S,
+                             const float* __restrict__ v, float* __restrict__ dP) {
+  const int c4n = F / 4;
+  const int64_t total = N * c4n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / c4n;
+    float4 d = reinterpret_cast<const float4*>(dH)[t];
+    if (S) {
+      const float4 s = reinterpret_cast<const float4*>(S)[t];
+      d.x *= act_grad_from_out(act, s.x); d.y *= act_grad_from_out(act, s.y);
+      d.z *= act_grad_from_out(act, s.z); d.w *= act_grad_from_out(act, s.w);
+    }
+    const float r = v[i];
+    d.x *= r; d.y *= r; d.z *= r; d.w *= r;
+    reinterpret_cast<float4*>(dP)[t] = d;
+  }
+}
+
 // generic MPLayer forward over (row_ptr | K) lists: repack w, aggregate, GEMM with the epilogue of layers.py:42 + model.py:167
 int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, int residual, const float* h,
                    const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
@@ -416,11 +436,12 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    int de_accum, float* dw, const float* csc_rec) {
   const int64_t KF = (int64_t)E * F;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
-  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + dw_scr + (A_save ? 0 : N * KF)) * 4);
+  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + N * F + dw_scr + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;
   float* Wp = ws;
   float* dA = ws + KF * F;
-  float* scr = dA + N * KF;
+  float* dP = dA + N * KF;
+  float* scr = dP + N * F;
   int rc = mp_repack_w(ctx, st, F, E, w, Wp);
   if (rc) return rc;
   if (!A_save) {   // the caller did not keep the forward aggregate: rebuild it
@@ -429,9 +450,16 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
     if (rc) return rc;
     A_save = Ar;
   }
-  rc = dense_dw(ctx, st, N, (int)KF, F, act, A_save, dh_out, s_save, inv_degree, dw, nullptr, 1, F, E, scr, "mp_dw");
+  if (N > 0) {
+    ProfScope ps(ctx, st, "mp_dP");
+    const int64_t work = N * (F / 4);
+    hipLaunchKernelGGL(mp_dp_kernel, dim3((unsigned)std::min<int64_t>(cdiv(work, 256), 256 * 16)), dim3(256), 0, st, N, F,
+                       act, dh_out, act == NG_ACT_NONE ? nullptr : s_save, inv_degree, dP);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  rc = dense_dw(ctx, st, N, (int)KF, F, NG_ACT_NONE, A_save, dP, nullptr, nullptr, dw, nullptr, 1, F, E, scr, "mp_dw");
   if (rc) return rc;
-  rc = dense_dx(ctx, st, N, (int)KF, F, act, dh_out, s_save, inv_degree, Wp, nullptr, dA, "mp_dA");
+  rc = dense_dx(ctx, st, N, (int)KF, F, NG_ACT_NONE, dP, nullptr, nullptr, Wp, nullptr, dA, "mp_dA");
   if (rc) return rc;
   rc = csr_edge_grad(ctx, st, N, K, F, E, h, row_ptr, col, dA, de, de_accum);
   if (rc) return rc;
