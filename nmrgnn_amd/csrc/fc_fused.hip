@@ -533,6 +533,47 @@ int fc_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const f
 }  // namespace ng
 
 // ---- C ABI ---------------------------------------------------------------------------------------------
+namespace ng {
+// dP[i][n] = dY[i][n] * act'(s[i][n]),  s = a[i][n] - (b ? b[i][n] : 0)  (the activation OUTPUT of the layer);
+// partial[blk][n] = column sums of dP over the block's rows (bias gradient, two-stage deterministic)
+__global__ __launch_bounds__(256) void fc_dp_kernel(int64_t N, int No, int64_t rows_per_block, int act,
+                                                    const float* __restrict__ dY, const float* __restrict__ a,
+                                                    const float* __restrict__ b, float* __restrict__ dP,
+                                                    float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float fc_red[];     // [RL][No]
+  const int c4n = No / 4;
+  const int RL = 256 / c4n;
+  const int q = threadIdx.x % c4n, r = threadIdx.x / c4n;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < RL) {
+    for (int64_t i = r0 + r; i < r1; i += RL) {
+      const int64_t o = i * c4n + q;
+      float4 d = reinterpret_cast<const float4*>(dY)[o];
+      float4 sv = reinterpret_cast<const float4*>(a)[o];
+      if (b) {
+        const float4 bv = reinterpret_cast<const float4*>(b)[o];
+        sv.x -= bv.x; sv.y -= bv.y; sv.z -= bv.z; sv.w -= bv.w;
+      }
+      if (act != NG_ACT_NONE) {
+        d.x *= act_grad_from_out(act, sv.x); d.y *= act_grad_from_out(act, sv.y);
+        d.z *= act_grad_from_out(act, sv.z); d.w *= act_grad_from_out(act, sv.w);
+      }
+      reinterpret_cast<float4*>(dP)[o] = d;
+      cs.x += d.x; cs.y += d.y; cs.z += d.z; cs.w += d.w;
+    }
+    *reinterpret_cast<float4*>(fc_red + r * No + 4 * q) = cs;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < No; it += 256) {
+    float t = 0.f;
+    for (int rr = 0; rr < RL; ++rr) t += fc_red[rr * No + it];
+    partial[(int64_t)blockIdx.x * No + it] = t;
+  }
+}
+}  // namespace ng
+
 extern "C" int ng_fc_block_fwd(ng_ctx* ctx, void* stream, int64_t N, int F, int L, int act, const float* x,
                                const float* const* W, const float* const* b, float* const* y, float* g) {
   using namespace ng;
@@ -567,22 +608,46 @@ extern "C" int ng_fc_block_bwd(ng_ctx* ctx, void* stream, int64_t N, int F, int 
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, L >= 2, "fc_block: at least two layers");
   if (N > 0 && fc_fused_supported(F, L)) return fc_fused_bwd(ctx, st, N, L, act, x, g, W, dg, dx, dW, db);
-  // layer by layer: s_l = x_{l+1} - x_l rebuilt into the caller's scratch ([3][N][F])
+  // layer by layer.  Per layer ONE pass forms dP = dY * act'(s) (s = x_{l+1} - x_l rebuilt on the fly, or g for the last
+  // layer) together with the bias gradient's column sums; the dX and dW GEMMs then read dP (before: a pass that wrote
+  // s, then three consumers that each re-read dY and s).  scratch: [3][N][F] = dP | dX ping | dX pong
   NG_REQUIRE(ctx, scratch || N == 0, "fc_block_bwd: scratch [3*N*F] required for this feature size");
-  float* S = scratch;
+  NG_REQUIRE(ctx, F % 8 == 0 && F <= 1024, "fc_block_bwd: F % 8 == 0, F <= 1024");
+  float* dP = scratch;
   float* d0 = scratch + N * F;
   float* d1 = d0 + N * F;
-  int rc = ng_dense_bwd(ctx, stream, N, F, F / 2, act, 0, x[L - 1], W[L - 1], g, dg, d0, dW[L - 1], db[L - 1]);
-  if (rc) return rc;
-  float* cur = d0;
-  float* nxt = d1;
-  for (int l = L - 2; l >= 0; --l) {
-    rc = ng_add_scaled(ctx, stream, N * F, x[l + 1], x[l], -1.0f, S);
+  const float* cur = dg;
+  float* nxt = d0;
+  for (int l = L - 1; l >= 0; --l) {
+    const int No = l == L - 1 ? F / 2 : F;
+    const bool resid = l < L - 1;
+    if (N == 0) {
+      NG_HIP(ctx, hipMemsetAsync(dW[l], 0, (size_t)F * No * 4, st));
+      NG_HIP(ctx, hipMemsetAsync(db[l], 0, (size_t)No * 4, st));
+      continue;
+    }
+    const int c4n = No / 4, rl = 256 / c4n > 0 ? 256 / c4n : 1;
+    const int nb = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 4);
+    const int64_t rows = cdiv(cdiv(N, nb), rl) * rl;
+    const int nblk = (int)cdiv(N, rows);
+    float* partial = (float*)aux_workspace(ctx, (size_t)nblk * No * 4);
+    if (!partial) return NG_ERR_NOMEM;
+    {
+      ProfScope ps(ctx, st, "fc_dP");
+      hipLaunchKernelGGL(fc_dp_kernel, dim3(nblk), dim3(256), (size_t)rl * No * 4, st, N, No, rows, act, cur,
+                         resid ? x[l + 1] : g, resid ? x[l] : nullptr, dP, partial);
+      launch_reduce_z(st, partial, nblk, (int64_t)No, db[l]);
+      NG_HIP(ctx, hipGetLastError());
+    }
+    float* dwscr = (float*)workspace(ctx, dense_dw_scratch_floats(ctx, N, F, No, false) * sizeof(float));
+    if (!dwscr) return NG_ERR_NOMEM;
+    int rc = dense_dw(ctx, st, N, F, No, NG_ACT_NONE, x[l], dP, nullptr, nullptr, dW[l], nullptr, 0, 0, 0, dwscr, "dense_dw");
     if (rc) return rc;
     float* out = l == 0 ? dx : nxt;
-    rc = ng_dense_bwd(ctx, stream, N, F, F, act, 1, x[l], W[l], S, cur, out, dW[l], db[l]);
+    rc = dense_dx(ctx, st, N, F, No, NG_ACT_NONE, dP, nullptr, nullptr, W[l], resid ? cur : nullptr, out, "dense_dx");
     if (rc) return rc;
-    nxt = cur; cur = out;
+    cur = out;
+    nxt = out == d0 ? d1 : d0;
   }
   return NG_OK;
 }
