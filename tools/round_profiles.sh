@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything the round's evidence is made of, in one gpurun call.  Usage: COMMIT=<sha> bash tools/round_profiles.sh <tag>
+TAG=${1:-r02b}
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+bash tools/profile_bench.sh ${TAG} > gpurun_out/${TAG}_prof.log 2>&1
+bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1
+bash tools/pmc_mfma.sh > gpurun_out/${TAG}_pmc_mfma.log 2>&1
+# the same step at the reference's default width: per-kernel table, rocprof stats, PMC
+python tools/f256_ab.py > gpurun_out/${TAG}_f256_table.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_f256 -o f256 -- python tools/f256_ab.py > /dev/null 2>&1
+find gpurun_out/prof_${TAG}_f256 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_f256_kernel_stats.csv \;
+bash tools/pmc_f256.sh > gpurun_out/${TAG}_pmc_f256.txt 2>&1
+cp gpurun_out/pmc_f256.json gpurun_out/${TAG}_pmc_f256.json
+python tools/aggbench.py > gpurun_out/${TAG}_aggbench.txt 2>&1
+cp gpurun_out/aggbench.json gpurun_out/${TAG}_aggbench.json
+python tools/eval_bench.py > gpurun_out/${TAG}_eval_bench.txt 2>&1
+python tools/graph_frame.py > gpurun_out/${TAG}_graph_frame.txt 2>&1
+python tools/edge_ab.py > gpurun_out/${TAG}_edge_ab.txt 2>&1
+tail -3 gpurun_out/${TAG}_bench.err; head -c 400 gpurun_out/${TAG}_bench.json; echo; tail -4 gpurun_out/${TAG}_eval_bench.txt
