@@ -556,6 +556,7 @@ def whole_protein_leg(dev):
     atoms = atoms_onehot(s.elements)
     n = atoms.shape[0]
     eng = Engine(declare_gnn_space(HyperParameters()), atoms.shape[1], device=dev, seed=1234)
+    eng.freeze_weights(True)        # inference: packed weight images are kept across calls (what eval-struct does)
     pos = torch.from_numpy(frames).to(dev)
     at = torch.from_numpy(atoms).to(dev)
     res = {"workload": f"7lgi: {n} atoms x 100 jittered frames, atom_feature_size 256, graph build on the GPU + "

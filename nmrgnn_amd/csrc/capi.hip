@@ -78,6 +78,22 @@ void* aux_workspace(ng_ctx* ctx, size_t bytes) {
   return p;
 }
 
+void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* valid) {
+  *valid = false;
+  if (!ctx->wcache) return nullptr;
+  ng_ctx::WImage& w = ctx->wimg[std::make_pair(src, kind)];
+  if (w.bytes < bytes) {
+    DeviceGuard dg(ctx->device);
+    if (w.buf) { (void)hipDeviceSynchronize(); (void)hipFree(w.buf); w.buf = nullptr; w.bytes = 0; }
+    if (hipMalloc(&w.buf, bytes) != hipSuccess) { w.buf = nullptr; return nullptr; }
+    w.bytes = bytes;
+    w.ver = 0;
+  }
+  *valid = w.ver == ctx->wver;
+  w.ver = ctx->wver;
+  return w.buf;
+}
+
 ProfScope::ProfScope(ng_ctx* c, hipStream_t s, const char* name) : ctx(c), stream(s) {
   if (!ctx || !ctx->prof) return;
   hipEvent_t a = nullptr, b = nullptr;
@@ -99,6 +115,19 @@ ProfScope::~ProfScope() {
 }  // namespace ng
 
 extern "C" int ng_abi_version(void) { return NG_ABI_VERSION; }
+
+extern "C" int ng_weights_frozen(ng_ctx* ctx, int on) {
+  if (!ctx) return NG_ERR_INVALID;
+  ctx->wcache = on != 0;
+  ctx->wver++;
+  return NG_OK;
+}
+
+extern "C" int ng_weights_changed(ng_ctx* ctx) {
+  if (!ctx) return NG_ERR_INVALID;
+  ctx->wver++;
+  return NG_OK;
+}
 
 extern "C" int ng_reload_env(void) {
   ng::load_switches();
@@ -126,6 +155,8 @@ extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   ng::DeviceGuard dg(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->aux) (void)hipFree(ctx->aux);
+  for (auto& kv : ctx->wimg)
+    if (kv.second.buf) (void)hipFree(kv.second.buf);
   for (auto& r : ctx->recs) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);

@@ -360,11 +360,15 @@ int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
                 float* z_save) {
   const size_t img_bytes = (size_t)X3_NCHUNK * X3_CHUNK;
-  char* img = (char*)workspace(ctx, img_bytes + FH * 4);
+  bool have = false;
+  char* img = (char*)cached_image(ctx, W[0], 2, img_bytes + FH * 4, &have);
+  if (!img) img = (char*)workspace(ctx, img_bytes + FH * 4);
   if (!img) return NG_ERR_NOMEM;
-  hipLaunchKernelGGL(x3_pack_kernel, dim3(cdiv(X3_NCHUNK * 16 * 64, 256)), dim3(256), 0, st, W[0], W[1], W[2], W[3], E,
-                     (unsigned*)img);
-  NG_HIP(ctx, hipGetLastError());
+  if (!have) {
+    hipLaunchKernelGGL(x3_pack_kernel, dim3(cdiv(X3_NCHUNK * 16 * 64, 256)), dim3(256), 0, st, W[0], W[1], W[2], W[3], E,
+                       (unsigned*)img);
+    NG_HIP(ctx, hipGetLastError());
+  }
   EdgeX3Args a;
   a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
   a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);

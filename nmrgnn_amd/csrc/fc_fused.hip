@@ -460,11 +460,13 @@ int fc_fused_pack(ng_ctx* ctx, hipStream_t st, int L, const float* const* W, flo
 int fc_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const float* x, const float* const* W,
                  const float* const* b, float* const* y, float* g) {
   if (N == 0) return NG_OK;
-  float* ws = (float*)workspace(ctx, fc_fused_pack_floats(L) * 4);
+  bool have = false;
+  float* ws = (float*)cached_image(ctx, W[0], 5, fc_fused_pack_floats(L) * 4, &have);
+  if (!ws) ws = (float*)workspace(ctx, fc_fused_pack_floats(L) * 4);
   if (!ws) return NG_ERR_NOMEM;
   float* Wf = ws;
   float* Wb = ws + (size_t)L * FC_F * FC_F;
-  int rc = fc_fused_pack(ctx, st, L, W, Wf, Wb);
+  int rc = have ? NG_OK : fc_fused_pack(ctx, st, L, W, Wf, Wb);
   if (rc) return rc;
   FcFwdArgs a{};
   a.N = N; a.act = act; a.x = x; a.Wf = Wf; a.g = g; a.dummy = ws + (size_t)2 * L * FC_F * FC_F;

@@ -380,9 +380,11 @@ static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int
   const int nbw = a.N % 256 == 0 ? 4 : 2;          // 256-column tiles when N allows
   const int BN = 64 * nbw;
   const size_t img_bytes = (size_t)a.N * a.K * 6;  // three bf16 pieces per weight
-  char* img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
+  bool have = false;
+  char* img = (char*)cached_image(ctx, W, 3 + 16 * trans + 32 * nbw, img_bytes, &have);
+  if (!img) img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
   if (!img) return NG_ERR_NOMEM;
-  {
+  if (!have) {
     const int64_t n_thr = (int64_t)(a.N / 32) * (a.K / 16) * 64;
     hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, a.K, a.N, W, (unsigned*)img, trans,
                        nbw);

@@ -82,14 +82,15 @@ __global__ __launch_bounds__(256) void knn_kernel(int n, int K, float scale,
 // query is unchanged; the serial chain per thread is 8x shorter and a frame spreads over 8x as many workgroups —
 // what a single molecule-sized frame needs (2770 atoms: 0.47 ms -> see tools/knn_time.py).  Order and ties are
 // those of the one-lane kernel: (distance, index) ascending.
-template <int KMAX>
+// S = 8 or 16 lanes per query (one DPP row at most): a single molecule-sized frame (2770 queries) fills 87 / 173 workgroups
+template <int KMAX, int S>
 __global__ __launch_bounds__(256) void knn_kernel_s8(int n, int K, float scale, const float* __restrict__ pos,
                                                      int32_t* __restrict__ nlist, float* __restrict__ edges,
                                                      float* __restrict__ inv_degree) {
   __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
   const int frame = blockIdx.y;
-  const int sl = threadIdx.x & 7;
-  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int sl = threadIdx.x & (S - 1);
+  const int i = blockIdx.x * (256 / S) + threadIdx.x / S;
   const float* fp = pos + (int64_t)frame * n * 3;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (i < n) { qx = fp[3 * i]; qy = fp[3 * i + 1]; qz = fp[3 * i + 2]; }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void knn_kernel_s8(int n, int K, float scale, 
     }
     __syncthreads();
     if (i < n) {
-      for (int t = sl; t < cnt; t += 8) {
+      for (int t = sl; t < cnt; t += S) {
         const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
         const float d2 = dx * dx + dy * dy + dz * dz;
         const int j = t0 + t;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void knn_kernel_s8(int n, int K, float scale, 
     NG_KNN_STEP(0xB1)    // quad_perm 1,0,3,2
     NG_KNN_STEP(0x4E)    // quad_perm 2,3,0,1
     NG_KNN_STEP(0x141)   // row_half_mirror: the other quad of the group of eight
+    if (S >= 16) { NG_KNN_STEP(0x128) }   // row_ror:8: the other eight lanes of the DPP row
 #undef NG_KNN_STEP
     rd[k] = md; ri[k] = mi;
     const bool mine = bi[0] == mi && bd[0] == md;
@@ -182,8 +184,15 @@ extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, floa
   ProfScope ps(ctx, st, "knn_graph");
   const dim3 grid((unsigned)cdiv(n, 256), (unsigned)G), block(256);
   if (K <= 16 && !sw().knn_serial)      // NG_KNN=serial: one lane per query (the first kernel)
-    hipLaunchKernelGGL(knn_kernel_s8<16>, dim3((unsigned)cdiv(n, 32), (unsigned)G), block, 0, st, n, K, scale, pos, nlist,
-                       edges, inv_degree);
+  {
+    const int64_t nq = (int64_t)G * n;          // few queries: more lanes per query, so that the launch still fills the chip
+    if (nq <= 16384)
+      hipLaunchKernelGGL((knn_kernel_s8<16, 16>), dim3((unsigned)cdiv(n, 16), (unsigned)G), block, 0, st, n, K, scale, pos,
+                         nlist, edges, inv_degree);
+    else
+      hipLaunchKernelGGL((knn_kernel_s8<16, 8>), dim3((unsigned)cdiv(n, 32), (unsigned)G), block, 0, st, n, K, scale, pos,
+                         nlist, edges, inv_degree);
+  }
   else if (K <= 16)
     hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, st, n, K, scale, pos, nlist, edges, inv_degree);
   else if (K <= 32)

@@ -419,9 +419,11 @@ int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
   const int64_t KF = (int64_t)E * F;
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;
-  float* Wp = ws;
+  bool have = false;
+  float* Wc = (float*)cached_image(ctx, w, 1, (size_t)KF * F * 4, &have);
+  float* Wp = Wc ? Wc : ws;
   float* A = A_save ? A_save : ws + KF * F;
-  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  int rc = have ? NG_OK : mp_repack_w(ctx, st, F, E, w, Wp);
   if (rc) return rc;
   rc = csr_aggregate(ctx, st, N, K, F, E, h, row_ptr, col, e, A);
   if (rc) return rc;

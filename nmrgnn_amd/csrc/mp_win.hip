@@ -541,9 +541,11 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
                float* s_save) {
   if (N == 0) return NG_OK;
   const int KF = E * WF;
-  float* Wfrag = (float*)workspace(ctx, (size_t)(KF * WF + 64) * 4);
+  bool have = false;
+  float* Wfrag = (float*)cached_image(ctx, w, 4, (size_t)(KF * WF + 64) * 4, &have);
+  if (!Wfrag) Wfrag = (float*)workspace(ctx, (size_t)(KF * WF + 64) * 4);
   if (!Wfrag) return NG_ERR_NOMEM;
-  int rc = mpw_pack(ctx, st, E, 0, w, Wfrag);
+  int rc = have ? NG_OK : mpw_pack(ctx, st, E, 0, w, Wfrag);
   if (rc) return rc;
   MpWinFwdArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "../../include/nmrgnn_hip.h"
@@ -29,6 +31,13 @@ struct ng_ctx {
   std::vector<hipEvent_t> pool;
   // cached device properties
   int num_cu = 256;
+  // packed weight images kept across calls while the caller declares the weights frozen (ng_weights_frozen):
+  // inference repacks nothing.  key = (source pointer, image kind); an entry is valid while its version equals wver,
+  // which ng_weights_changed / ng_adam_step / (un)freezing bump.
+  struct WImage { void* buf = nullptr; size_t bytes = 0; uint64_t ver = 0; };
+  bool wcache = false;
+  uint64_t wver = 1;
+  std::map<std::pair<const void*, int>, WImage> wimg;
 };
 
 namespace ng {
@@ -85,6 +94,10 @@ inline int fail(ng_ctx* ctx, int code, const std::string& msg) {
 // scratch: returns nullptr on failure (error string set)
 void* workspace(ng_ctx* ctx, size_t bytes);
 void* aux_workspace(ng_ctx* ctx, size_t bytes);
+// Frozen-weight image cache.  Returns nullptr when the cache is off (pack into scratch as before); otherwise a
+// persistent buffer of `bytes` for (src, kind) with *valid = true when it already holds the image of the current
+// weights (skip the pack launch).  kinds: 1 MPLayer Wp, 2 edge x3 image, 3 GEMM x3 image, 4 window fragments, 5 FC fragments
+void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* valid);
 
 // RAII-less profiling bracket: call begin before the launch(es), end after.
 struct ProfScope {

@@ -613,9 +613,11 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;
   float* ws = (float*)workspace(ctx, need);
   if (!ws) return NG_ERR_NOMEM;
-  float* Wp = ws;
+  bool have = false;
+  float* Wc = (float*)cached_image(ctx, w, 1, (size_t)KF * F * 4, &have);
+  float* Wp = Wc ? Wc : ws;
   float* A = A_save ? A_save : ws + KF * F;
-  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  int rc = have ? NG_OK : mp_repack_w(ctx, st, F, E, w, Wp);
   if (rc) return rc;
   rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, A);
   if (rc) return rc;
@@ -786,6 +788,7 @@ extern "C" int ng_adam_step(ng_ctx* ctx, void* stream, int64_t n, float* p, cons
                             float grad_scale) {
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, step >= 1, "adam: step counts from 1");
+  ctx->wver++;                       // packed weight images of a frozen-weight cache are stale from here on
   if (n == 0) return NG_OK;
   const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) /
                       (1.0 - std::pow((double)beta1, (double)step));

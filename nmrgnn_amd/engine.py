@@ -62,6 +62,7 @@ class Engine:
         self.fc_act = ACT[hp.get('fc_activation')]
         self.mp_act = ACT[hp.get('mp_activation')]
         self.params = ParamStore(hp, self.C, self.device, seed=seed)
+        self.params.on_change = lambda: self.lib.ng_weights_changed(self.ctx.handle)
         c, gap = rbf_grid(hp.get('rbf_low'), hp.get('rbf_high'), self.H)
         self.centers = torch.from_numpy(c).to(self.device)
         self.gap = gap
@@ -75,6 +76,17 @@ class Engine:
         self.adam_t = 0
         self.tape = None
         self._rng_calls = 0
+
+    # ------------------------------------------------------------------ frozen weights (inference)
+    def freeze_weights(self, on=True):
+        """Inference with constant weights: the library keeps its packed weight images across calls instead of
+        re-packing them on every call (several launches per call at molecule size).  Weight changes through
+        ``params.load_state_dict`` / ``adam_step`` are noticed; after writing into a parameter view directly call
+        ``weights_changed()``."""
+        self._ck(self.lib.ng_weights_frozen(self.ctx.handle, 1 if on else 0), "ng_weights_frozen")
+
+    def weights_changed(self):
+        self._ck(self.lib.ng_weights_changed(self.ctx.handle), "ng_weights_changed")
 
     # ------------------------------------------------------------------ helpers
     def _st(self):

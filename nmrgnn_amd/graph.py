@@ -35,7 +35,7 @@ class GraphBatch:
     row_ptr = None
 
     def __init__(self, atoms, nlist, edges, inv_degree, graph_ptr=None, device=None,
-                 validate=True):
+                 validate=True, nlist_c=None):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
@@ -64,8 +64,11 @@ class GraphBatch:
         # compute-side copy of the lists: padded slots (edges == 0, weight exactly 0 after the edge mask)
         # point at the atom itself instead of row 0, so that the row range a tile of atoms references
         # stays local and the window-resident MP kernels (csrc/mp_win.hip) can keep it in LDS
-        own = torch.arange(self.N, dtype=torch.int32, device=self.device)[:, None]
-        self.nlist_c = torch.where(self.edges > 0, self.nlist, own).contiguous()
+        if nlist_c is not None:            # the caller knows the lists carry no padded slot (e.g. kNN with n > K)
+            self.nlist_c = nlist_c
+        else:
+            own = torch.arange(self.N, dtype=torch.int32, device=self.device)[:, None]
+            self.nlist_c = torch.where(self.edges > 0, self.nlist, own).contiguous()
 
     # ------------------------------------------------------------------ CSR form
     @classmethod
@@ -210,7 +213,9 @@ def frames_to_batch(atoms, frames, neighbor_number=16, scale=0.1, device=None):
     ctx.check(ctx.lib.ng_knn_graph(ctx.handle, st, G, n, K, float(scale), ptr(pos), ptr(nlist), ptr(edges),
                                    ptr(inv)), "ng_knn_graph")
     ptrs = np.arange(G + 1, dtype=np.int64) * n
-    return GraphBatch(at.repeat(G, 1), nlist, edges, inv, graph_ptr=ptrs, device=device, validate=False)
+    # n > K: every atom has K real neighbours, no padded slot -> the compute-side list IS the list
+    return GraphBatch(at.repeat(G, 1) if G > 1 else at, nlist, edges, inv, graph_ptr=ptrs, device=device, validate=False,
+                      nlist_c=nlist if n > K else None)
 
 
 def frames_to_batch_cutoff(atoms, frames, cutoff=4.0, scale=0.1, device=None):

@@ -49,6 +49,8 @@ def eval_structure(struct_files, output_csv, model_file=None, neighbor_number=16
     frame_ids = list(range(0, len(u), stride))
     atoms = atoms_onehot(u.elements)
     n = atoms.shape[0]
+    model.build(atoms.shape[1])
+    model.freeze()          # inference only: the engine keeps its packed weight images across the per-frame calls
     timing = {'Structure': 0.0, 'Model Inference (MI355X)': 0.0, 'Parsing': 0.0}
     rows = []
     for b0 in range(0, len(frame_ids), max(1, frames_per_batch)):

@@ -94,6 +94,12 @@ class GNNModel:
     call = __call__
     predict = __call__
 
+    def freeze(self, on=True):
+        """declare the weights constant (inference): packed weight images are cached across calls"""
+        self._need_engine()
+        self.engine.freeze_weights(on)
+        return self
+
     # -- weights
     def get_weights(self):
         self._need_engine()

@@ -68,6 +68,7 @@ class ParamStore:
             o, n = self.offsets[name], int(np.prod(shape))
             self.views[name] = self.flat[o:o + n].view(*shape)
             self.grad_views[name] = self.grad[o:o + n].view(*shape)
+        self.on_change = None
         self.init_glorot(seed)
 
     def init_glorot(self, seed):
@@ -99,6 +100,8 @@ class ParamStore:
             if tuple(t.shape) != tuple(self.shapes[k]):
                 raise ValueError(f"{k}: shape {tuple(t.shape)} != {tuple(self.shapes[k])}")
             self.views[k].copy_(t)
+        if getattr(self, "on_change", None) is not None:
+            self.on_change()              # packed weight images cached by the library are stale now
 
     def grads_dict(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.grad_views.items()}

@@ -64,3 +64,37 @@ def test_training_step_is_bitwise_reproducible(gpu_device, F):
         else:
             assert torch.equal(cur[0], ref[0])
             assert torch.equal(cur[1], ref[1])
+
+
+def test_frozen_weight_cache_tracks_weight_changes(gpu_device):
+    """ng_weights_frozen keeps the packed weight images across calls; every sanctioned way of changing weights
+    (load_state_dict, an Adam step) must invalidate them, unfreezing must switch the cache off — the outputs always equal
+    those of an engine that re-packs on every call."""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    for F in (64, 256):
+        hp = make_hp(atom_feature_size=F)
+        b = synth.make_batch(3, 50, 16, 10, 0.1, seed=3)
+        gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+        ref = Engine(hp, 10, device=gpu_device, seed=9)          # never frozen
+        eng = Engine(hp, 10, device=gpu_device, seed=9)
+        eng.freeze_weights(True)
+        assert torch.equal(eng.forward(gb), ref.forward(gb))
+        assert torch.equal(eng.forward(gb), ref.forward(gb))     # second call: served from the cache
+        sd = randomize_biases(ref, seed=4)
+        eng.params.load_state_dict(sd)                           # announces the change itself
+        assert torch.equal(eng.forward(gb), ref.forward(gb))
+        dpe = torch.ones(gb.N, device=gpu_device)
+        for e in (eng, ref):
+            e.forward(gb, training=True, seed=3)
+            e.backward(dpe)
+            e.adam_step(lr=1e-2)                                 # ng_adam_step bumps the weight version
+        assert torch.equal(eng.forward(gb), ref.forward(gb))
+        eng.params["fc/0/bias"].add_(0.5)                        # a raw write into a view needs weights_changed()
+        ref.params["fc/0/bias"].add_(0.5)
+        eng.weights_changed()
+        assert torch.equal(eng.forward(gb), ref.forward(gb))
+        eng.freeze_weights(False)
+        assert torch.equal(eng.forward(gb), ref.forward(gb))
