@@ -18,4 +18,5 @@ cp gpurun_out/aggbench.json gpurun_out/${TAG}_aggbench.json
 python tools/eval_bench.py > gpurun_out/${TAG}_eval_bench.txt 2>&1
 python tools/graph_frame.py > gpurun_out/${TAG}_graph_frame.txt 2>&1
 python tools/edge_ab.py > gpurun_out/${TAG}_edge_ab.txt 2>&1
+python tools/frame_loop.py > gpurun_out/${TAG}_frame_loop.txt 2>&1
 tail -3 gpurun_out/${TAG}_bench.err; head -c 400 gpurun_out/${TAG}_bench.json; echo; tail -4 gpurun_out/${TAG}_eval_bench.txt
