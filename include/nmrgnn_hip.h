@@ -199,13 +199,22 @@ int ng_cutoff_fill(ng_ctx*, void* stream, int G, int n, float cutoff, float scal
 int ng_knn_graph(ng_ctx*, void* stream, int G, int n, int K, float scale, const float* pos,
                  int32_t* nlist, float* edges, float* inv_degree);
 
-/* AMPLayer attention aggregation, nmrgnn/layers.py:89-96 (forward only; the layer is exported by the
- * reference package but not used by its model):
+/* AMPLayer attention aggregation, nmrgnn/layers.py:89-96 (the layer is exported by the reference package but not
+ * used by its model):
  *   b[i,:] = softmax_j( inv[i] * <e[i,j,:] @ wk, h[i,:] @ wq> ),  agg[i,:] = sum_j b[i,j] * h[nlist[i,j],:]
  * The layer output is act(agg @ wv) = ng_dense_fwd(agg, wv, bias 0).  K <= 64, E <= 64. */
 int ng_amp_attend(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const float* h,
                   const int32_t* nlist, const float* e, const float* inv_degree, const float* wq,
                   const float* wk, float* agg);
+/* Backward of ng_amp_attend (the gradient TensorFlow derives for nmrgnn/layers.py:89-96): from dagg = d loss/d agg
+ * it writes dh [N,F] (both uses of the node features: the gathered values and the query), de [N,K,E], dwq [F,E] and
+ * dwk [E,E].  in_ptr [N+1] / in_slot [N*K] list, for every atom t, the slots i*K+j of nlist that hold t (ALL slots:
+ * the reference's softmax runs over padded slots too, layers.py:94); the sums follow the list order, no atomics.
+ * The wv product in front is ng_dense_bwd. */
+int ng_amp_attend_bwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, const float* h,
+                      const int32_t* nlist, const float* e, const float* inv_degree, const float* wq,
+                      const float* wk, const int32_t* in_ptr, const int32_t* in_slot, const float* dagg,
+                      float* dh, float* de, float* dwq, float* dwk);
 
 /* FCBlock, nmrgnn/model.py:179-196, all layers in one call:
  *   x_{l+1} = act(x_l @ W[l] + b[l]) + x_l   for l < L-1  (F -> F),   g = act(x_{L-1} @ W[L-1] + b[L-1])  (F -> F/2)

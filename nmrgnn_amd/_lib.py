@@ -76,6 +76,7 @@ SIGNATURES = {
     "ng_fc_block_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_knn_graph": (_int, [_vp, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _vp]),
     "ng_amp_attend": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_amp_attend_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int] + [_vp] * 13),
     "ng_loss_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_loss_name": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "ng_adam_step": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _f]),

@@ -334,6 +334,116 @@ __global__ __launch_bounds__(256) void amp_attend_kernel(int64_t N, int K, int F
   }
 }
 
+// Backward of the attention aggregation.  With q = h_i wq, u = wk q, s_j = inv_i <e_ij, u>, b = softmax(s),
+// agg_i = sum_j b_j h[nl_ij] and dA = d loss / d agg_i:
+//   db_j = <dA, h[nl_ij]>,  ds_j = b_j (db_j - sum_k b_k db_k),  de_ij = inv_i ds_j u,
+//   du = inv_i sum_j ds_j e_ij,  dq = wk^T du,  dwk = sum_i du q^T,  dwq = sum_i h_i dq^T,
+//   dh_t = sum_{(i,j): nl_ij = t} b_ij dA_i  +  dq_t wq^T.
+// Pass 1 (one wave per atom) recomputes q, u, b and leaves b [N,K], q, du, dq [N,E] in the workspace and de in
+// place; pass 2 pulls dh over the incoming-slot lists (no atomics: the order of the sum is the list order);
+// pass 3 forms the two weight gradients from per-block partial sums reduced in a fixed order.
+__global__ __launch_bounds__(256) void amp_attend_bwd_atom_kernel(
+    int64_t N, int K, int F, int E, const float* __restrict__ h, const int32_t* __restrict__ nlist,
+    const float* __restrict__ e, const float* __restrict__ inv, const float* __restrict__ wq,
+    const float* __restrict__ wk, const float* __restrict__ dagg, float* __restrict__ bsave,
+    float* __restrict__ qbuf, float* __restrict__ dubuf, float* __restrict__ dqbuf, float* __restrict__ de) {
+  __shared__ float sq[4][64], su[4][64], sdu[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  if (i >= N) return;
+  for (int n = 0; n < E; ++n) {
+    float p = 0.f;
+    for (int l = lane; l < F; l += 64) p += h[i * F + l] * wq[l * E + n];
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    if (lane == 0) sq[wv][n] = p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < E) {
+    float p = 0.f;
+    for (int k = 0; k < E; ++k) p += wk[lane * E + k] * sq[wv][k];
+    su[wv][lane] = p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float iv = inv[i];
+  float qd = -INFINITY;
+  int nb = 0;
+  if (lane < K) {
+    const float* ep = e + (i * K + lane) * E;
+    float p = 0.f;
+    for (int n = 0; n < E; ++n) p += ep[n] * su[wv][n];
+    qd = iv * p;
+    nb = nlist[i * K + lane];
+  }
+  float mx = qd;
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  const float ex = lane < K ? __expf(qd - mx) : 0.f;
+  float sm = ex;
+  for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
+  const float b = ex / sm;
+  float db = 0.f;
+  for (int j = 0; j < K; ++j) {
+    const int tj = __shfl(nb, j, 64);
+    float p = 0.f;
+    for (int l = lane; l < F; l += 64) p += dagg[i * F + l] * h[(int64_t)tj * F + l];
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    if (lane == j) db = p;
+  }
+  float t = b * db;
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  const float ds = b * (db - t);
+  if (lane < K) {
+    bsave[i * K + lane] = b;
+    float* dp = de + (i * K + lane) * E;
+    for (int n = 0; n < E; ++n) dp[n] = iv * ds * su[wv][n];
+  }
+  for (int n = 0; n < E; ++n) {
+    float p = lane < K ? ds * e[(i * K + lane) * E + n] : 0.f;
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    if (lane == 0) sdu[wv][n] = iv * p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < E) {
+    float p = 0.f;
+    for (int n = 0; n < E; ++n) p += wk[n * E + lane] * sdu[wv][n];
+    qbuf[i * E + lane] = sq[wv][lane];
+    dubuf[i * E + lane] = sdu[wv][lane];
+    dqbuf[i * E + lane] = p;
+  }
+}
+
+__global__ __launch_bounds__(256) void amp_attend_bwd_pull_kernel(
+    int64_t N, int K, int F, int E, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_slot,
+    const float* __restrict__ bsave, const float* __restrict__ dagg, const float* __restrict__ dqbuf,
+    const float* __restrict__ wq, float* __restrict__ dh) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= N) return;
+  const int a = in_ptr[t], z = in_ptr[t + 1];
+  for (int l = lane; l < F; l += 64) {
+    float acc = 0.f;
+    for (int n = 0; n < E; ++n) acc += dqbuf[t * E + n] * wq[l * E + n];
+    for (int c = a; c < z; ++c) {
+      const int s = in_slot[c];
+      acc += bsave[s] * dagg[(int64_t)(s / K) * F + l];
+    }
+    dh[t * F + l] = acc;
+  }
+}
+
+// partial[b][r*C + c] = sum over the block's atoms of X[i,r] * Y[i,c]
+__global__ __launch_bounds__(256) void amp_outer_partial_kernel(int64_t N, int R, int C, int64_t rows_per_block,
+                                                                const float* __restrict__ X,
+                                                                const float* __restrict__ Y,
+                                                                float* __restrict__ partial) {
+  const int64_t i0 = (int64_t)blockIdx.x * rows_per_block, i1 = min(N, i0 + rows_per_block);
+  for (int idx = threadIdx.x; idx < R * C; idx += 256) {
+    const int r = idx / C, c = idx % C;
+    float acc = 0.f;
+    for (int64_t i = i0; i < i1; ++i) acc += X[i * R + r] * Y[i * C + c];
+    partial[(int64_t)blockIdx.x * R * C + idx] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------ loss
 // one wave per graph: lg = sum w (y-p)^2 / sum w ; dpred = -2 w (y-p) / (sum w * G)
 __global__ __launch_bounds__(256) void loss_graph_kernel(int G, const int32_t* __restrict__ gptr,
@@ -744,6 +854,44 @@ extern "C" int ng_amp_attend(ng_ctx* ctx, void* stream, int64_t N, int K, int F,
   ProfScope ps(ctx, st, "amp_attend");
   hipLaunchKernelGGL(amp_attend_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, st, N, K, F, E, h,
                      nlist, e, inv_degree, wq, wk, agg);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_amp_attend_bwd(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, const float* h,
+                                 const int32_t* nlist, const float* e, const float* inv_degree,
+                                 const float* wq, const float* wk, const int32_t* in_ptr,
+                                 const int32_t* in_slot, const float* dagg, float* dh, float* de, float* dwq,
+                                 float* dwk) {
+  if (!ctx) return NG_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  NG_REQUIRE(ctx, K >= 1 && K <= 64, "amp: neighbour count must be in [1,64]");
+  NG_REQUIRE(ctx, E >= 1 && E <= 64, "amp: edge feature size must be in [1,64]");
+  NG_REQUIRE(ctx, F >= 1, "amp: bad feature size");
+  if (N == 0) {
+    NG_HIP(ctx, hipMemsetAsync(dwq, 0, (size_t)F * E * 4, st));
+    NG_HIP(ctx, hipMemsetAsync(dwk, 0, (size_t)E * E * 4, st));
+    return NG_OK;
+  }
+  const int64_t rows_per_block = 256;
+  const int64_t nb = cdiv(N, rows_per_block);
+  const size_t n_small = (size_t)N * E, n_b = (size_t)N * K;
+  const size_t part = (size_t)nb * ((size_t)F * E + (size_t)E * E);
+  float* ws = (float*)workspace(ctx, (n_b + 3 * n_small + part) * 4);
+  if (!ws) return NG_ERR_NOMEM;
+  float *bsave = ws, *qbuf = bsave + n_b, *dubuf = qbuf + n_small, *dqbuf = dubuf + n_small;
+  float *pq = dqbuf + n_small, *pk = pq + (size_t)nb * F * E;
+  ProfScope ps(ctx, st, "amp_attend_bwd");
+  hipLaunchKernelGGL(amp_attend_bwd_atom_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, st, N, K, F, E, h,
+                     nlist, e, inv_degree, wq, wk, dagg, bsave, qbuf, dubuf, dqbuf, de);
+  hipLaunchKernelGGL(amp_attend_bwd_pull_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, st, N, K, F, E,
+                     in_ptr, in_slot, bsave, dagg, dqbuf, wq, dh);
+  hipLaunchKernelGGL(amp_outer_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, N, F, E, rows_per_block, h,
+                     dqbuf, pq);
+  hipLaunchKernelGGL(amp_outer_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, N, E, E, rows_per_block,
+                     dubuf, qbuf, pk);
+  launch_reduce_z(st, pq, (int)nb, (int64_t)F * E, dwq);
+  launch_reduce_z(st, pk, (int)nb, (int64_t)E * E, dwk);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

@@ -181,6 +181,22 @@ class _DenseStack(_Layer):
                                        ptr(y), None), "ng_dense_fwd")
         return y[:, :Nout].contiguous() if Np != Nout else y
 
+    def _dense_bwd(self, x, W, y, dy, act, dev):
+        """gradients of ``y = act(x @ W + b)`` (no residual): (dx, dW, db); same zero padding as :meth:`_dense`."""
+        M, Kin = x.shape
+        Nout = W.shape[1]
+        Kp, Np = (Kin + 7) // 8 * 8, (Nout + 3) // 4 * 4
+        pad = torch.nn.functional.pad
+        x, W = pad(x, (0, Kp - Kin)).contiguous(), pad(W, (0, Np - Nout, 0, Kp - Kin)).contiguous()
+        y, dy = pad(y, (0, Np - Nout)).contiguous(), pad(dy, (0, Np - Nout)).contiguous()
+        dx = torch.empty(M, Kp, dtype=torch.float32, device=dev)
+        dW = torch.empty(Kp, Np, dtype=torch.float32, device=dev)
+        db = torch.empty(Np, dtype=torch.float32, device=dev)
+        ctx = self._ctx(dev)
+        ctx.check(ctx.lib.ng_dense_bwd(ctx.handle, self._st(dev), M, Kp, Np, ACT[act], 0, ptr(x), ptr(W), ptr(y),
+                                       ptr(dy), ptr(dx), ptr(dW), ptr(db)), "ng_dense_bwd")
+        return dx[:, :Kin].contiguous(), dW[:Kin, :Nout].contiguous(), db[:Nout].contiguous()
+
 
 class EdgeFCBlock(_DenseStack):
     """nmrgnn/model.py:109-144: (edge_fc_layers-1) x Dense(edge_hidden_size, fc_activation) + Dense(edge_feature_size)."""
@@ -262,7 +278,8 @@ class FCBlock(_DenseStack):
 class AMPLayer(_DenseStack):
     """nmrgnn/layers.py:48-100: attention message passing.  ``b = softmax_j(inv_degree_i *
     <edges_ij @ wk, nodes_i @ wq>)``, ``out = activation(sum_j b_ij * (nodes[nlist_ij] @ wv))``.
-    Forward only, like its use in the reference (a shape test; the model is built from MPLayer)."""
+    The reference only calls it in a shape test (the model is built from MPLayer); :meth:`backward` returns what
+    TensorFlow's autodiff would for that call."""
 
     def __init__(self, activation=None, kernel_regularizer=None, name='AMPLayer', **kwargs):
         super().__init__()
@@ -296,4 +313,33 @@ class AMPLayer(_DenseStack):
                                         ptr(edges), ptr(inv), ptr(self.wq.contiguous()),
                                         ptr(self.wk.contiguous()), ptr(agg)), "ng_amp_attend")
         zero = torch.zeros(F, dtype=torch.float32, device=dev)
-        return self._dense(agg, self.wv, zero, self.activation, False, dev)
+        out = self._dense(agg, self.wv, zero, self.activation, False, dev)
+        self._saved = (nodes, nlist, edges, inv, agg, out)
+        return out
+
+    def backward(self, dout):
+        """Gradients of the last call: returns ``(dnodes [N,F], dedges [N,K,E])`` and leaves the weight gradients in
+        ``self.grads`` (keys 'wq', 'wk', 'wv').  The sums run in a fixed order (incoming-slot lists, no atomics)."""
+        if getattr(self, "_saved", None) is None:
+            raise RuntimeError("AMPLayer.backward needs a forward call first")
+        nodes, nlist, edges, inv, agg, out = self._saved
+        dev = nodes.device
+        N, F = nodes.shape
+        K, E = nlist.shape[1], edges.shape[-1]
+        dagg, dwv, _ = self._dense_bwd(agg, self.wv, out, _f32(dout, dev).reshape(N, F), self.activation, dev)
+        tgt = nlist.reshape(-1).to(torch.int64)
+        in_slot = torch.argsort(tgt, stable=True).to(torch.int32).contiguous()
+        in_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        in_ptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=N), 0)
+        in_ptr = in_ptr.to(torch.int32).contiguous()
+        dh = torch.empty(N, F, dtype=torch.float32, device=dev)
+        de = torch.empty(N, K, E, dtype=torch.float32, device=dev)
+        dwq = torch.empty(F, E, dtype=torch.float32, device=dev)
+        dwk = torch.empty(E, E, dtype=torch.float32, device=dev)
+        ctx = self._ctx(dev)
+        ctx.check(ctx.lib.ng_amp_attend_bwd(ctx.handle, self._st(dev), N, K, F, E, ptr(nodes), ptr(nlist), ptr(edges),
+                                            ptr(inv), ptr(self.wq.contiguous()), ptr(self.wk.contiguous()),
+                                            ptr(in_ptr), ptr(in_slot), ptr(dagg), ptr(dh), ptr(de), ptr(dwq),
+                                            ptr(dwk)), "ng_amp_attend_bwd")
+        self.grads = {"wq": dwq, "wk": dwk, "wv": dwv}
+        return dh, de

@@ -296,6 +296,39 @@ def amp_layer_forward(nodes, nlist, edges, inv_degree, wq, wk, wv, act=None):
     return _act(act)(reduced)
 
 
+def amp_layer_backward(nodes, nlist, edges, inv_degree, wq, wk, wv, act, dout):
+    """Reverse pass through layers.py:89-96 exactly as written there (values = gathered @ wv BEFORE the weighted sum).
+    Returns dict(nodes, edges, wq, wk, wv).  Checked against central differences in tests/test_oracle.py."""
+    nodes = np.asarray(nodes, np.float64)
+    edges = np.asarray(edges, np.float64)
+    inv = np.asarray(inv_degree, np.float64)
+    wq, wk, wv = (np.asarray(w, np.float64) for w in (wq, wk, wv))
+    nl = np.asarray(nlist)
+    sliced = nodes[nl]
+    query = nodes @ wq
+    keys = edges @ wk
+    values = sliced @ wv
+    qdot = np.einsum('i,ijk,ik->ij', inv, keys, query)
+    b = np.exp(qdot - qdot.max(axis=-1, keepdims=True))
+    b /= b.sum(axis=-1, keepdims=True)
+    reduced = np.einsum('ij,ijk->ik', b, values)
+    dred = np.asarray(dout, np.float64) * _act_grad(act)(reduced)
+    db = np.einsum('ik,ijk->ij', dred, values)
+    dvalues = b[:, :, None] * dred[:, None, :]
+    dwv = np.einsum('ijl,ijk->lk', sliced, dvalues)
+    dsliced = dvalues @ wv.T
+    dnodes = np.zeros_like(nodes)
+    np.add.at(dnodes, nl.reshape(-1), dsliced.reshape(-1, nodes.shape[1]))
+    dqdot = b * (db - np.sum(b * db, axis=-1, keepdims=True))
+    dkeys = inv[:, None, None] * dqdot[:, :, None] * query[:, None, :]
+    dquery = np.einsum('i,ij,ijk->ik', inv, dqdot, keys)
+    dwk = np.einsum('ijn,ijk->nk', edges, dkeys)
+    dedges = dkeys @ wk.T
+    dwq = nodes.T @ dquery
+    dnodes += dquery @ wq.T
+    return dict(nodes=dnodes, edges=dedges, wq=dwq, wk=dwk, wv=dwv)
+
+
 def name_loss(y_true, y_pred, label_idx, s=1.0):
     """nmrgnn/losses.py:30-39 for ONE graph.  y_true[:,0]=label, [:,1]=name id, [:,-1]=weight."""
     y_true = np.asarray(y_true, np.float64)

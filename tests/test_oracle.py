@@ -250,3 +250,34 @@ def test_name_loss_balance_matches_reference_formula_autograd():
     from nmrgnn_amd.losses import NameLoss
     single = NameLoss(label_idx=None, s=0.3)(np.stack([y[:40], np.zeros(40), w[:40]], 1), pred[:40])
     assert single == pytest.approx(O.batch_loss_name(y[:40], w[:40], pred[:40], [0, 40], 0.3)[0])
+
+
+@pytest.mark.parametrize("act", [None, "softplus", "tanh"])
+def test_amp_layer_backward_matches_central_differences(act):
+    """oracle.amp_layer_backward (the reverse of layers.py:89-96) against central differences of the literal forward."""
+    rng = np.random.default_rng(11)
+    N, K, F, E = 7, 5, 6, 3
+    nodes = rng.standard_normal((N, F))
+    nlist = rng.integers(0, N, (N, K))
+    edges = rng.standard_normal((N, K, E))
+    edges[:, K - 1] = 0.0
+    nlist[:, K - 1] = 0
+    inv = 1.0 / rng.integers(1, K, N)
+    wq, wk, wv = rng.standard_normal((F, E)), rng.standard_normal((E, E)), rng.standard_normal((F, F)) * 0.4
+    dout = rng.standard_normal((N, F))
+    g = O.amp_layer_backward(nodes, nlist, edges, inv, wq, wk, wv, act, dout)
+    args = dict(nodes=nodes, edges=edges, wq=wq, wk=wk, wv=wv)
+
+    def loss(**kw):
+        a = {**args, **kw}
+        return float(np.sum(dout * O.amp_layer_forward(a["nodes"], nlist, a["edges"], inv, a["wq"], a["wk"], a["wv"], act)))
+
+    h = 1e-6
+    for name, x in args.items():
+        for _ in range(6):
+            idx = tuple(rng.integers(0, d) for d in x.shape)
+            xp, xm = x.copy(), x.copy()
+            xp[idx] += h
+            xm[idx] -= h
+            fd = (loss(**{name: xp}) - loss(**{name: xm})) / (2 * h)
+            assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, idx, fd, g[name][idx])
