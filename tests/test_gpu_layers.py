@@ -116,6 +116,7 @@ def test_amplayer_backward_matches_oracle(gpu_device, F, E, act):
     """Gradients of AMPLayer (layers.py:48-100) w.r.t. nodes, edges, wq, wk, wv vs the fp64 reverse pass of the oracle;
     padded slots (nlist 0, edges 0) take part in the softmax and receive gradient, as in the reference.  Run twice: the
     backward has no atomics, so the results are bit-identical."""
+    import torch
     import nmrgnn_amd
     from oracle import nmrgnn_oracle as O
     rng = np.random.default_rng(5)
