@@ -138,9 +138,6 @@ __device__ __forceinline__ void bx_dw_load(BxDwFrags& f, const char* zb, const c
 // (layer, n-slab) column sums in disjoint column groups — 6 MFMAs per layer instead of 80 DPP adds + an LDS update.
 __device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], f32x16& accB, int cbase, const char* __restrict__ imgZ,
                                            const char* __restrict__ imgG, int kslab, int nsl0, int lane) {
-  const unsigned grp = (unsigned)((lane & 31) / 5);
-  const unsigned o0 = grp == (unsigned)cbase ? 0x3F803F80u : 0u, o1 = grp == (unsigned)(cbase + 1) ? 0x3F803F80u : 0u;
-  const u32x4 ones0 = {o0, o0, o0, o0}, ones1 = {o1, o1, o1, o1};
   const int g = lane >> 4, i = lane & 15;
   // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2) of the quad, columns 4(i&3)..+3
   const char* zb = imgZ + (4 * (g >> 1) + 8 * (i >> 2)) * BX_ROWZ + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * kslab;
@@ -156,6 +153,13 @@ __device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], f32x16& accB, int c
     acc[0] = mfma_bf16(c.a0[0], c.b[1], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[1], acc[1]);
     acc[0] = mfma_bf16(c.a0[0], c.b[0], acc[0]); acc[1] = mfma_bf16(c.a1[0], c.b[0], acc[1]);
     if (ks == kslab) {
+      // the ones operand is rebuilt here from the lane id (the asm keeps the compiler from hoisting it out of the tile
+      // loop, where it became a spilled invariant whose reload carried a vmcnt(0) into the middle of the prefetches)
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const unsigned grp = (unsigned)((lv & 31) / 5);
+      const unsigned o0 = grp == (unsigned)cbase ? 0x3F803F80u : 0u, o1 = grp == (unsigned)(cbase + 1) ? 0x3F803F80u : 0u;
+      const u32x4 ones0 = {o0, o0, o0, o0}, ones1 = {o1, o1, o1, o1};
 #pragma unroll
       for (int p = 2; p >= 0; --p) { accB = mfma_bf16(c.a0[p], ones0, accB); accB = mfma_bf16(c.a1[p], ones1, accB); }
     }
@@ -183,17 +187,18 @@ __device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restr
   f32x16 acc0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-  u32x4 wa[2][3], b[2][3];
+  u32x4 wa[3][3], b[2][3];     // W^T fragments two steps ahead (L2 latency is ~3 steps of 6 MFMAs), G rows one step ahead
 #pragma unroll
   for (int p = 0; p < 3; ++p) { wa[0][p] = w0[p]; b[0][p] = *reinterpret_cast<const u32x4*>(gb + p * BX_PIECE_G); }
+  bx_wload(wa[1], wrs, wvo, wso, 1);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
+    if (ks < 6) bx_wload(wa[(ks + 2) % 3], wrs, wvo, wso, ks + 2);
     if (ks < 7) {
-      bx_wload(wa[(ks + 1) & 1], wrs, wvo, wso, ks + 1);
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[(ks + 1) & 1][p] = *reinterpret_cast<const u32x4*>(gb + 32 * (ks + 1) + p * BX_PIECE_G);
     }
-    acc0 = mma6(wa[ks & 1], b[ks & 1], acc0);
+    acc0 = mma6(wa[ks % 3], b[ks & 1], acc0);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
