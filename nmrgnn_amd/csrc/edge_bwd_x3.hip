@@ -183,7 +183,11 @@ __device__ __forceinline__ void bx_dz_gemm(float (&out)[16], const char* __restr
                                            __amdgpu_buffer_rsrc_t wrs, const u32x4 (&w0)[3], int L, int zk, int lane) {
   const int half = lane >> 5;
   const char* gb = imgG + prow_g * BX_ROWG + 16 * half;
-  const int wvo = lane * 16, wso = ((L * 4 + zk) * 8) * 3 * 1024;
+  const int wvo = lane * 16;
+  int wso = ((L * 4 + zk) * 8) * 3 * 1024;
+  // opaque to the optimizer: otherwise the 2 x 24 fragment offsets (wso + const) are hoisted out of the tile loop as
+  // scalar invariants, spilled into VGPR lanes and fetched back with v_readlane + s_nop 4 in front of every load
+  asm volatile("" : "+s"(wso));
   f32x16 acc0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
@@ -226,6 +230,16 @@ __device__ __forceinline__ float bx_sprime(float x, float z) {
   return fmaf(-x, __builtin_amdgcn_exp2f(-1.4426950408889634f * z), x);
 }
 
+// the same for two values at once: the scale and the final fma as packed fp32 instructions
+typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bx_sprime2(float& x0, float& x1, float z0, float z1) {
+  const bx_f32x2 t = bx_f32x2{z0, z1} * bx_f32x2{-1.4426950408889634f, -1.4426950408889634f};
+  const bx_f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const bx_f32x2 x = {x0, x1};
+  const bx_f32x2 r = __builtin_elementwise_fma(-x, e, x);
+  x0 = r[0]; x1 = r[1];
+}
+
 #ifdef BX_STAMP
 #define BX_T(k)                                                                              \
   do {                                                                                       \
@@ -264,7 +278,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
 #define BX_ZOFF(ROW0, GI) (BX_ZFULL(ROW0) ? (int)(((ROW0) / 32 + zrt) * 16384 + (zk * 256 + lane) * 16) : (GI) * (FH * 4) + col0 * 4)
 #define BX_ZQ(ROW0) (BX_ZFULL(ROW0) ? 1024 : 32)
 
-  for (int t = tid; t < FH * 4; t += BX_THREADS) sWo4[t] = (t & 3) < E ? a.Wo[(t >> 2) * E + (t & 3)] : 0.f;
+  // Wo for the G3 product, stored as column PAIRS [c/2][n][c&1]: a 16-B read delivers (Wo[c][n], Wo[c+1][n]) side by
+  // side for two n, the operand shape of v_pk_fma_f32 (row-major [c][4] cost six v_mov per column pair to rearrange)
+  for (int t = tid; t < FH * 4; t += BX_THREADS) {
+    const int c = t >> 2, n = t & 3;
+    sWo4[((c >> 1) * 4 + n) * 2 + (c & 1)] = n < E ? a.Wo[c * E + n] : 0.f;
+  }
   if (tid < FH) sCen[tid] = a.centers[tid];
 
   f32x16 accW[3][2];
@@ -349,13 +368,19 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
     }
     {   // G3 = (dE Wo^T) * s'(Z3)  ->  GA ;  db3
       float g[16];
+      typedef float f32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 w = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));
-          const float pre = dEm[0] * w.x + dEm[1] * w.y + dEm[2] * w.z + dEm[3] * w.w;
-          g[4 * q + j] = bx_sprime(pre, z3r[4 * q + j]);
+        for (int j = 0; j < 4; j += 2) {
+          const float4 w01 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));      // (x0 x1 y0 y1)
+          const float4 w23 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j) + 4);  // (z0 z1 w0 w1)
+          f32x2v pre = f32x2v{w01.x, w01.y} * dEm[0];
+          pre = __builtin_elementwise_fma(f32x2v{w01.z, w01.w}, f32x2v{dEm[1], dEm[1]}, pre);
+          pre = __builtin_elementwise_fma(f32x2v{w23.x, w23.y}, f32x2v{dEm[2], dEm[2]}, pre);
+          pre = __builtin_elementwise_fma(f32x2v{w23.z, w23.w}, f32x2v{dEm[3], dEm[3]}, pre);
+          g[4 * q + j] = pre[0]; g[4 * q + j + 1] = pre[1];
+          bx_sprime2(g[4 * q + j], g[4 * q + j + 1], z3r[4 * q + j], z3r[4 * q + j + 1]);
         }
       bx_img_write<BX_ROWG>(GA, prg, col0, g);
     }
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
       BX_T(6);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] = bx_sprime(g[r], z2r[r]);
+      for (int r = 0; r < 16; r += 2) bx_sprime2(g[r], g[r + 1], z2r[r], z2r[r + 1]);
       bx_img_write<BX_ROWG>(GB, prg, col0, g);       // G2
     }
     BX_T(7);
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void edge_bwd_x3_kernel(EdgeBwdX3Arg
       // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
       prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] = bx_sprime(g[r], z1r[r]);
+      for (int r = 0; r < 16; r += 2) bx_sprime2(g[r], g[r + 1], z1r[r], z1r[r + 1]);
       bx_img_write<BX_ROWG>(GA, prg, col0, g);       // G1
     }
     BX_T(11);
