@@ -47,11 +47,13 @@ const char* ng_last_error(ng_ctx* ctx);
 /* The NG_* path switches (NG_EDGE_MATH, NG_GEMM_MATH, NG_MP_PATH, ... — listed in csrc/ng_common.h) are parsed from
  * the environment once per process; ng_reload_env() parses them again (tests / A-B tools that flip one in-process). */
 int ng_reload_env(void);
-/* Inference with constant weights: ng_weights_frozen(ctx, 1) lets the library keep its packed weight images (MFMA
- * fragment orders, bf16-piece images) across calls instead of re-packing them on every call; any change of a weight
- * tensor afterwards must be announced with ng_weights_changed(ctx) (ng_adam_step does so itself);
- * ng_weights_frozen(ctx, 0) switches the cache off again (the default). */
-int ng_weights_frozen(ng_ctx* ctx, int on);
+/* Inference with constant weights: between ng_weights_frozen(ctx, owner != 0) and ng_weights_frozen(ctx, 0) the library
+ * keeps its packed weight images (MFMA fragment orders, bf16-piece images) across calls instead of re-packing them on
+ * every call.  The images are keyed by the weight tensors' addresses, so `owner` names the model they belong to: a
+ * call with a different non-zero owner discards what the cache holds (another model's freed weights may have had the
+ * same addresses).  A change of a weight tensor of the current owner must be announced with ng_weights_changed(ctx)
+ * (ng_adam_step does so itself).  Off (owner 0) is the default; calls made while it is off never touch the cache. */
+int ng_weights_frozen(ng_ctx* ctx, int owner);
 int ng_weights_changed(ng_ctx* ctx);
 /* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
 int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);

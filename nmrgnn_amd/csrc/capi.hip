@@ -116,10 +116,13 @@ ProfScope::~ProfScope() {
 
 extern "C" int ng_abi_version(void) { return NG_ABI_VERSION; }
 
-extern "C" int ng_weights_frozen(ng_ctx* ctx, int on) {
+extern "C" int ng_weights_frozen(ng_ctx* ctx, int owner) {
   if (!ctx) return NG_ERR_INVALID;
-  ctx->wcache = on != 0;
-  ctx->wver++;
+  if (owner != 0 && owner != ctx->wowner) {   // another model takes the cache over: nothing in it is its own
+    ctx->wver++;
+    ctx->wowner = owner;
+  }
+  ctx->wcache = owner != 0;
   return NG_OK;
 }
 

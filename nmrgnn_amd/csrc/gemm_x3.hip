@@ -371,9 +371,124 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// SHORT operands (one molecule per call: M = 2770 rows give the 128-row tiling 22 workgroups on 256 CUs).  32-row
+// tiles, 256 columns per workgroup as above (wave w: columns [64 w, 64 w + 64), W^T fragments from L2 into registers),
+// but everything is sized for latency instead of reuse: a 12-MFMA k-half covers 0.2 us, an L2 round trip takes three
+// times that and a first touch of X more, so the fragments run THREE k-halves ahead (ring of four) and X moves in
+// 128-wide k-tiles (one barrier and one prefetch per 96 MFMAs of a wave), split into a two-stage LDS ring.
+constexpr int GS_ROW = 272;                      // bytes per row of an X piece plane: 128 bf16 + 16 (b128 rows conflict-free)
+constexpr int GS_PLANE = 32 * GS_ROW;            // 8,704
+constexpr int GS_LDS = 2 * 3 * GS_PLANE;         // 52,224
+
+template <bool GRAD>
+__global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gs[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int nq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  const int ct = blockIdx.y;
+  const int KT = a.K / GX_BK, NT = a.K / 128;
+  constexpr int WCHUNK = gx_wchunk(4);
+
+  // this thread's slice of an X tile: row tid >> 3, 16 floats at column 16 (tid & 7) of the 128-wide k-tile
+  const int xr = tid >> 3, xc = tid & 7;
+  const int64_t xrow = std::min<int64_t>(m0 + xr, a.M - 1);
+  const float* xp = a.X + xrow * a.K + 16 * xc;
+  const float* sp = GRAD && a.Sin ? a.Sin + xrow * a.K + 16 * xc : nullptr;
+  const float rsi = GRAD && a.rs_in ? a.rs_in[xrow] : 1.0f;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / 256) * KT * WCHUNK), 0x00020000);
+
+  float4 xv[4], sv[4];
+  auto x_request = [&](int t) {            // clamped: the last request re-reads the last tile
+    const int64_t koff = (int64_t)128 * std::min(t, NT - 1);
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      xv[i4] = *reinterpret_cast<const float4*>(xp + koff + 4 * i4);
+      if (GRAD && sp) sv[i4] = *reinterpret_cast<const float4*>(sp + koff + 4 * i4);
+    }
+  };
+  auto x_fill = [&](char* sX) {
+    float v[16] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w, xv[1].x, xv[1].y, xv[1].z, xv[1].w,
+                   xv[2].x, xv[2].y, xv[2].z, xv[2].w, xv[3].x, xv[3].y, xv[3].z, xv[3].w};
+    if (GRAD) {
+      if (sp) {
+        const float sg[16] = {sv[0].x, sv[0].y, sv[0].z, sv[0].w, sv[1].x, sv[1].y, sv[1].z, sv[1].w,
+                              sv[2].x, sv[2].y, sv[2].z, sv[2].w, sv[3].x, sv[3].y, sv[3].z, sv[3].w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= act_grad_from_out(a.act_in, sg[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] *= rsi;
+    }
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+    char* d = sX + xr * GS_ROW + 32 * xc;
+    *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
+    *reinterpret_cast<u32x4*>(d + GS_PLANE) = u32x4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<u32x4*>(d + GS_PLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
+    *reinterpret_cast<u32x4*>(d + 2 * GS_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
+    *reinterpret_cast<u32x4*>(d + 2 * GS_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+  };
+  // W^T fragments of k-half q (= 32-wide step q >> 1, half q & 1) for this wave's two 32-column blocks; requests
+  // past the end re-read the last half (never multiplied)
+  auto w_request = [&](u32x4 (&wa)[2][3], int q) {
+    const int qc = std::min(q, 2 * KT - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(
+            wrs, lane * 16, (ct * KT + (qc >> 1)) * WCHUNK + (((2 * nq + j) * 2 + (qc & 1)) * 3 + p) * 1024, 0);
+        wa[j][p] = __builtin_bit_cast(u32x4, raw);
+      }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  u32x4 w[4][2][3];
+  x_request(0);
+  w_request(w[0], 0); w_request(w[1], 1); w_request(w[2], 2);
+  x_fill(smem_gs);
+  x_request(1);
+  NG_LDS_BARRIER();
+#pragma unroll 1
+  for (int t = 0; t < NT; ++t) {
+    const char* cur = smem_gs + (t & 1) * (3 * GS_PLANE);
+    char* nxt = smem_gs + ((t + 1) & 1) * (3 * GS_PLANE);
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+      w_request(w[(hh + 3) & 3], 8 * t + hh + 3);
+      if (hh == 0 && t + 1 < NT) { x_fill(nxt); x_request(t + 2); }
+      u32x4 xb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        xb[p] = *reinterpret_cast<const u32x4*>(cur + p * GS_PLANE + l31 * GS_ROW + (16 * hh + 8 * half) * 2);
+      mma6_2a(w[hh & 3][0], w[hh & 3][1], xb, acc[0], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    NG_LDS_BARRIER();
+  }
+
+  // epilogue: lane holds, for row m = m0 + l31, columns n = 256 ct + 32 (2 nq + j) + 8 q + 4 half + (0..3)
+  const int64_t m = m0 + l31;
+  if (m < a.M) gx_epilogue_block<2>(a, acc, m, 256 * ct + 64 * nq + 4 * half, a.rowscale ? a.rowscale[m] : 1.0f);
+}
+
+// the short kernel: N % 256 (its column tiling), K % 128 (its k-tiles)
+static bool gx_short_ok(int K, int N) { return N % 256 == 0 && K % 128 == 0 && !sw().gemm_4wave; }
+
 bool gemm_x3_fwd_ok(int64_t M, int K, int N) {
   if (sw().gemm_math_fp32) return false;
-  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && M >= 4096 && (int64_t)N * K * 6 < ((int64_t)1 << 31);
+  const bool tall = M >= 4096, short_op = M >= 256 && gx_short_ok(K, N);
+  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && (tall || short_op) && (int64_t)N * K * 6 < ((int64_t)1 << 31);
 }
 
 static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int trans, bool grad, const char* tag) {
@@ -393,7 +508,12 @@ static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int
   a.Wimg = img;
   ProfScope ps(ctx, st, tag);
   const dim3 grid((unsigned)cdiv(a.M, GX_BM), (unsigned)(a.N / BN));
-  if (nbw == 4 && !sw().gemm_4wave) {
+  if (gx_short_ok(a.K, a.N) && cdiv(a.M, GX_BM) * (a.N / BN) * 2 <= ctx->num_cu) {
+    // fewer 128-row tiles than half the CUs
+    const dim3 grid1((unsigned)cdiv(a.M, 32), (unsigned)(a.N / 256));
+    if (grad) hipLaunchKernelGGL((gemm_x3_short_kernel<true>), grid1, dim3(256), GS_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_x3_short_kernel<false>), grid1, dim3(256), GS_LDS, st, a);
+  } else if (nbw == 4 && !sw().gemm_4wave) {
     if (grad) hipLaunchKernelGGL((gemm_x3_fwdr_kernel<true>), grid, dim3(256), G4_LDS, st, a);
     else hipLaunchKernelGGL((gemm_x3_fwdr_kernel<false>), grid, dim3(256), G4_LDS, st, a);
   } else if (nbw == 4) {

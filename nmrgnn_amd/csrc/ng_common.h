@@ -36,6 +36,7 @@ struct ng_ctx {
   // which ng_weights_changed / ng_adam_step / (un)freezing bump.
   struct WImage { void* buf = nullptr; size_t bytes = 0; uint64_t ver = 0; };
   bool wcache = false;
+  int wowner = 0;
   uint64_t wver = 1;
   std::map<std::pair<const void*, int>, WImage> wimg;
 };

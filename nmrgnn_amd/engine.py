@@ -36,6 +36,8 @@ class Tape:
 
 
 class Engine:
+    _ids = 0
+
     def __init__(self, hp, num_elem, peak_std=None, peak_avg=None, device=None, seed=1234):
         if not torch.cuda.is_available():
             raise _lib.NGError("nmrgnn_amd needs an AMD GPU (torch.cuda.is_available() is False); "
@@ -76,14 +78,20 @@ class Engine:
         self.adam_t = 0
         self.tape = None
         self._rng_calls = 0
+        self._frozen = False
+        Engine._ids += 1
+        self._id = Engine._ids          # owner tag of the frozen-weight cache
 
     # ------------------------------------------------------------------ frozen weights (inference)
     def freeze_weights(self, on=True):
         """Inference with constant weights: the library keeps its packed weight images across calls instead of
         re-packing them on every call (several launches per call at molecule size).  Weight changes through
         ``params.load_state_dict`` / ``adam_step`` are noticed; after writing into a parameter view directly call
-        ``weights_changed()``."""
-        self._ck(self.lib.ng_weights_frozen(self.ctx.handle, 1 if on else 0), "ng_weights_frozen")
+        ``weights_changed()``.  The library's cache is keyed by weight addresses and shared by everything on the
+        device, so it is switched on only for the duration of THIS engine's forward calls, under this engine's id."""
+        self._frozen = bool(on)
+        if not on:
+            self._ck(self.lib.ng_weights_frozen(self.ctx.handle, 0), "ng_weights_frozen")
 
     def weights_changed(self):
         self._ck(self.lib.ng_weights_changed(self.ctx.handle), "ng_weights_changed")
@@ -114,6 +122,15 @@ class Engine:
         """peaks[N].  training=True keeps the tape for backward().
         ``noise`` (xi[N,K], standard normal) / ``dropout_mask`` ([N,F/2], values 0 or 1/keep) may be
         supplied explicitly (parity tests); otherwise they are drawn on the GPU from ``seed``."""
+        if not self._frozen:
+            return self._forward(batch, training, noise, dropout_mask, seed)
+        self._ck(self.lib.ng_weights_frozen(self.ctx.handle, self._id), "ng_weights_frozen")
+        try:
+            return self._forward(batch, training, noise, dropout_mask, seed)
+        finally:
+            self.lib.ng_weights_frozen(self.ctx.handle, 0)
+
+    def _forward(self, batch, training, noise, dropout_mask, seed):
         lib, h, st = self.lib, self.ctx.handle, self._st()
         P = self.params
         N, K, F, E, H = batch.N, batch.K, self.F, self.E, self.H

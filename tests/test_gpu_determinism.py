@@ -98,3 +98,19 @@ def test_frozen_weight_cache_tracks_weight_changes(gpu_device):
         assert torch.equal(eng.forward(gb), ref.forward(gb))
         eng.freeze_weights(False)
         assert torch.equal(eng.forward(gb), ref.forward(gb))
+        # the cache is keyed by weight addresses and shared by everything on the device: two frozen models must not see
+        # each other's images, and a model built where a deleted frozen one lived must not inherit them
+        eng.freeze_weights(True)
+        other, other_ref = Engine(hp, 10, device=gpu_device, seed=21), Engine(hp, 10, device=gpu_device, seed=21)
+        other.freeze_weights(True)
+        for _ in range(2):
+            assert torch.equal(eng.forward(gb), ref.forward(gb))
+            assert torch.equal(other.forward(gb), other_ref.forward(gb))
+        del eng, other
+        torch.cuda.empty_cache()
+        for seed in (33, 34):
+            late, late_ref = Engine(hp, 10, device=gpu_device, seed=seed), Engine(hp, 10, device=gpu_device, seed=seed)
+            late.freeze_weights(True)
+            assert torch.equal(late.forward(gb), late_ref.forward(gb))
+            assert torch.equal(late.forward(gb), late_ref.forward(gb))
+            del late, late_ref
