@@ -34,8 +34,11 @@ constexpr int BX_THREADS = 512;
 // Image geometry.  G images are read as rows (ds_read_b128: stride must be a multiple of 16 B; 272 B = 68 dwords
 // puts 16 consecutive rows on disjoint 4-bank slots) and as columns (transposing reads); the Z image only as
 // columns (stride 264 B: the 8-B piece writes of 32 rows then cost the minimum of 2 LDS cycles).  A transposing
-// read fetches 4 consecutive edges x 32 B per 16-lane group, so the ROWS are stored permuted: the 4 edges of a
-// quad sit 8 banks apart (bx_prow_*), without which every such read is a 2-way bank conflict.
+// read fetches 4 consecutive edges x 32 B per 16-lane group, and the LDS serves 32 lanes (two groups, the two 32-B
+// column blocks of a slab) per clock over 64 banks: the ROWS are stored permuted so that the 4 edges of a quad sit 16
+// banks apart (bx_prow_*: 4 rows of 272 B, 8 rows of 264 B) and the two groups interleave in 8-bank runs.  Measured
+// (tools/ubench/trbank2.hip, ns per wave read with 8 waves reading): 9.8 this way, 14.8 with the quad 8 banks apart
+// (the G images until late round 2), 27.3 unpermuted.
 constexpr int BX_ROWG = 272, BX_ROWZ = 264;
 constexpr int BX_PIECE_G = FTM * BX_ROWG, BX_PIECE_Z = FTM * BX_ROWZ;
 constexpr int BX_IMG_G = 3 * BX_PIECE_G;     // 52,224 B
@@ -56,7 +59,7 @@ __device__ __forceinline__ int bx_prow_z(int e) {
 }
 __device__ __forceinline__ int bx_prow_g(int e) {
   const int hi = e >> 4, a = (e >> 2) & 3, b = e & 3;
-  return 16 * hi + 2 * b + (a & 1) + 8 * (a >> 1);
+  return 16 * hi + 4 * b + a;
 }
 
 struct EdgeBwdX3Args {
@@ -141,7 +144,7 @@ __device__ __forceinline__ void bx_dw_gemm(f32x16 (&acc)[2], f32x16& accB, int c
   const int g = lane >> 4, i = lane & 15;
   // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2) of the quad, columns 4(i&3)..+3
   const char* zb = imgZ + (4 * (g >> 1) + 8 * (i >> 2)) * BX_ROWZ + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * kslab;
-  const char* g0 = imgG + (2 * (i >> 2) + 8 * (g >> 1)) * BX_ROWG + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * nsl0;
+  const char* g0 = imgG + (4 * (i >> 2) + 2 * (g >> 1)) * BX_ROWG + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * nsl0;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     BxDwFrags c;       // single-buffered: the kernel has no registers for a second set; the partner wave covers the LDS latency
