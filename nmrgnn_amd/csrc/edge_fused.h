@@ -34,6 +34,10 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
 namespace ng {
 // forward on the bf16 matrix pipe with three-way operand splitting (edge_fwd_x3.hip); NG_EDGE_MATH=bf16x3
 bool edge_x3_enabled();
+// two-piece fp16 split (edge_fwd_h2.hip): the default; same tape layouts as edge_x3_fwd
+int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
+                float* z_save);
 int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
                 float* z_save);

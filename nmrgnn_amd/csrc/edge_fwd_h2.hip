@@ -1,0 +1,366 @@
+// Fused edge forward on the fp16 matrix pipe with fp32-grade arithmetic: every fp32 operand split into TWO fp16
+// pieces, three piece products per multiply (h2_common.cuh).  Default since late round 2; NG_EDGE_MATH=bf16x3 selects
+// the exact three-piece bf16 kernel (edge_fwd_x3.hip, six products), NG_EDGE_MATH=fp32 the f32-input MFMA kernel.
+// Reference: nmrgnn/model.py:251-261 + nmrgnn/layers.py:137-140 + nmrgnn/model.py:132-138.
+//
+// Why.  Matrix time and VALU time ADD on a gfx950 SIMD, and the three-piece kernel sits on that sum:
+// 616 MFMAs + ~3200 VALU instructions per wave and 256-edge tile.  Two fp16 pieces carry 22-24 significand bits —
+// fp32's 24 — so three products (lh + hl + hh) reach fp32-level error with HALF the matrix instructions, and the
+// residual of a split is one v_fma_mix_f32 instead of shift / and / subtract twice.
+//
+// Mapping (same as edge_fwd_x3.hip, same accumulator layout => same blocked tape).  512 threads = 8 waves, one
+// persistent workgroup per CU, 256 edges per tile; wave w owns edges [32w, 32w+32) through ALL layers:
+//   v_mfma_f32_32x32x16_f16  D[feature][edge] += A[feature][k] * B[k][edge]
+//   A = weight pieces from LDS (ds_read_b128 of a lane-linear fragment image), B = activation pieces in VGPRs.
+// The contraction index of the next layer is permuted (x3_feat) so that a lane's 16 outputs of a block are its own
+// k-slots of two k-steps: softplus -> split -> pack turns accumulators into the next B operand in registers.
+//
+// Weight scale.  W pieces are taken from 2^WS * W (WS = 8, exact): the l piece of a typical weight (|W| ~ 0.1) would
+// otherwise be an fp16 subnormal (2^-12 |W| < 2^-14) with only a few significant bits.  Accumulators then hold
+// 2^WS * (pre-activation); the softplus reads them through scaled constants (one extra v_mul per element).
+// Activations stay unscaled: RBF values and softplus outputs are O(1), their small elements carry an ABSOLUTE error
+// <= 2^-25 (subnormal l pieces are honoured by the MFMA), below the fp32 rounding of the O(1) partners they are
+// summed with.  Softplus outputs >= 65504 would overflow the h piece (inf -> NaN output, loud).
+//
+// Weights reach LDS by LDS-DMA in 32-KB chunks (half a layer: 2 output blocks x 4 input blocks x 2 k-steps x
+// 2 pieces x 1 KB fragments), 7 chunks per tile, ring of two slots, one barrier per chunk.
+#include <algorithm>
+#include <string>
+
+#include "edge_fused.h"
+#include "h2_common.cuh"
+
+namespace ng {
+
+constexpr int H2_TM = 256;
+constexpr int H2_CHUNK = 32 * 1024;
+constexpr int H2_NCHUNK = 7;
+constexpr int H2_RING = 2 * H2_CHUNK;
+constexpr int H2_TLD = 36;                 // row stride (floats) of a wave's 32 x 32 transposition tile
+constexpr int H2_TBYTES = 8 * 32 * H2_TLD * 4;
+constexpr int H2_WS = 8;                   // log2 of the weight scale
+constexpr float H2_WSCALE = (float)(1 << H2_WS), H2_WINV = 1.0f / (float)(1 << H2_WS);
+
+// feature (within a 32-block) held in k-slot t (0..7) of k-step s by lane half hf  ==  accumulator register 8s+t
+__host__ __device__ inline int h2_feat(int t, int s, int hf) { return (t & 3) + 16 * s + 8 * (t >> 2) + 4 * hf; }
+
+// Weight image: chunk c (0..5): layer c>>1, output blocks 2*(c&1) + {0,1};  chunk 6: output layer (rows >= E zero).
+//   fragment ((bo_l*4 + bi)*2 + s)*2 + p, 1 KB each, lane-linear 16 B per lane:
+//   lane (row i = l&31, k-slot t) = piece_p( 2^WS W[k = 32 bi + h2_feat(t, s, l>>5)][n = 32 bo + i] )
+__global__ void h2_pack_kernel(const float* __restrict__ W0, const float* __restrict__ W1,
+                               const float* __restrict__ W2, const float* __restrict__ Wo, int E,
+                               unsigned* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (chunk, bo_l, bi, s, lane)
+  if (idx >= H2_NCHUNK * 16 * 64) return;
+  const int lane = idx & 63, s = (idx >> 6) & 1, bi = (idx >> 7) & 3, bo_l = (idx >> 9) & 1, c = idx >> 10;
+  const int i = lane & 31, hf = lane >> 5;
+  float v[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int k = 32 * bi + h2_feat(t, s, hf);
+    if (c < 6) {
+      const float* W = (c >> 1) == 0 ? W0 : ((c >> 1) == 1 ? W1 : W2);
+      v[t] = H2_WSCALE * W[k * FH + 32 * (2 * (c & 1) + bo_l) + i];
+    } else {
+      v[t] = (bo_l == 0 && i < E) ? H2_WSCALE * Wo[k * E + i] : 0.f;
+    }
+  }
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
+  const int frag = ((bo_l * 4 + bi) * 2 + s) * 2;
+  unsigned* dst = img + (size_t)c * (H2_CHUNK / 4) + (size_t)frag * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
+}
+
+struct EdgeH2Args {
+  int64_t n_edges;
+  const float* d_src;
+  const float* d_eff;
+  const float* centers;
+  float neg_inv_gap_log2e;
+  const char* img;        // [7][32 KB]
+  const float* bh[3];
+  const float* bo;
+  int E;
+  float* e_out;
+  float* z_save;          // [3][n_edges][128] or nullptr
+  float* dummy;           // 128 floats
+};
+
+// one chunk = 32 wave-instructions of 1 KB; wave w moves KB w, w+8, w+16, w+24 (scalar resource + scalar offset + one
+// lane-offset VGPR)
+__device__ __forceinline__ void h2_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, int cid, char* slot, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kb = wave + 8 * j;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(slot + kb * 1024), 16,
+                                             lane * 16, cid * H2_CHUNK + kb * 1024, 0, 0);
+  }
+}
+
+// softplus of x = 2^-WS y, read from the scaled accumulator y
+__device__ __forceinline__ float h2_softplus(float y) {
+  const float t = __builtin_amdgcn_exp2f((-1.4426950408889634f * H2_WINV) * fabsf(y));
+  return fmaf(0.6931471805599453f, __builtin_amdgcn_logf(1.0f + t), fmaxf(y * H2_WINV, 0.0f));
+}
+
+// initial accumulator = scaled bias (sb holds 2^WS b)
+__device__ __forceinline__ f32x16 h2_bias(const float* __restrict__ sb, int bo, int hf) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 bv = *reinterpret_cast<const float4*>(sb + 32 * bo + 8 * q + 4 * hf);
+    acc[4 * q + 0] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void h2_load_a(const u32x4* fr, int step, u32x4 (&a0)[2], u32x4 (&a1)[2]) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    a0[p] = fr[((0 * 8 + step) * 2 + p) * 64];
+    a1[p] = fr[((1 * 8 + step) * 2 + p) * 64];
+  }
+}
+
+// half a hidden layer: two output blocks from the chunk in `slot`; 8 steps (bi, s), the weight fragments of step i+1
+// are requested before the 6 MFMAs of step i.  PRE: the softplus of the two blocks the PREVIOUS chunk finished
+// (pre0, pre1) is spread over the steps, four elements per step.
+template <bool PRE>
+__device__ __forceinline__ void h2_hidden_chunk(const char* slot, const u32x4 (&bf)[4][2][2], f32x16& acc0,
+                                                f32x16& acc1, const float* __restrict__ sb, int bo0, int lane,
+                                                f32x16& pre0, f32x16& pre1) {
+  const u32x4* fr = reinterpret_cast<const u32x4*>(slot) + lane;
+  u32x4 a0[2][2], a1[2][2];
+  h2_load_a(fr, 0, a0[0], a1[0]);
+  acc0 = h2_bias(sb, bo0, lane >> 5);
+  acc1 = h2_bias(sb, bo0 + 1, lane >> 5);
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    if (step < 7) h2_load_a(fr, step + 1, a0[(step + 1) & 1], a1[(step + 1) & 1]);
+    mma3_2a(a0[step & 1], a1[step & 1], bf[step >> 1][step & 1], acc0, acc1);
+    if (PRE) {
+      pre0[2 * step] = h2_softplus(pre0[2 * step]); pre0[2 * step + 1] = h2_softplus(pre0[2 * step + 1]);
+      pre1[2 * step] = h2_softplus(pre1[2 * step]); pre1[2 * step + 1] = h2_softplus(pre1[2 * step + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// layer epilogue for one output block: softplus (SP: still to do), optional save, split into the next layer's B
+// fragments.  SAVE: 0 none; 1 row-major tape through a wave-private LDS transposition; 2 blocked tape
+// (edge_fused.h: edge_tape_blocked) — the accumulator layout itself, one contiguous KB per wave store.
+template <int SAVE, bool SP>
+__device__ __forceinline__ void h2_epilogue(const f32x16& acc, u32x4 (&bfo)[2][2], float* __restrict__ tb,
+                                            float* __restrict__ zblk, float* __restrict__ dummy, int rows_left,
+                                            int lane, float* __restrict__ zp, int qstride) {
+  typedef float nt4 __attribute__((ext_vector_type(4)));
+  const int hf = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float z0 = SP ? h2_softplus(acc[4 * q + 0]) : acc[4 * q + 0], z1 = SP ? h2_softplus(acc[4 * q + 1]) : acc[4 * q + 1];
+    const float z2 = SP ? h2_softplus(acc[4 * q + 2]) : acc[4 * q + 2], z3 = SP ? h2_softplus(acc[4 * q + 3]) : acc[4 * q + 3];
+    if (SAVE == 1) *reinterpret_cast<float4*>(tb + l31 * H2_TLD + 8 * q + 4 * hf) = make_float4(z0, z1, z2, z3);
+    if (SAVE == 2) __builtin_nontemporal_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
+    // registers 4q..4q+3  ->  k-step s = q>>1, k-slots t = 4(q&1)..+3  ->  dwords 2(q&1), 2(q&1)+1
+    const int s = q >> 1, j = 2 * (q & 1);
+    unsigned h, l;
+    split2_pair(z0, z1, h, l);
+    bfo[s][0][j] = h; bfo[s][1][j] = l;
+    split2_pair(z2, z3, h, l);
+    bfo[s][0][j + 1] = h; bfo[s][1][j + 1] = l;
+  }
+  if (SAVE == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (lane >> 3) + 8 * i, c = 4 * (lane & 7);
+      const float4 v = *reinterpret_cast<const float4*>(tb + r * H2_TLD + c);
+      float* d = r < rows_left ? zblk + (int64_t)r * FH + c : dummy + c;
+      __builtin_nontemporal_store(nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4*>(d));
+    }
+  }
+}
+
+#define H2_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int SAVE>
+__global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_h2[];
+  char* ring = smem_h2;
+  float* sT = reinterpret_cast<float*>(smem_h2 + H2_RING);     // [8 waves][32][36] store transposition (SAVE == 1)
+  float* sCen = reinterpret_cast<float*>(smem_h2 + H2_RING + (SAVE == 1 ? H2_TBYTES : 0));   // [128]
+  float* sBias = sCen + FH;                                     // [3][128], scaled
+  float* sBo = sBias + 3 * FH;                                  // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < FH) {
+    sCen[tid] = a.centers[tid];
+    sBias[tid] = H2_WSCALE * a.bh[0][tid];
+    sBias[FH + tid] = H2_WSCALE * a.bh[1][tid];
+    sBias[2 * FH + tid] = H2_WSCALE * a.bh[2][tid];
+  }
+  if (tid < 32) sBo[tid] = tid < a.E ? a.bo[tid] : 0.f;
+
+  const int64_t ntiles = (a.n_edges + H2_TM - 1) / H2_TM;
+  float ds_n, de_n;
+  {
+    const int64_t g0 = std::min<int64_t>((int64_t)blockIdx.x * H2_TM + 32 * wave + l31, a.n_edges - 1);
+    ds_n = a.d_src[g0]; de_n = a.d_eff[g0];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, H2_NCHUNK * H2_CHUNK, 0x00020000);
+  // ring state: chunk id (0..6) and slot of the NEXT chunk to request / to consume
+  int req_c = 0, req_s = 0, use_s = 0;
+  h2_dma_chunk(rsrc, req_c, ring + req_s * H2_CHUNK, wave, lane);
+  req_c = 1; req_s = 1;
+  H2_WAIT_DMA();   // chunk 0 landed (this wave's share)
+
+#define H2_STEP_BEGIN()                                              \
+  NG_LDS_BARRIER();                                                  \
+  h2_dma_chunk(rsrc, req_c, ring + req_s * H2_CHUNK, wave, lane);   \
+  req_c = req_c == H2_NCHUNK - 1 ? 0 : req_c + 1;                    \
+  req_s ^= 1;
+#define H2_STEP_END()                                                \
+  H2_WAIT_DMA();                                                     \
+  use_s ^= 1;
+
+  u32x4 bf[4][2][2];
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t gr = tile * H2_TM + 32 * wave + l31;
+    const bool valid = gr < a.n_edges;
+    const float ds = valid ? ds_n : 0.f;
+    const float mask = ds > 0.f ? 1.f : 0.f;
+    // ---- RBF straight into B fragments; masked edges: d = 1e19 -> exp2(-inf) = exact 0
+    {
+      const float dm = ds > 0.f ? de_n : 1.0e19f;
+      const float c2 = a.neg_inv_gap_log2e;
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int tq = 0; tq < 2; ++tq) {
+            const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * bi + 16 * s + 8 * tq + 4 * hf);
+            float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
+            u0 = __builtin_amdgcn_exp2f(u0 * u0 * c2); u1 = __builtin_amdgcn_exp2f(u1 * u1 * c2);
+            u2 = __builtin_amdgcn_exp2f(u2 * u2 * c2); u3 = __builtin_amdgcn_exp2f(u3 * u3 * c2);
+            unsigned h, l;
+            split2_pair(u0, u1, h, l);
+            bf[bi][s][0][2 * tq] = h; bf[bi][s][1][2 * tq] = l;
+            split2_pair(u2, u3, h, l);
+            bf[bi][s][0][2 * tq + 1] = h; bf[bi][s][1][2 * tq + 1] = l;
+          }
+    }
+    {   // distances of this workgroup's next tile
+      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, a.n_edges - 1);
+      ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
+    }
+    // ---- three hidden layers, two chunks each
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+      f32x16 acc[4];
+      H2_STEP_BEGIN();
+      h2_hidden_chunk<false>(ring + use_s * H2_CHUNK, bf, acc[0], acc[1], sBias + layer * FH, 0, lane, acc[2], acc[3]);
+      H2_STEP_END();
+      H2_STEP_BEGIN();
+      h2_hidden_chunk<true>(ring + use_s * H2_CHUNK, bf, acc[2], acc[3], sBias + layer * FH, 2, lane, acc[0], acc[1]);
+      H2_STEP_END();
+      // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
+      const int64_t wrow0 = tile * H2_TM + 32 * wave;
+      const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
+      float* zl = SAVE ? a.z_save + (int64_t)layer * a.n_edges * FH : nullptr;
+      float* zw = SAVE ? zl + wrow0 * FH : nullptr;
+      const bool full = rows_left >= 32;
+      float* zp = nullptr;
+      int bstride = 0, qstride = 0;
+      if (SAVE == 2) {
+        zp = full ? zl + (tile * 8 + wave) * 4096 + lane * 4
+                  : (l31 < rows_left ? zl + (wrow0 + l31) * FH + 4 * hf : a.dummy + 4 * hf);
+        bstride = full ? 1024 : 32;
+        qstride = full ? 256 : 8;
+      }
+      float* tb = sT + wave * (32 * H2_TLD);
+      h2_epilogue<SAVE, false>(acc[0], bf[0], tb, zw, a.dummy, rows_left, lane, zp, qstride);
+      h2_epilogue<SAVE, false>(acc[1], bf[1], tb, zw + 32, a.dummy, rows_left, lane, zp + bstride, qstride);
+      h2_epilogue<SAVE, true>(acc[2], bf[2], tb, zw + 64, a.dummy, rows_left, lane, zp + 2 * bstride, qstride);
+      h2_epilogue<SAVE, true>(acc[3], bf[3], tb, zw + 96, a.dummy, rows_left, lane, zp + 3 * bstride, qstride);
+    }
+    // ---- output layer: rows 0..E-1 of one 32-row block
+    {
+      f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+      H2_STEP_BEGIN();
+      const u32x4* fr = reinterpret_cast<const u32x4*>(ring + use_s * H2_CHUNK) + lane;
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        u32x4 a0[2], a1[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          a0[p] = fr[((2 * bi + 0) * 2 + p) * 64];
+          a1[p] = fr[((2 * bi + 1) * 2 + p) * 64];
+        }
+        {
+          const u32x4 (&b)[2] = bf[bi][0];
+          acc0 = mfma_f16(a0[1], b[0], acc0); acc0 = mfma_f16(a0[0], b[1], acc0);
+          acc2 = mfma_f16(a0[0], b[0], acc2);
+        }
+        {
+          const u32x4 (&b)[2] = bf[bi][1];
+          acc1 = mfma_f16(a1[1], b[0], acc1); acc1 = mfma_f16(a1[0], b[1], acc1);
+          acc3 = mfma_f16(a1[0], b[0], acc3);
+        }
+      }
+      const f32x16 acc = (acc0 + acc1) + (acc2 + acc3);   // small products | leading products
+      H2_STEP_END();
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ne = r + 4 * hf;
+          if (ne < a.E) a.e_out[gr * a.E + ne] = mask * fmaf(acc[r], H2_WINV, sBo[ne]);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
+                float* z_save) {
+  const size_t img_bytes = (size_t)H2_NCHUNK * H2_CHUNK;
+  bool have = false;
+  char* img = (char*)cached_image(ctx, W[0], 6, img_bytes + FH * 4, &have);
+  if (!img) img = (char*)workspace(ctx, img_bytes + FH * 4);
+  if (!img) return NG_ERR_NOMEM;
+  if (!have) {
+    hipLaunchKernelGGL(h2_pack_kernel, dim3(cdiv(H2_NCHUNK * 16 * 64, 256)), dim3(256), 0, st, W[0], W[1], W[2], W[3], E,
+                       (unsigned*)img);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  EdgeH2Args a;
+  a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
+  a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
+  a.img = img;
+  a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
+  a.bo = b[3]; a.E = E; a.e_out = e_out; a.z_save = z_save;
+  a.dummy = (float*)(img + img_bytes);
+  const int64_t ntiles = cdiv(n_edges, H2_TM);
+  const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
+  const size_t misc = (size_t)(FH + 3 * FH + 32) * 4;
+  ProfScope ps(ctx, st, "edge_fwd_h2");
+  if (z_save && edge_tape_blocked(E, n_edges))
+    hipLaunchKernelGGL(edge_fwd_h2_kernel<2>, dim3(grid), dim3(512), H2_RING + misc, st, a);
+  else if (z_save)
+    hipLaunchKernelGGL(edge_fwd_h2_kernel<1>, dim3(grid), dim3(512), H2_RING + H2_TBYTES + misc, st, a);
+  else
+    hipLaunchKernelGGL(edge_fwd_h2_kernel<0>, dim3(grid), dim3(512), H2_RING + misc, st, a);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+}  // namespace ng

@@ -1,0 +1,55 @@
+// Shared pieces of the two-piece fp16 split-operand kernels (edge_fwd_h2.hip, edge_bwd_h2.hip, gemm_h2 paths).
+// An fp32 value x is written as x = h + l + r with h = rne_f16(x), l = rne_f16(x - h) (the subtraction is exact in
+// fp32), |r| <= 2^-22 |x| (typically 2^-24: two 11-bit significands with a signed residual cover 22-23 bits), and a
+// product a*b is taken as  al*bh + ah*bl + ah*bh  (smallest first), every piece product exact in the fp32 accumulator
+// of v_mfma_f32_32x32x16_f16 (11 x 11 significand bits).  Dropped: al*bl <= 2^-22 |a||b| and the residuals — the size
+// of an fp32 rounding of the product.  Three matrix instructions per fp32 multiply instead of the six of the exact
+// three-piece bf16 split (x3_common.cuh), and a two-instruction residual (v_fma_mix_f32 + v_cvt_pk_f16_f32).
+// Range: fp16 pieces need |x| < 65504 (activations: unscaled; gradients: scaled by a power of two per launch, see
+// edge_bwd_h2.hip); below 2^-14 the l piece is a subnormal the matrix pipe honours (tools/ubench/mfma_f16.hip), so the
+// absolute representation error never exceeds max(2^-25, 2^-22 |x|).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "x3_common.cuh"
+
+namespace ng {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_cvt __attribute__((ext_vector_type(2)));
+
+// two floats -> packed fp16, round to nearest even (compiler-native conversion: see the hazard note in x3_common.cuh)
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{lo, hi}, f16x2_cvt));
+}
+
+// (x0, x1) -> packed fp16 pieces; piece of x0 in the low half, of x1 in the high half
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+  h = cvt_pk_f16(x0, x1);
+  const f16x2_cvt hv = __builtin_bit_cast(f16x2_cvt, h);
+  const float r0 = __builtin_fmaf((float)hv[0], -1.0f, x0);     // v_fma_mix_f32: conversion inside the fma, exact result
+  const float r1 = __builtin_fmaf((float)hv[1], -1.0f, x1);
+  l = cvt_pk_f16(r0, r1);
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// the three piece products of (A pair) x (B pair), smallest terms first; index 0 = h, 1 = l
+__device__ __forceinline__ f32x16 mma3(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 acc) {
+  acc = mfma_f16(a[1], b[0], acc);
+  acc = mfma_f16(a[0], b[1], acc);
+  acc = mfma_f16(a[0], b[0], acc);
+  return acc;
+}
+
+// the same for TWO accumulators that share the B pair; the chains alternate so that consecutive MFMAs are independent
+__device__ __forceinline__ void mma3_2a(const u32x4 (&a0)[2], const u32x4 (&a1)[2], const u32x4 (&b)[2], f32x16& acc0,
+                                        f32x16& acc1) {
+  acc0 = mfma_f16(a0[1], b[0], acc0); acc1 = mfma_f16(a1[1], b[0], acc1);
+  acc0 = mfma_f16(a0[0], b[1], acc0); acc1 = mfma_f16(a1[0], b[1], acc1);
+  acc0 = mfma_f16(a0[0], b[0], acc0); acc1 = mfma_f16(a1[0], b[0], acc1);
+}
+
+}  // namespace ng

@@ -45,7 +45,8 @@ namespace ng {
 
 // Process-wide path switches, parsed from the environment ONCE (first use) instead of a getenv + string compare
 // on every launch; ng_reload_env() re-reads them (tests and A/B tools flip variables inside one process).
-//   NG_EDGE_MATH=fp32      edge MLP forward+backward on f32-input MFMA (default: bf16 x3 split operands)
+//   NG_EDGE_MATH=fp32      edge MLP forward+backward on f32-input MFMA (default: two-piece fp16 split operands)
+//   NG_EDGE_MATH=bf16x3    edge MLP on the exact three-piece bf16 split (six piece products per multiply)
 //   NG_EDGE_BWD_MATH=fp32  only the edge backward on f32-input MFMA
 //   NG_GEMM_MATH=fp32      generic GEMMs on f32-input MFMA (default: split operands where the shape allows)
 //   NG_EDGE_PATH=layered   one launch per edge-MLP layer (any H / Le)
@@ -56,6 +57,7 @@ namespace ng {
 //   NG_KNN=serial          one lane per query atom in the kNN graph kernel
 struct Switches {
   bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
+  bool edge_math_bf16x3 = false;
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false;
   bool gemm_4wave = false;      // NG_GEMM_TILE=4wave: the un-pipelined 4-wave split-operand GEMM (A/B measurements)

@@ -1,7 +1,8 @@
-"""Edge forward on the bf16 matrix pipe (edge_fwd_x3.hip: every fp32 operand split exactly into three bf16
-pieces, six piece products per multiply, fp32 accumulate) against a float64 numpy statement of
+"""Edge forward / backward on the 16-bit matrix pipe with split fp32 operands against a float64 numpy statement of
 nmrgnn/model.py:251-261 + layers.py:137-140 + model.py:132-138 — and against the f32-input MFMA kernel
-(NG_EDGE_MATH=fp32): the split path must be as close to float64 as the fp32 path is."""
+(NG_EDGE_MATH=fp32): a split path must be as close to float64 as the fp32 path is.
+  f16x2  (default, edge_fwd_h2.hip): two fp16 pieces, three piece products per multiply
+  bf16x3 (edge_fwd_x3.hip / edge_bwd_x3.hip): exact three-piece bf16 split, six piece products"""
 import ctypes as C
 
 import numpy as np
@@ -84,24 +85,25 @@ def test_edge_forward_split_vs_float64(gpu_device, monkeypatch, n, E, save):
     e_ref, z_ref = ref_edge(f32(d_src), f32(d_eff), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws],
                             [f32(b) for b in bs])
     out = {}
-    for math in ("bf16x3", "fp32"):
+    for math in ("f16x2", "bf16x3", "fp32"):
         monkeypatch.setenv("NG_EDGE_MATH", math)
         out[math] = run_gpu(gpu_device, d_src, d_eff, centers, gap, Ws, bs, E, save)
     # the output layer is a 128-term dot product: its rounding error scales with sum |z||W|, not with the result
     mag = (np.abs(z_ref[2]) @ np.abs(f32(Ws[3])) + np.abs(f32(bs[3]))).max()
     err = {k: np.abs(v[0] - e_ref) for k, v in out.items()}
-    assert err["bf16x3"].max() < 1e-6 * mag, (err["bf16x3"].max(), err["fp32"].max(), mag)
-    assert np.sqrt((err["bf16x3"] ** 2).mean()) < 2e-7 * mag
-    if save:
-        # hidden activations: the split products carry no more error than the f32-input MFMA chain (measured: less)
-        for l in range(3):
-            dz = {k: v[1][l] - z_ref[l] for k, v in out.items()}
-            assert np.abs(dz["bf16x3"]).max() < 1e-5, l
-            if n >= 255:
-                rms = {k: np.sqrt((v ** 2).mean()) for k, v in dz.items()}
-                assert rms["bf16x3"] < 1.2 * rms["fp32"] + 1e-8, (l, rms)
-    # masked edges give exact zeros, rows past the end are never written
-    assert np.all(out["bf16x3"][0][d_src == 0] == 0.0)
+    for split in ("f16x2", "bf16x3"):
+        assert err[split].max() < 1e-6 * mag, (split, err[split].max(), err["fp32"].max(), mag)
+        assert np.sqrt((err[split] ** 2).mean()) < 2e-7 * mag, split
+        if save:
+            # hidden activations: the split products carry no more error than the f32-input MFMA chain
+            for l in range(3):
+                dz = {k: v[1][l] - z_ref[l] for k, v in out.items()}
+                assert np.abs(dz[split]).max() < 1e-5, (split, l)
+                if n >= 255:
+                    rms = {k: np.sqrt((v ** 2).mean()) for k, v in dz.items()}
+                    assert rms[split] < 1.2 * rms["fp32"] + 1e-8, (split, l, rms)
+        # masked edges give exact zeros, rows past the end are never written
+        assert np.all(out[split][0][d_src == 0] == 0.0)
 
 
 def ref_edge_bwd(d_src, d_eff, centers, gap, Ws, bs, de):
