@@ -1,0 +1,628 @@
+// Fused persistent backward of the edge path on the fp16 matrix pipe with two-piece split fp32 operands
+// (h2_common.cuh: three piece products per multiply).  Default since late round 2; same math, phases, tile loop,
+// workgroup partials and reduction kernel as edge_bwd_x3.hip (exact three-piece bf16 split, NG_EDGE_MATH=bf16x3) and
+// edge_fused_bwd.hip (f32-input MFMA, NG_EDGE_MATH=fp32).  Backward of nmrgnn/model.py:251-261, SURVEY App. B.
+//
+//   A:  dE = S*m*de ;  G3 = (dE Wo^T) * s'(Z3)   [VALU]      dWo += Z3^T dE, dbo += sum dE   [VALU, fp32]
+//   B:  dW3 += Z2^T G3 ; db3 += colsum G3 ; dZ2 = G3 W3^T ; G2 = dZ2 * s'(Z2)
+//   C:  dW2 += Z1^T G2 ; db2 += colsum G2 ; dZ1 = G2 W2^T ; G1 = dZ1 * s'(Z1)
+//   D:  R = m*rbf(d) recomputed ; dW1 += R^T G1 ; db1 += colsum G1
+//
+// Ranges.  fp16 pieces hold |x| < 65504 and resolve absolute steps of 2^-25 (subnormal l pieces are honoured by the
+// MFMA).  Activations (Z, R: O(1)) are split unscaled.  Gradients can be arbitrarily small (loss scaling, 1/G), so the
+// whole backward — linear in dE — runs on S*dE with S a power of two chosen per call by hx_scale_kernel from
+//   max|de| * max(nWo, nWo nW3, nWo nW3 nW2),  n. = largest absolute row sum of the matrix a gradient passes through,
+// the worst case any G entry can reach: S puts that bound at 2^15, so no piece can overflow, and typical entries
+// (orders of magnitude below the bound, still >> 2^-14) keep full two-piece precision.  The partials are multiplied
+// by 1/S when they are written.  W^T pieces are taken from 2^8 W (the l piece of a typical weight would otherwise be
+// subnormal); the dZ epilogue multiplies by 2^-8.
+//
+// Mapping.  512 threads = 8 waves (2 per SIMD), one persistent workgroup per CU, 64-edge tiles.
+// Every GEMM operand that comes from activations lives in LDS as an fp16-piece IMAGE [2 pieces][64 edges][136]:
+// three images (Z-type, G ping, G pong) = 101 KB.  Elementwise work is done ONCE per element in the accumulator
+// layout of the dZ GEMM (lane = edge row, 16 columns of the wave's 32-column slab): the lane that loads Z_l from
+// HBM in that layout splits it into the image AND keeps the fp32 values for s'(Z_l) in its own epilogue.
+//   dZ GEMM (wave: k-slab zk = w&3, edge half zrt = w>>2): A = W^T pieces streamed from a fragment-ordered image
+//     in L2 (buffer loads), B = G pieces read as rows of the image (ds_read_b128), 24 MFMAs.
+//   dW GEMM (wave: k-slab w>>1, n-slabs 2(w&1)+{0,1}; contraction over the tile's 64 edges): both operands are
+//     COLUMNS of an image; ds_read_b64_tr_b16 delivers a lane 4 consecutive edges of its column (two reads = one
+//     8-edge MFMA operand), 24 MFMAs per layer.  The three 128x128 accumulators stay in registers (96 VGPRs).
+//   Bias gradients ride on the dW GEMM: G^T x ones in one extra accumulator (hx_dw_gemm).
+#include <algorithm>
+#include <string>
+#include <cstdio>
+
+#include "edge_fused.h"
+#include "h2_common.cuh"
+
+namespace ng {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define HX_LDS(T) __attribute__((address_space(3))) T
+
+constexpr int HX_THREADS = 512;
+// Image geometry.  G images are read as rows (ds_read_b128: stride must be a multiple of 16 B; 272 B = 68 dwords
+// puts 16 consecutive rows on disjoint 4-bank slots) and as columns (transposing reads); the Z image only as
+// columns (stride 264 B: the 8-B piece writes of 32 rows then cost the minimum of 2 LDS cycles).  A transposing
+// read fetches 4 consecutive edges x 32 B per 16-lane group, and the LDS serves 32 lanes (two groups, the two 32-B
+// column blocks of a slab) per clock over 64 banks: the ROWS are stored permuted so that the 4 edges of a quad sit 16
+// banks apart (hx_prow_*: 4 rows of 272 B, 8 rows of 264 B) and the two groups interleave in 8-bank runs.  Measured
+// (tools/ubench/trbank2.hip, ns per wave read with 8 waves reading): 9.8 this way, 14.8 with the quad 8 banks apart
+// (the G images until late round 2), 27.3 unpermuted.
+constexpr int HX_ROWG = 272, HX_ROWZ = 264;
+constexpr int HX_PIECE_G = FTM * HX_ROWG, HX_PIECE_Z = FTM * HX_ROWZ;
+constexpr int HX_IMG_G = 2 * HX_PIECE_G;     // 34,816 B
+constexpr int HX_IMG_Z = 2 * HX_PIECE_Z;     // 33,792 B
+constexpr int HX_STG = 132;                  // fp32 staging row stride (floats)
+constexpr int HX_MISC_FLOATS = FH * 4 + FTM * 4 + FH;   // sWo4 | sdE | sCen
+constexpr int HX_IMGS = HX_IMG_Z + 2 * HX_IMG_G;
+#ifdef HX_STAMP
+constexpr int HX_LDS_BYTES = HX_IMGS + HX_MISC_FLOATS * 4 + 1024;
+#else
+constexpr int HX_LDS_BYTES = HX_IMGS + HX_MISC_FLOATS * 4;
+#endif             // 106,752 of 163,840
+constexpr int HX_WS = 8;                     // log2 of the W^T scale
+constexpr float HX_WSCALE = (float)(1 << HX_WS), HX_WINV = 1.0f / (float)(1 << HX_WS);
+
+// physical row of edge e (0..63) in the Z image / in a G image
+__device__ __forceinline__ int hx_prow_z(int e) {
+  const int hi = e >> 4, a = (e >> 2) & 3, b = e & 3;
+  return 2 * (a + 4 * b) + (hi & 1) + 32 * (hi >> 1);
+}
+__device__ __forceinline__ int hx_prow_g(int e) {
+  const int hi = e >> 4, a = (e >> 2) & 3, b = e & 3;
+  return 16 * hi + 4 * b + a;
+}
+
+struct EdgeBwdH2Args {
+  int64_t n_edges;
+  const float* d_src;
+  const float* d_eff;
+  const float* centers;
+  float neg_inv_gap_log2e;
+  const char* wt_img;   // [2 layers (W2, W3)][4 k-slabs][8 k-steps][2 pieces][1 KB], pieces of 2^8 W
+  const float* scale;   // {S, 1/S} written by hx_scale_kernel
+  const float* Wo;      // [128][E]
+  const float* z_save;  // [3][z_layer_stride / 128 edges][128], first edge of THIS launch's segment
+  int64_t z_layer_stride;  // floats between the layers of the tape (= total edges * 128; a launch covers one segment)
+  const float* de;      // [n_edges][E]
+  float* partial;       // [grid][part_stride], layout of edge_fused_bwd.hip
+  int part_stride;
+  int E;
+  int tape_blocked;     // z_save layout: 1 = blocked inside full 32-edge groups (edge_fused.h), 0 = row-major
+  unsigned long long* stamps;
+};
+
+// W^T fragments of the dZ GEMMs: lane (row k = 32 zk + (l&31), k-slot t) = piece_p( 2^8 W[k][n = 16 ks + 8 (l>>5) + t] )
+__global__ void h2_pack_wt_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
+                                  unsigned* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (L, zk, ks, lane)
+  if (idx >= 2 * 4 * 8 * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) & 7, zk = (idx >> 9) & 3, L = idx >> 11;
+  const float* W = L == 0 ? W2 : W3;
+  const int k = 32 * zk + (lane & 31), n0 = 16 * ks + 8 * (lane >> 5);
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    split2_pair(HX_WSCALE * W[k * FH + n0 + 2 * j], HX_WSCALE * W[k * FH + n0 + 2 * j + 1], h[j], l[j]);
+  unsigned* dst = img + (size_t)(((L * 4 + zk) * 8 + ks) * 2) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
+}
+
+// 16 values of one row (columns col0 + 8q + j, v[4q + j]) -> the two piece planes of an image
+template <int ROWB>
+__device__ __forceinline__ void hx_img_write(char* __restrict__ img, int row, int col0, const float (&v)[16]) {
+  constexpr int HX_ROWB = ROWB, HX_PIECE = FTM * ROWB;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned h0, l0, h1, l1;
+    split2_pair(v[4 * q + 0], v[4 * q + 1], h0, l0);
+    split2_pair(v[4 * q + 2], v[4 * q + 3], h1, l1);
+    char* p = img + row * HX_ROWB + (col0 + 8 * q) * 2;
+    *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(p + HX_PIECE) = u32x2{l0, l1};
+  }
+}
+
+// one MFMA operand (8 consecutive edges of this lane's column) = two transposing reads of 4 edges each; `step` is
+// the byte distance between the two quads' first rows
+__device__ __forceinline__ u32x4 hx_tr_frag(const char* p, int step) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HX_LDS(s16x4)*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HX_LDS(s16x4)*)(p + step));
+  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+  return u32x4{a[0], a[1], b[0], b[1]};
+}
+
+struct HxDwFrags { u32x4 b[2], a0[2], a1[2]; };
+
+// operands of k-step ks (edges 16 ks .. 16 ks + 15): physical rows per hx_prow_z / hx_prow_g
+__device__ __forceinline__ void hx_dw_load(HxDwFrags& f, const char* zb, const char* g0, int ks) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    f.b[p] = hx_tr_frag(zb + p * HX_PIECE_Z + ((ks & 1) + 32 * (ks >> 1)) * HX_ROWZ, 2 * HX_ROWZ);
+    f.a0[p] = hx_tr_frag(g0 + p * HX_PIECE_G + 16 * ks * HX_ROWG, HX_ROWG);
+    f.a1[p] = hx_tr_frag(g0 + 64 + p * HX_PIECE_G + 16 * ks * HX_ROWG, HX_ROWG);
+  }
+}
+
+// acc[j][n][k] += sum_edges G[e][n] Zin[e][k]   (D rows n = G columns of slab nsl0 + j, D cols k = Zin columns of kslab)
+// Bias gradient on the matrix pipe: db[n] = sum_e G[e][n] = G^T x ones.  In the step ks == kslab (the four waves
+// that share an n-slab pair split the tile's edges) the G fragments are multiplied once more by a B operand that
+// is 1.0 in five columns (5c .. 5c+4, c = 2 layer + j) and 0 elsewhere: ONE accumulator collects all six
+// (layer, n-slab) column sums in disjoint column groups — 4 MFMAs per layer instead of 80 DPP adds + an LDS update.
+__device__ __forceinline__ void hx_dw_gemm(f32x16 (&acc)[2], f32x16& accB, int cbase, const char* __restrict__ imgZ,
+                                           const char* __restrict__ imgG, int kslab, int nsl0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  // the 16-lane group reads a [4 edges][16 columns] block: lane i supplies edge (i>>2) of the quad, columns 4(i&3)..+3
+  const char* zb = imgZ + (4 * (g >> 1) + 8 * (i >> 2)) * HX_ROWZ + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * kslab;
+  const char* g0 = imgG + (4 * (i >> 2) + 2 * (g >> 1)) * HX_ROWG + (16 * (g & 1) + 4 * (i & 3)) * 2 + 64 * nsl0;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    HxDwFrags c;       // single-buffered: the kernel has no registers for a second set; the partner wave covers the LDS latency
+    hx_dw_load(c, zb, g0, ks);
+    mma3_2a(c.a0, c.a1, c.b, acc[0], acc[1]);
+    if (ks == kslab) {
+      // the ones operand is rebuilt here from the lane id (the asm keeps the compiler from hoisting it out of the tile
+      // loop, where it became a spilled invariant whose reload carried a vmcnt(0) into the middle of the prefetches)
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const unsigned grp = (unsigned)((lv & 31) / 5);
+      const unsigned o0 = grp == (unsigned)cbase ? 0x3C003C00u : 0u, o1 = grp == (unsigned)(cbase + 1) ? 0x3C003C00u : 0u;
+      const u32x4 ones0 = {o0, o0, o0, o0}, ones1 = {o1, o1, o1, o1};
+#pragma unroll
+      for (int p = 1; p >= 0; --p) { accB = mfma_f16(c.a0[p], ones0, accB); accB = mfma_f16(c.a1[p], ones1, accB); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void hx_wload(u32x4 (&w)[2], __amdgpu_buffer_rsrc_t wrs, int wvo, int wso, int ks) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + (ks * 2 + p) * 1024, 0);
+    w[p] = __builtin_bit_cast(u32x4, raw);
+  }
+}
+
+// dZ[e][k] = sum_n G[e][n] W[k][n]  for k-slab zk, edge rows 32 zrt..; D rows = k, D cols = edges.
+// Returned lane layout: edge 32 zrt + (l&31), columns 32 zk + 8q + 4 (l>>5) + j  in register 4q + j.
+// w0 holds the W^T fragments of step 0 (requested by the caller before the preceding GEMM); steps ks+1 .. ks+3 are
+// in flight while step ks multiplies.
+__device__ __forceinline__ void hx_dz_gemm(float (&out)[16], const char* __restrict__ imgG, int prow_g,
+                                           __amdgpu_buffer_rsrc_t wrs, const u32x4 (&w0)[2], int L, int zk, int lane) {
+  const int half = lane >> 5;
+  const char* gb = imgG + prow_g * HX_ROWG + 16 * half;
+  const int wvo = lane * 16;
+  int wso = ((L * 4 + zk) * 8) * 2 * 1024;
+  // opaque to the optimizer: otherwise the 2 x 24 fragment offsets (wso + const) are hoisted out of the tile loop as
+  // scalar invariants, spilled into VGPR lanes and fetched back with v_readlane + s_nop 4 in front of every load
+  asm volatile("" : "+s"(wso));
+  f32x16 acc0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+  u32x4 wa[4][2], b[2][2];     // W^T fragments three steps ahead (L2 latency is ~6 steps of 3 MFMAs), G rows one step ahead
+#pragma unroll
+  for (int p = 0; p < 2; ++p) { wa[0][p] = w0[p]; b[0][p] = *reinterpret_cast<const u32x4*>(gb + p * HX_PIECE_G); }
+  hx_wload(wa[1], wrs, wvo, wso, 1);
+  hx_wload(wa[2], wrs, wvo, wso, 2);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks < 5) hx_wload(wa[(ks + 3) & 3], wrs, wvo, wso, ks + 3);
+    if (ks < 7) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) b[(ks + 1) & 1][p] = *reinterpret_cast<const u32x4*>(gb + 32 * (ks + 1) + p * HX_PIECE_G);
+    }
+    acc0 = mma3(wa[ks & 3], b[ks & 1], acc0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[r] = acc0[r] * HX_WINV;     // the W^T pieces carry 2^8
+}
+
+// this lane's 16 values of a saved activation row (clamped row: rows past the end multiply a zero gradient).
+// Buffer loads: scalar resource + one 32-bit lane offset — per-lane 64-bit pointers for five arrays got spilled and
+// every reload put a vmcnt(0) into the middle of the prefetch.
+// Tape layout (edge_fused.h: edge_tape_blocked): inside a FULL 32-edge group the block this wave needs is stored in
+// exactly this register layout — four contiguous 1-KB wave loads; the last partial group is row-major (16-B pieces
+// of 32 rows, 32 B apart).  voff: this lane's byte offset, qbytes: distance between its four loads (wave-uniform).
+__device__ __forceinline__ void hx_load_z(float (&z)[16], __amdgpu_buffer_rsrc_t rs, int voff, int qbytes) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, q * qbytes, 0);
+    const f32x4v v = __builtin_bit_cast(f32x4v, raw);
+    z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+  }
+}
+
+// x * s'(.) with s' = 1 - exp(-z) recovered from the softplus OUTPUT z:  x - x * 2^(-z log2 e)   (mul, exp, fma)
+__device__ __forceinline__ float hx_sprime(float x, float z) {
+  return fmaf(-x, __builtin_amdgcn_exp2f(-1.4426950408889634f * z), x);
+}
+
+// the same for two values at once: the scale and the final fma as packed fp32 instructions
+typedef float hx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hx_sprime2(float& x0, float& x1, float z0, float z1) {
+  const hx_f32x2 t = hx_f32x2{z0, z1} * hx_f32x2{-1.4426950408889634f, -1.4426950408889634f};
+  const hx_f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const hx_f32x2 x = {x0, x1};
+  const hx_f32x2 r = __builtin_elementwise_fma(-x, e, x);
+  x0 = r[0]; x1 = r[1];
+}
+
+#ifdef HX_STAMP
+#define HX_T(k)                                                                              \
+  do {                                                                                       \
+    if (lane == 0 && (wave & 3) == 0 && titer >= 2 && titer < 6)                             \
+      sStamp[((wave >> 2) * 4 + (titer - 2)) * 16 + (k)] = __builtin_readcyclecounter();     \
+  } while (0)
+#else
+#define HX_T(k)
+#endif
+
+__global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_hx[];
+  char* IZ = smem_hx;                           // Z2 -> Z1 -> R
+  char* GA = smem_hx + HX_IMG_Z;                // G3 -> G1
+  char* GB = smem_hx + HX_IMG_Z + HX_IMG_G;     // fp32 Z3 staging -> G2
+  float* stg = reinterpret_cast<float*>(GB);
+  float* sWo4 = reinterpret_cast<float*>(smem_hx + HX_IMGS);      // [128][4]
+  float* sdE = sWo4 + FH * 4;         // [64][4]
+  float* sCen = sdE + FTM * 4;        // [128]
+#ifdef HX_STAMP
+  unsigned long long* sStamp = reinterpret_cast<unsigned long long*>(sCen + FH);   // [2][4][16]
+  int titer = -1;
+#endif
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kslab = wave >> 1, nsl0 = 2 * (wave & 1);   // dW blocks
+  const int zk = wave & 3, zrt = wave >> 2;             // dZ block / elementwise ownership
+  const int cn = tid & 127, rq = tid >> 7;              // dWo ownership
+  const int row = 32 * zrt + l31;                       // this lane's edge row in the tile
+  const int col0 = 32 * zk + 4 * half;                  // its columns: col0 + 8q + j
+  const int prz = hx_prow_z(row), prg = hx_prow_g(row); // where that row lives in the images
+  const int E = a.E;
+  const float gscale = a.scale[0], ginv = a.scale[1];   // gradients run scaled by a power of two (header)
+  // tape offsets of this wave's block for the tile starting at ROW0 (see hx_load_z)
+#define HX_ZFULL(ROW0) (a.tape_blocked && (ROW0) + 32 * zrt + 32 <= a.n_edges)
+#define HX_ZOFF(ROW0, GI) (HX_ZFULL(ROW0) ? (int)(((ROW0) / 32 + zrt) * 16384 + (zk * 256 + lane) * 16) : (GI) * (FH * 4) + col0 * 4)
+#define HX_ZQ(ROW0) (HX_ZFULL(ROW0) ? 1024 : 32)
+
+  // Wo for the G3 product, stored as column PAIRS [c/2][n][c&1]: a 16-B read delivers (Wo[c][n], Wo[c+1][n]) side by
+  // side for two n, the operand shape of v_pk_fma_f32 (row-major [c][4] cost six v_mov per column pair to rearrange)
+  for (int t = tid; t < FH * 4; t += HX_THREADS) {
+    const int c = t >> 2, n = t & 3;
+    sWo4[((c >> 1) * 4 + n) * 2 + (c & 1)] = n < E ? a.Wo[c * E + n] : 0.f;
+  }
+  if (tid < FH) sCen[tid] = a.centers[tid];
+
+  f32x16 accW[3][2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW[l][j][r] = 0.f;
+  f32x16 accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = 0.f;
+  float accWo[4] = {0.f, 0.f, 0.f, 0.f};
+  float accbo = 0.f;
+
+  const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
+  // one buffer resource per array (offsets are 32-bit: n_edges * 512 B < 4 GB, checked by the host)
+  const unsigned zbytes = (unsigned)(a.n_edges * FH * 4);
+  const __amdgpu_buffer_rsrc_t rsZ1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + a.z_layer_stride), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + 2 * a.z_layer_stride), 0, zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_src), 0, (unsigned)(a.n_edges * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_eff), 0, (unsigned)(a.n_edges * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDe = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.de), 0, (unsigned)(a.n_edges * a.E * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wt_img), 0, 2 * 4 * 8 * 2 * 1024, 0x00020000);
+  __syncthreads();
+
+  // per-tile inputs of this lane's row, requested one tile ahead
+  float z3r[16], z2r[16], pf_ds, pf_dn, pf_de[4];
+  // Nothing here may USE a loaded value (no select, no conversion): a use inside this block makes the compiler
+  // wait for the HBM loads right behind their issue, in front of the GEMM they are meant to hide under.  Indices are
+  // clamped, the masks are applied at the point of use in the next iteration.
+  auto prefetch = [&](int64_t row0) {
+    const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
+    const int gi = (int)gr;
+    hx_load_z(z3r, rsZ3, HX_ZOFF(row0, gi), HX_ZQ(row0));
+    pf_ds = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDs, gi * 4, 0, 0));
+    pf_dn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDn, gi * 4, 0, 0));
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      pf_de[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDe, (gi * E + std::min(n, E - 1)) * 4, 0, 0));
+  };
+  // Z2 of the next tile: its registers are free only after phase B's epilogue
+  auto prefetch_z2 = [&](int64_t row0) {
+    const int gi = (int)std::min<int64_t>(row0 + row, a.n_edges - 1);
+    hx_load_z(z2r, rsZ2, HX_ZOFF(row0, gi), HX_ZQ(row0));
+  };
+  if ((int64_t)blockIdx.x < ntiles) { prefetch((int64_t)blockIdx.x * FTM); prefetch_z2((int64_t)blockIdx.x * FTM); }
+
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef HX_STAMP
+    ++titer;
+#endif
+    HX_T(0);
+    const int64_t row0 = tile * FTM;
+    const int64_t grow = std::min<int64_t>(row0 + row, a.n_edges - 1);
+    const bool on = pf_ds > 0.f && row0 + row < a.n_edges;
+    const float dn = pf_dn;
+    float dEm[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dEm[n] = (on && n < E) ? gscale * pf_de[n] : 0.f;
+    float z1r[16];
+    hx_load_z(z1r, rsZ1, HX_ZOFF(row0, (int)grow), HX_ZQ(row0));        // used after phase B's GEMMs
+    // ------------------------------------------------------------------ phase A
+    if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(dEm[0], dEm[1], dEm[2], dEm[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(stg + row * HX_STG + col0 + 8 * q) =
+          make_float4(z3r[4 * q + 0], z3r[4 * q + 1], z3r[4 * q + 2], z3r[4 * q + 3]);
+    HX_T(1);
+    NG_LDS_BARRIER();
+    HX_T(2);
+    // dWo[k][n] += sum_rows Z3[row][k] dE[row][n]   (thread: k = cn, rows 16rq..16rq+15), fp32 on the VALU
+#pragma unroll 4
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) {
+      const float z = stg[r * HX_STG + cn];
+      const float4 d = *reinterpret_cast<const float4*>(sdE + 4 * r);
+      accWo[0] += z * d.x; accWo[1] += z * d.y; accWo[2] += z * d.z; accWo[3] += z * d.w;
+      if (cn < 4) accbo += sdE[4 * r + cn];
+    }
+    {   // G3 = (dE Wo^T) * s'(Z3)  ->  GA ;  db3
+      float g[16];
+      typedef float f32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const float4 w01 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));      // (x0 x1 y0 y1)
+          const float4 w23 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j) + 4);  // (z0 z1 w0 w1)
+          f32x2v pre = f32x2v{w01.x, w01.y} * dEm[0];
+          pre = __builtin_elementwise_fma(f32x2v{w01.z, w01.w}, f32x2v{dEm[1], dEm[1]}, pre);
+          pre = __builtin_elementwise_fma(f32x2v{w23.x, w23.y}, f32x2v{dEm[2], dEm[2]}, pre);
+          pre = __builtin_elementwise_fma(f32x2v{w23.z, w23.w}, f32x2v{dEm[3], dEm[3]}, pre);
+          g[4 * q + j] = pre[0]; g[4 * q + j + 1] = pre[1];
+          hx_sprime2(g[4 * q + j], g[4 * q + j + 1], z3r[4 * q + j], z3r[4 * q + j + 1]);
+        }
+      hx_img_write<HX_ROWG>(GA, prg, col0, g);
+    }
+    hx_img_write<HX_ROWZ>(IZ, prz, col0, z2r);       // Z2 pieces
+    u32x4 w0[2];
+    hx_wload(w0, wrs, lane * 16, ((1 * 4 + zk) * 8) * 2 * 1024, 0);
+    HX_T(3);
+    NG_LDS_BARRIER();
+    HX_T(4);
+    // ------------------------------------------------------------------ phase B (layer 3)
+    // the two waves of a SIMD (zrt = 0 / 1) take the two independent GEMMs of the phase in opposite order, so that
+    // one wave's epilogue (VALU: s', bias sums, split) runs beside the other's MFMAs
+    if (zrt == 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
+    HX_T(5);
+    {
+      float g[16];
+      // the wave whose epilogue comes NEXT gets the matrix pipe first (the arbiter otherwise favours the partner,
+      // which then runs both of its GEMMs back to back and both epilogues end up side by side)
+      if (zrt != 0) __builtin_amdgcn_s_setprio(2);
+      hx_dz_gemm(g, GA, prg, wrs, w0, 1, zk, lane);
+      if (zrt != 0) __builtin_amdgcn_s_setprio(0);
+      HX_T(6);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z2r[r], z2r[r + 1]);
+      hx_img_write<HX_ROWG>(GB, prg, col0, g);       // G2
+    }
+    HX_T(7);
+    if (zrt != 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
+    HX_T(8);
+    NG_LDS_BARRIER();
+    HX_T(9);
+    hx_img_write<HX_ROWZ>(IZ, prz, col0, z1r);       // Z1 pieces
+    hx_wload(w0, wrs, lane * 16, ((0 * 4 + zk) * 8) * 2 * 1024, 0);
+    NG_LDS_BARRIER();
+    HX_T(10);
+    // ------------------------------------------------------------------ phase C (layer 2)
+    if (zrt == 0) hx_dw_gemm(accW[1], accB, 2, IZ, GB, kslab, nsl0, lane);
+    {
+      float g[16];
+      if (zrt != 0) __builtin_amdgcn_s_setprio(2);
+      hx_dz_gemm(g, GB, prg, wrs, w0, 0, zk, lane);
+      if (zrt != 0) __builtin_amdgcn_s_setprio(0);
+      // next tile's Z3 / d / dE (registers dead since phase A).  Issued BEHIND the last W^T fragment loads of the tile:
+      // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
+      prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z1r[r], z1r[r + 1]);
+      hx_img_write<HX_ROWG>(GA, prg, col0, g);       // G1
+    }
+    HX_T(11);
+    if (zrt != 0) hx_dw_gemm(accW[1], accB, 2, IZ, GB, kslab, nsl0, lane);
+    NG_LDS_BARRIER();
+    HX_T(12);
+    {   // R = m * rbf(d_eff)  ->  IZ   (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
+      float rr[16];
+      const float dm = on ? dn : 1.0e19f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 mu = *reinterpret_cast<const float4*>(sCen + col0 + 8 * q);
+        const float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
+        rr[4 * q + 0] = __builtin_amdgcn_exp2f(u0 * u0 * a.neg_inv_gap_log2e);
+        rr[4 * q + 1] = __builtin_amdgcn_exp2f(u1 * u1 * a.neg_inv_gap_log2e);
+        rr[4 * q + 2] = __builtin_amdgcn_exp2f(u2 * u2 * a.neg_inv_gap_log2e);
+        rr[4 * q + 3] = __builtin_amdgcn_exp2f(u3 * u3 * a.neg_inv_gap_log2e);
+      }
+      hx_img_write<HX_ROWZ>(IZ, prz, col0, rr);
+    }
+    NG_LDS_BARRIER();
+    HX_T(13);
+    // ------------------------------------------------------------------ phase D (layer 1)
+    prefetch_z2(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
+    hx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
+    HX_T(14);
+    NG_LDS_BARRIER();
+    HX_T(15);
+  }
+
+#ifdef HX_STAMP
+  __syncthreads();
+  if (blockIdx.x == 3 && tid < 128) a.stamps[tid] = sStamp[tid];
+  __syncthreads();
+#endif
+  // ---------------------------------------------------------------------- write this workgroup's partial
+  float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
+  {
+    const int k = kslab * 32 + l31;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = (nsl0 + j) * 32 + 8 * q + 4 * half;
+          *reinterpret_cast<float4*>(part + l * FH * FH + k * FH + n) =
+              make_float4(ginv * accW[l][j][4 * q + 0], ginv * accW[l][j][4 * q + 1], ginv * accW[l][j][4 * q + 2],
+                          ginv * accW[l][j][4 * q + 3]);
+        }
+  }
+  // bias sums of the two edge halves, dWo / dbo of the four row quarters: summed through LDS (IZ is free now)
+  float* red = reinterpret_cast<float*>(IZ);
+  float* dbw = reinterpret_cast<float*>(GA);     // [4 k-slab waves][3 layers][128]
+  const int red_stride = 3 * FH + FH * E + E;
+  {
+    const int c = l31 / 5;     // this lane's column group; its first column carries the sums
+    if (c < 6 && l31 == 5 * c && (c & 1) >= 0) {
+      const int layer = c >> 1, j = c & 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dbw[(kslab * 3 + layer) * FH + 32 * (nsl0 + j) + (r & 3) + 8 * (r >> 2) + 4 * half] = ginv * accB[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = dbw[(rq * 3 + l) * FH + cn];
+  for (int n = 0; n < E; ++n) red[rq * red_stride + 3 * FH + cn * E + n] = ginv * accWo[n];
+  if (cn < E) red[rq * red_stride + 3 * FH + FH * E + cn] = ginv * accbo;
+  __syncthreads();
+  for (int t = tid; t < red_stride; t += HX_THREADS)
+    part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
+}
+
+// ---- the power-of-two gradient scale (header: Ranges).  Stage 1: per-block max |de|; stage 2 (one block): the
+// largest absolute row sums of Wo, W3, W2 and S = 2^floor(log2(2^15 / bound)).  max is exact and order-free, so the
+// scale — and with it every bit of the result — does not depend on the launch geometry.
+constexpr int HX_SCALE_BLOCKS = 256;
+__global__ __launch_bounds__(256) void hx_absmax_kernel(const float* __restrict__ de, int64_t n, float* __restrict__ blockmax) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(de[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(128) void hx_scale_kernel(const float* __restrict__ blockmax, int nblocks, const float* __restrict__ W2,
+                                                       const float* __restrict__ W3, const float* __restrict__ Wo, int E,
+                                                       float* __restrict__ scale) {
+  __shared__ float red[4][128];
+  const int k = threadIdx.x;      // row k of W2 / W3 / Wo
+  float m = 0.f, r2 = 0.f, r3 = 0.f, ro = 0.f;
+  for (int i = k; i < nblocks; i += 128) m = fmaxf(m, blockmax[i]);
+  for (int n = 0; n < FH; ++n) { r2 += fabsf(W2[k * FH + n]); r3 += fabsf(W3[k * FH + n]); }
+  for (int n = 0; n < E; ++n) ro += fabsf(Wo[k * E + n]);
+  red[0][k] = m; red[1][k] = r2; red[2][k] = r3; red[3][k] = ro;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (k < s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[j][k] = fmaxf(red[j][k], red[j][k + s]);
+    __syncthreads();
+  }
+  if (k == 0) {
+    const float b3 = red[0][0] * red[3][0], b2 = b3 * red[2][0], b1 = b2 * red[1][0];
+    const float bound = fmaxf(b3, fmaxf(b2, b1));
+    int ex = 0;
+    // a NaN / inf gradient keeps S = 1 and propagates; an all-zero one too
+    if (bound > 0.f && bound < 3.0e38f) {
+      int eb;
+      (void)frexpf(bound, &eb);              // bound = f * 2^eb, f in [0.5, 1)  ->  bound <= 2^eb
+      ex = 15 - eb;
+      ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+    }
+    scale[0] = ldexpf(1.0f, ex);
+    scale[1] = ldexpf(1.0f, -ex);
+  }
+}
+
+// Buffer offsets inside the kernel are 32-bit (one resource per array, 512 B of tape per edge), so one LAUNCH covers
+// at most HX_SEG_EDGES edges (the segment size of edge_bwd_x3.hip: edge_bwd_x3_segments); longer edge lists run as
+// several launches over consecutive segments, each with its own rows of the partial buffer.
+constexpr int64_t HX_SEG_EDGES = ((int64_t)1 << 23) - 256;
+constexpr size_t HX_WT_BYTES = (size_t)2 * 4 * 8 * 2 * 1024;
+
+size_t edge_bwd_h2_ws_bytes() { return HX_WT_BYTES + (size_t)(HX_SCALE_BLOCKS + 2) * 4; }
+
+// wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_x3_segments(n_edges) * grid][part_stride]
+int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                       const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked) {
+  float* blockmax = reinterpret_cast<float*>(wt_img + HX_WT_BYTES);
+  float* scale = blockmax + HX_SCALE_BLOCKS;
+  {
+    ProfScope ps(ctx, st, "edge_bwd_h2_prep");
+    hipLaunchKernelGGL(h2_pack_wt_kernel, dim3(16), dim3(256), 0, st, W[1], W[2], (unsigned*)wt_img);
+    const int nb = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 256));
+    hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb), dim3(256), 0, st, de, n_edges * E, blockmax);
+    hipLaunchKernelGGL(hx_scale_kernel, dim3(1), dim3(128), 0, st, blockmax, nb, W[1], W[2], W[3], E, scale);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  const int nseg = edge_bwd_x3_segments(n_edges);
+  for (int sg = 0; sg < nseg; ++sg) {
+    const int64_t e0 = (int64_t)sg * HX_SEG_EDGES;
+    EdgeBwdH2Args a;
+    a.n_edges = std::min<int64_t>(HX_SEG_EDGES, n_edges - e0); a.d_src = d_src + e0; a.d_eff = d_eff + e0; a.centers = centers;
+    a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
+    a.wt_img = wt_img; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH; a.de = de + e0 * E;
+    a.partial = partial + (size_t)sg * grid * part_stride; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;
+    a.stamps = nullptr;
+#ifdef HX_STAMP
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { hipMalloc(&dbg, 1024); }
+    a.stamps = dbg;
+#endif
+    ProfScope ps(ctx, st, "edge_bwd_h2");
+    hipLaunchKernelGGL(edge_bwd_h2_kernel, dim3(grid), dim3(HX_THREADS), HX_LDS_BYTES, st, a);
+    NG_HIP(ctx, hipGetLastError());
+    if (sg + 1 < nseg) continue;
+#ifdef HX_STAMP
+    {
+      static int calls = 0;
+      if (++calls == 3) {
+        unsigned long long h[128];
+        hipStreamSynchronize(st);
+        hipMemcpy(h, a.stamps, 1024, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 2; ++w)
+          for (int t = 0; t < 4; ++t) {
+            printf("wave %d tile %d:", 4 * w, t);
+            for (int k = 1; k < 16; ++k) printf(" %5lld", (long long)(h[(w * 4 + t) * 16 + k] - h[(w * 4 + t) * 16 + k - 1]));
+            if (t < 3) printf(" | next %5lld", (long long)(h[(w * 4 + t + 1) * 16] - h[(w * 4 + t) * 16 + 15]));
+            printf("\n");
+          }
+      }
+    }
+#endif
+  }
+  return NG_OK;
+}
+
+}  // namespace ng

@@ -56,4 +56,9 @@ size_t edge_bwd_x3_ws_bytes();
 int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
                        char* wt_img, float* partial, int part_stride, int grid, int tape_blocked);
+// the same contract on the fp16 pipe with two-piece operands (edge_bwd_h2.hip): the default
+size_t edge_bwd_h2_ws_bytes();
+int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
+                       const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked);
 }  // namespace ng

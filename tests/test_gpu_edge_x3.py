@@ -184,15 +184,42 @@ def test_edge_backward_split_vs_float64(gpu_device, monkeypatch, n, E):
         mag_dW[l], mag_db[l] = np.abs(xs[l]).T @ np.abs(G), np.abs(G).sum(0)
         g = G @ Wf[l].T
     out = {}
-    for math in ("bf16x3", "fp32"):
+    for math in ("f16x2", "bf16x3", "fp32"):
         monkeypatch.setenv("NG_EDGE_MATH", math)
         out[math] = run_gpu_bwd(gpu_device, d_src, d_eff, centers, gap, Ws, zs32, de, E)
     for l in range(4):
         for name, ref, mag, k in (("dW", ref_dW[l], mag_dW[l], 0), ("db", ref_db[l], mag_db[l], 1)):
             scale = max(mag.max(), 1e-6)
             err = {mth: np.abs(o[k][l] - ref).max() / scale for mth, o in out.items()}
-            assert err["bf16x3"] < 1e-6, (name, l, err)                 # ~16 fp32 roundings of the term scale
-            assert err["bf16x3"] < 4.0 * err["fp32"] + 1e-7, (name, l, err)
+            for split in ("f16x2", "bf16x3"):
+                assert err[split] < 1e-6, (split, name, l, err)                 # ~16 fp32 roundings of the term scale
+                assert err[split] < 4.0 * err["fp32"] + 1e-7, (split, name, l, err)
+
+
+@pytest.mark.parametrize("shift", [-40, -13, 9, 30])
+def test_edge_backward_f16x2_gradient_scale_is_exact(gpu_device, monkeypatch, shift):
+    """The two-piece fp16 backward runs on S * dE with S a power of two picked per call from max|dE| and the weight
+    norms (edge_bwd_h2.hip), so that fp16 pieces neither overflow nor lose bits whatever the loss scaling is.
+    Size-independent property: multiplying dE by 2^shift must multiply every gradient by exactly 2^shift — bit for bit
+    (S moves by the same power of two; nothing else sees the change)."""
+    n, E = 5000, 3
+    rng = np.random.default_rng(11)
+    d_src = rng.uniform(0.05, 1.2, n)
+    d_src[rng.random(n) < 0.15] = 0.0
+    centers = np.linspace(0.0, 1.2, H)
+    gap = centers[1] - centers[0]
+    Ws = [rng.standard_normal((H, H)) * 0.15 for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2]
+    bs = [rng.standard_normal(H) * 0.1 for _ in range(3)] + [rng.standard_normal(E) * 0.1]
+    de = rng.standard_normal((n, E)).astype(np.float32).astype(np.float64)
+    _, _, zs = ref_edge_bwd(d_src, d_src, centers, gap, Ws, bs, de)
+    zs32 = [np.asarray(z, dtype=np.float32).astype(np.float64) for z in zs]
+    monkeypatch.setenv("NG_EDGE_MATH", "f16x2")
+    base = run_gpu_bwd(gpu_device, d_src, d_src, centers, gap, Ws, zs32, de, E)
+    moved = run_gpu_bwd(gpu_device, d_src, d_src, centers, gap, Ws, zs32, de * 2.0 ** shift, E)
+    for k in range(2):
+        for l in range(4):
+            assert np.array_equal(moved[k][l], base[k][l] * 2.0 ** shift), (k, l)
+    assert all(np.isfinite(g).all() for k in range(2) for g in moved[k])
 
 
 def test_edge_backward_beyond_one_launch_segment(gpu_device):
