@@ -83,7 +83,7 @@ def test_hip_equals_reference_graph_training(gpu_device, tag):
 
 @pytest.mark.parametrize("math", ["fp32"])
 def test_strict_fp32_mfma_has_the_same_error(gpu_device, monkeypatch, math):
-    """The default path runs its contractions as bf16x3 split products; with f32-input MFMA only
+    """The default path runs its contractions as split products on the 16-bit matrix pipe (edge MLP: two fp16 pieces); with f32-input MFMA only
     (NG_EDGE_MATH / NG_GEMM_MATH = fp32) the error against the reference graph is of the same size,
     i.e. the remaining distance is float32 arithmetic, not the split."""
     c = load_savedmodel_case("pdb108m")
@@ -94,7 +94,7 @@ def test_strict_fp32_mfma_has_the_same_error(gpu_device, monkeypatch, math):
     strict = eng.forward(gb, training=False).cpu().numpy().astype(np.float64)
     e_def = np.abs(base - c["peaks64"]).max()
     e_strict = np.abs(strict - c["peaks64"]).max()
-    print(f"[pdb108m] default (split bf16x3) max err {e_def:.3e}; strict f32-MFMA max err {e_strict:.3e}; "
+    print(f"[pdb108m] default (split operands) max err {e_def:.3e}; strict f32-MFMA max err {e_strict:.3e}; "
           f"max |default - strict| {np.abs(base - strict).max():.3e}")
     assert not np.array_equal(base, strict)        # the switch really selected other kernels
     assert e_def <= 4 * e_strict + 1e-5

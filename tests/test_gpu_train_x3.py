@@ -28,8 +28,10 @@ def _run(gpu_device, monkeypatch, math, steps=12):
     return np.array(losses), eng.params.flat.detach().cpu().numpy().astype(np.float64)
 
 
-def test_training_trajectories_coincide(gpu_device, monkeypatch):
-    l_x3, p_x3 = _run(gpu_device, monkeypatch, "bf16x3")
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+def test_training_trajectories_coincide(gpu_device, monkeypatch, split):
+    """f16x2: the default two-piece fp16 kernels (edge_fwd_h2 / edge_bwd_h2); bf16x3: the exact three-piece ones"""
+    l_x3, p_x3 = _run(gpu_device, monkeypatch, split)
     l_32, p_32 = _run(gpu_device, monkeypatch, "fp32")
     assert l_32[-1] < l_32[0]                                   # it trains
     assert np.max(np.abs(l_x3 - l_32) / np.abs(l_32)) < 2e-5, (l_x3, l_32)
