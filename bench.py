@@ -199,7 +199,7 @@ def cpu_baseline(hp_dict, sample_graphs, seed, budget_s=20.0):
             "ms_per_step": med * 1e3}
 
 
-# kernels whose generic GEMM runs on the bf16 pipe with split operands when the shape allows (gemm_x3.hip)
+# kernels whose generic GEMM runs on the fp16 pipe with two-piece split operands when the shape allows (gemm_h2.hip)
 X3_GEMM_TAGS = {"mp_update_fwd", "mp_dw", "mp_dA", "dense_fwd", "dense_dx", "dense_dw", "edge_dense_fwd",
                 "edge_dense_dx", "edge_dense_dw"}
 # kernel tag -> the source files whose content decides whether a committed PMC number still describes it
@@ -266,8 +266,8 @@ def roofline_rows(prof, psteps, work, x3_gemm):
             bound, fl, by = work[name]
             if bound == "mfma":
                 ach = fl / (avg_ms * 1e-3) / 1e12
-                on_x3 = name in X3_KERNELS or (x3_gemm and name in X3_GEMM_TAGS)
-                on_h2 = name in H2_KERNELS
+                on_x3 = name in X3_KERNELS
+                on_h2 = name in H2_KERNELS or (x3_gemm and name in X3_GEMM_TAGS)
                 peak = (PEAK_MFMA_F16_TFLOPS / 3.0 if on_h2 else
                         PEAK_MFMA_BF16_TFLOPS / 6.0 if on_x3 else PEAK_MFMA_F32_TFLOPS)
                 row.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)

@@ -79,6 +79,19 @@ void* aux_workspace(ng_ctx* ctx, size_t bytes) {
   return p;
 }
 
+void* small_scratch(ng_ctx* ctx) {
+  if (ctx->small) return ctx->small;
+  DeviceGuard dg(ctx->device);
+  void* p = nullptr;
+  const hipError_t e = hipMalloc(&p, NG_SMALL_BYTES);
+  if (e != hipSuccess) {
+    ctx->err = std::string("small scratch hipMalloc: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  ctx->small = p;
+  return p;
+}
+
 void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* valid) {
   *valid = false;
   if (!ctx->wcache) return nullptr;
@@ -159,6 +172,7 @@ extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   ng::DeviceGuard dg(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->aux) (void)hipFree(ctx->aux);
+  if (ctx->small) (void)hipFree(ctx->small);
   for (auto& kv : ctx->wimg)
     if (kv.second.buf) (void)hipFree(kv.second.buf);
   for (auto& r : ctx->recs) {

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
 #pragma unroll
   for (int r = 0; r < 16; ++r) accB[r] = 0.f;
   float accWo[4] = {0.f, 0.f, 0.f, 0.f};
-  float accbo = 0.f;
+  float accbo[4] = {0.f, 0.f, 0.f, 0.f};     // sum of this lane's row of dE over the tiles (8 lanes hold each row)
 
   const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
   // one buffer resource per array (offsets are 32-bit: n_edges * 512 B < 4 GB, checked by the host)
@@ -359,6 +359,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
     float dEm[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) dEm[n] = (on && n < E) ? gscale * pf_de[n] : 0.f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) accbo[n] += dEm[n];
     float z1r[16];
     hx_load_z(z1r, rsZ1, HX_ZOFF(row0, (int)grow), HX_ZQ(row0));        // used after phase B's GEMMs
     // ------------------------------------------------------------------ phase A
@@ -376,7 +378,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       const float z = stg[r * HX_STG + cn];
       const float4 d = *reinterpret_cast<const float4*>(sdE + 4 * r);
       accWo[0] += z * d.x; accWo[1] += z * d.y; accWo[2] += z * d.z; accWo[3] += z * d.w;
-      if (cn < 4) accbo += sdE[4 * r + cn];
     }
     {   // G3 = (dE Wo^T) * s'(Z3)  ->  GA ;  db3
       float g[16];
@@ -504,11 +505,18 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
         dbw[(kslab * 3 + layer) * FH + 32 * (nsl0 + j) + (r & 3) + 8 * (r >> 2) + 4 * half] = ginv * accB[r];
     }
   }
+  // dbo: the lanes that own a row (zk == 0, lower half) publish their sums; fixed-order sum over the 64 rows below
+  if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(accbo[0], accbo[1], accbo[2], accbo[3]);
   __syncthreads();
 #pragma unroll
   for (int l = 0; l < 3; ++l) red[rq * red_stride + l * FH + cn] = dbw[(rq * 3 + l) * FH + cn];
   for (int n = 0; n < E; ++n) red[rq * red_stride + 3 * FH + cn * E + n] = ginv * accWo[n];
-  if (cn < E) red[rq * red_stride + 3 * FH + FH * E + cn] = ginv * accbo;
+  if (cn < E) {
+    float sbo = 0.f;
+    if (rq == 0)
+      for (int r = 0; r < FTM; ++r) sbo += sdE[4 * r + cn];
+    red[rq * red_stride + 3 * FH + FH * E + cn] = ginv * sbo;
+  }
   __syncthreads();
   for (int t = tid; t < red_stride; t += HX_THREADS)
     part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];

@@ -541,7 +541,7 @@ namespace ng {
 __global__ __launch_bounds__(256) void fc_dp_kernel(int64_t N, int No, int64_t rows_per_block, int act,
                                                     const float* __restrict__ dY, const float* __restrict__ a,
                                                     const float* __restrict__ b, float* __restrict__ dP,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ partial, float* __restrict__ blockmax) {
   extern __shared__ __attribute__((aligned(16))) float fc_red[];     // [RL][No]
   const int c4n = No / 4;
   const int RL = 256 / c4n;
@@ -549,6 +549,7 @@ __global__ __launch_bounds__(256) void fc_dp_kernel(int64_t N, int No, int64_t r
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amax = 0.f;      // max |dP| of the block: the fp16 GEMMs' power-of-two gradient scale (gemm_h2.hip)
   if (r < RL) {
     for (int64_t i = r0 + r; i < r1; i += RL) {
       const int64_t o = i * c4n + q;
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(256) void fc_dp_kernel(int64_t N, int No, int64_t r
       }
       reinterpret_cast<float4*>(dP)[o] = d;
       cs.x += d.x; cs.y += d.y; cs.z += d.z; cs.w += d.w;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
     }
     *reinterpret_cast<float4*>(fc_red + r * No + 4 * q) = cs;
   }
@@ -573,6 +575,7 @@ __global__ __launch_bounds__(256) void fc_dp_kernel(int64_t N, int No, int64_t r
     for (int rr = 0; rr < RL; ++rr) t += fc_red[rr * No + it];
     partial[(int64_t)blockIdx.x * No + it] = t;
   }
+  if (blockmax) block_max_store(amax, blockmax);
 }
 }  // namespace ng
 
@@ -634,19 +637,26 @@ extern "C" int ng_fc_block_bwd(ng_ctx* ctx, void* stream, int64_t N, int F, int 
     const int nblk = (int)cdiv(N, rows);
     float* partial = (float*)aux_workspace(ctx, (size_t)nblk * No * 4);
     if (!partial) return NG_ERR_NOMEM;
+    const float* gsc = nullptr;         // the same dP feeds both products: one scale, from the dP kernel's block maxima
     {
       ProfScope ps(ctx, st, "fc_dP");
+      int cap = 0;
+      float* bmax = dense_grad_uses_h2(N, F, No) ? gemm_grad_blockmax(ctx, &cap) : nullptr;
       hipLaunchKernelGGL(fc_dp_kernel, dim3(nblk), dim3(256), (size_t)rl * No * 4, st, N, No, rows, act, cur,
-                         resid ? x[l + 1] : g, resid ? x[l] : nullptr, dP, partial);
+                         resid ? x[l + 1] : g, resid ? x[l] : nullptr, dP, partial, bmax);
       launch_reduce_z(st, partial, nblk, (int64_t)No, db[l]);
       NG_HIP(ctx, hipGetLastError());
+      if (bmax) {
+        const int rcs = gemm_grad_scale_from_blocks(ctx, st, nblk, &gsc);
+        if (rcs) return rcs;
+      }
     }
     float* dwscr = (float*)workspace(ctx, dense_dw_scratch_floats(ctx, N, F, No, false) * sizeof(float));
     if (!dwscr) return NG_ERR_NOMEM;
-    int rc = dense_dw(ctx, st, N, F, No, NG_ACT_NONE, x[l], dP, nullptr, nullptr, dW[l], nullptr, 0, 0, 0, dwscr, "dense_dw");
+    int rc = dense_dw(ctx, st, N, F, No, NG_ACT_NONE, x[l], dP, nullptr, nullptr, dW[l], nullptr, 0, 0, 0, dwscr, "dense_dw", gsc);
     if (rc) return rc;
     float* out = l == 0 ? dx : nxt;
-    rc = dense_dx(ctx, st, N, F, No, NG_ACT_NONE, dP, nullptr, nullptr, W[l], resid ? cur : nullptr, out, "dense_dx");
+    rc = dense_dx(ctx, st, N, F, No, NG_ACT_NONE, dP, nullptr, nullptr, W[l], resid ? cur : nullptr, out, "dense_dx", gsc);
     if (rc) return rc;
     cur = out;
     nxt = out == d0 ? d1 : d0;

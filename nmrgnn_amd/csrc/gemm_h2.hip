@@ -1,14 +1,24 @@
-// Generic dense forward on the bf16 matrix pipe with exactly split fp32 operands (x3_common.cuh):
-//   Y = act(rowscale * (X W) + b) (+ R),   X [M][K], W [K][N] row-major fp32,   K % 32 == 0, N % 128 == 0.
-// The matrix-bound shapes of the reference's default width (atom_feature_size = 256: the MPLayer update
-// [N, 768] x [768, 256] of nmrgnn/layers.py:39-40 and the FCBlock layers of model.py:191-196) ran at 87-99 TF on the
-// f32-input MFMA tile GEMM (gemm_ops.hip); this kernel serves dense_fwd for them.  NG_GEMM_MATH=fp32 opts out.
+// Generic dense products on the fp16 matrix pipe with two-piece split fp32 operands (h2_common.cuh: x = h + l,
+// three piece products per multiply, fp32 accumulate):
+//   forward   Y = act(rowscale * (X W) + b) (+ R),   X [M][K], W [K][N] row-major fp32,   K % 32 == 0, N % 128 == 0
+//   dX = dP W^T (+ add),  dW = X^T dP   with  dP = dY * act'(S) * rowscale  formed by the operand loaders.
+// They serve dense_fwd / dense_dx / dense_dw for the matrix-bound shapes of the reference's default width
+// (atom_feature_size = 256: the MPLayer update [N, 768] x [768, 256] of nmrgnn/layers.py:39-40, its dA / dw products and
+// the FCBlock layers of model.py:191-196).  NG_GEMM_MATH=fp32 opts out (f32-input MFMA tile GEMM, gemm_ops.hip).
+// Until late round 2 these kernels used the exact three-piece bf16 split (six products); two fp16 pieces halve the
+// matrix instructions and the split work per element at the same float64 error (tests/test_gpu_gemm_h2.py).
+//
+// Ranges (see h2_common.cuh).  Weight pieces are taken from 2^8 W.  Activation operands (X) are split unscaled.
+// Gradient operands (dP) are multiplied by a power of two S before the split, S = 2^(14 - e) with 2^e >= max|dY| max|rs|
+// (gh_absmax_kernel + gh_scale_kernel, one pass over dY per gradient tensor: gemm_grad_scale; dense_dx and dense_dw of
+// the same dP share it), so pieces cannot overflow and keep their bits whatever the loss scaling is; epilogues
+// multiply by 2^-8 / S.
 //
 // 256 threads = 4 waves, tile 128 rows x 256 columns (128 when N % 256 != 0), two workgroups per CU; per 32-wide k-step:
-//   W pieces: fragment-ordered image packed once per call, 48 / 24 KB per (column tile, k-step) copied to LDS by LDS-DMA;
+//   W pieces: fragment-ordered image packed once per call, 32 / 16 KB per (column tile, k-step) copied to LDS by LDS-DMA;
 //   X pieces: each thread loads 16 consecutive floats of one row (prefetched one step ahead), splits them and writes
-//             the three piece planes [128][32 + 8] bf16;
-//   wave (n-half, m-half): 4 x 2 (2 x 2) blocks of 32 x 32, v_mfma_f32_32x32x16_bf16, A = W^T pieces (rows n), B = X pieces
+//             the two piece planes [128][32 + 8] fp16;
+//   wave (n-half, m-half): 4 x 2 (2 x 2) blocks of 32 x 32, v_mfma_f32_32x32x16_f16, A = W^T pieces (rows n), B = X pieces
 //   (columns m), so a lane ends with 4 consecutive n of one row m: 16-byte stores.
 #include <algorithm>
 #include <cstdlib>
@@ -17,7 +27,8 @@
 #include "edge_fused.h"     // NG_LDS_BARRIER
 #include "mfma_gemm.cuh"    // act_apply
 #include "ng_internal.h"
-#include "x3_common.cuh"
+#include "h2_common.cuh"
+#include "reduce.cuh"
 
 namespace ng {
 
@@ -25,11 +36,12 @@ constexpr int GX_BM = 128, GX_BN = 128, GX_BK = 32;
 constexpr int GX_XROW = 80;                       // bytes per row of an X piece plane (64 + 16: conflict-free b128 rows)
 constexpr int GX_XPLANE = GX_BM * GX_XROW;        // 10,240
 // NBW = 32-column blocks per wave (2 -> 128-column tiles, 4 -> 256-column tiles: half the barriers and X splits per MFMA)
-constexpr int gx_wchunk(int nbw) { return 2 * nbw * 2 * 3 * 1024; }   // [n-block][k-step of 16][piece][1 KB]
-constexpr int gx_lds(int nbw) { return 3 * GX_XPLANE + gx_wchunk(nbw); } // 55,296 / 79,872: two workgroups per CU
+constexpr int gx_wchunk(int nbw) { return 2 * nbw * 2 * 2 * 1024; }   // [n-block][k-step of 16][piece][1 KB]
+constexpr int gx_lds(int nbw) { return 2 * GX_XPLANE + gx_wchunk(nbw); } // 36,864 / 53,248: two workgroups per CU
+constexpr float GX_WSCALE = 256.0f, GX_WINV = 1.0f / 256.0f;      // weight pieces are taken from 2^8 W
 
-// image[(ct * KT + kt)][nb][ks][p][lane][8 bf16]:  lane (row n = 128 ct + 32 nb + (l&31), k-slot t) =
-//   piece_p( W[k = 32 kt + 16 ks + 8 (l>>5) + t][n] )
+// image[(ct * KT + kt)][nb][ks][p][lane][8 fp16]:  lane (row n = 128 ct + 32 nb + (l&31), k-slot t) =
+//   piece_p( 2^8 W[k = 32 kt + 16 ks + 8 (l>>5) + t][n] )
 // trans: the weights are stored [N][K] (dX = dP W^T: contraction over the stored matrix's columns)
 __global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img, int trans, int nbw) {
   const int KT = K / GX_BK;
@@ -40,14 +52,14 @@ __global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsign
   const int nb = (int)((idx >> 7) % NB);
   const int kt = (int)(((idx >> 7) / NB) % KT), ct = (int)(((idx >> 7) / NB) / KT);
   const int n = BN * ct + 32 * nb + (lane & 31), k0 = GX_BK * kt + 16 * ks + 8 * (lane >> 5);
-  unsigned h[4], m[4], l[4];
+  unsigned h[4], l[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    split3_pair(trans ? W[(int64_t)n * K + k0 + 2 * j] : W[(int64_t)(k0 + 2 * j) * N + n],
-                trans ? W[(int64_t)n * K + k0 + 2 * j + 1] : W[(int64_t)(k0 + 2 * j + 1) * N + n], h[j], m[j], l[j]);
-  unsigned* dst = img + ((int64_t)(ct * KT + kt) * (NB * 2 * 3 * 256)) + ((nb * 2 + ks) * 3) * 256 + lane * 4;
+    split2_pair(GX_WSCALE * (trans ? W[(int64_t)n * K + k0 + 2 * j] : W[(int64_t)(k0 + 2 * j) * N + n]),
+                GX_WSCALE * (trans ? W[(int64_t)n * K + k0 + 2 * j + 1] : W[(int64_t)(k0 + 2 * j + 1) * N + n]), h[j], l[j]);
+  unsigned* dst = img + ((int64_t)(ct * KT + kt) * (NB * 2 * 2 * 256)) + ((nb * 2 + ks) * 2) * 256 + lane * 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = m[j]; dst[512 + j] = l[j]; }
+  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
 }
 
 struct GxArgs {
@@ -65,7 +77,102 @@ struct GxArgs {
   const float* Sin;
   const float* rs_in;
   int act_in;
+  const float* gscale;   // GRAD: {S, 1/S} of the gradient operand (device memory); nullptr: 1
 };
+
+// ---- power-of-two scale of a gradient operand (header: Ranges).  The context's small scratch (64 KB, never moved)
+// holds [GH_MAXBLOCKS block maxima of |dY| | GH_RSBLOCKS maxima of |rs| | {S, 1/S}]; everything is ordered on the
+// caller's stream.  Producers of a gradient tensor (mp_dp_kernel, fc_dp_kernel) write the block maxima as a by-product
+// (gemm_grad_blockmax / gemm_grad_scale_from_blocks); gemm_grad_scale is the stand-alone pass for everything else.
+constexpr int GH_MAXBLOCKS = 8192, GH_RSBLOCKS = 256;
+static_assert((GH_MAXBLOCKS + GH_RSBLOCKS + 2) * 4 <= NG_SMALL_BYTES, "small scratch layout");
+
+__global__ __launch_bounds__(256) void gh_absmax_kernel(const float4* __restrict__ x, int64_t n4, float* __restrict__ blockmax) {
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent loads in flight
+    const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                       fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                       fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = x[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  block_max_store(m, blockmax);
+}
+
+__global__ __launch_bounds__(256) void gh_rsmax_kernel(const float* __restrict__ rs, int64_t n, float* __restrict__ blockmax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(rs[i]));
+  block_max_store(m, blockmax);
+}
+
+// S = 2^(14 - e), 2^e > max|dY| * max|rs|: |S dP| < 2^14 leaves a factor 4 for activation derivatives above 1
+// (gelu, selu, swish: <= 1.2).  max is exact and order-free: the scale does not depend on the launch geometry.
+__global__ __launch_bounds__(256) void gh_scale_kernel(const float* __restrict__ blockmax, int nblocks,
+                                                       const float* __restrict__ rsmax, int nrs, float* __restrict__ scale) {
+  __shared__ float red[2][256];
+  const int t = threadIdx.x;
+  float m = 0.f, r = 0.f;
+  for (int i = t; i < nblocks; i += 256) m = fmaxf(m, blockmax[i]);
+  for (int i = t; i < nrs; i += 256) r = fmaxf(r, rsmax[i]);
+  red[0][t] = m; red[1][t] = r;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) { red[0][t] = fmaxf(red[0][t], red[0][t + s]); red[1][t] = fmaxf(red[1][t], red[1][t + s]); }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float bound = red[0][0] * (nrs > 0 ? red[1][0] : 1.0f);
+    int ex = 0;
+    if (bound > 0.f && bound < 3.0e38f) {      // zero, inf or NaN gradients keep S = 1 (and propagate)
+      int eb;
+      (void)frexpf(bound, &eb);
+      ex = 14 - eb;
+      ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+    }
+    scale[0] = ldexpf(1.0f, ex);
+    scale[1] = ldexpf(1.0f, -ex);
+  }
+}
+
+float* gemm_grad_blockmax(ng_ctx* ctx, int* capacity) {
+  if (capacity) *capacity = GH_MAXBLOCKS;
+  return reinterpret_cast<float*>(small_scratch(ctx));
+}
+
+int gemm_grad_scale_from_blocks(ng_ctx* ctx, hipStream_t st, int nblocks, const float** scale_out) {
+  float* blockmax = reinterpret_cast<float*>(small_scratch(ctx));
+  if (!blockmax) return NG_ERR_NOMEM;
+  NG_REQUIRE(ctx, nblocks >= 0 && nblocks <= GH_MAXBLOCKS, "grad scale: block count");
+  float* scale = blockmax + GH_MAXBLOCKS + GH_RSBLOCKS;
+  hipLaunchKernelGGL(gh_scale_kernel, dim3(1), dim3(256), 0, st, blockmax, nblocks, nullptr, 0, scale);
+  NG_HIP(ctx, hipGetLastError());
+  *scale_out = scale;
+  return NG_OK;
+}
+
+int gemm_grad_scale(ng_ctx* ctx, hipStream_t st, const float* dY, int64_t M, int N, const float* rowscale,
+                    const float** scale_out) {
+  float* blockmax = reinterpret_cast<float*>(small_scratch(ctx));   // fixed address: callers keep *scale_out
+  if (!blockmax) return NG_ERR_NOMEM;
+  float* rsmax = blockmax + GH_MAXBLOCKS;
+  float* scale = rsmax + GH_RSBLOCKS;
+  const int64_t n4 = M * N / 4;                      // N % 4 == 0 (dense_dx / dense_dw contracts)
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(2048, cdiv(n4, 256 * 4)));
+  const int nr = rowscale ? (int)std::max<int64_t>(1, std::min<int64_t>(GH_RSBLOCKS, cdiv(M, 1024))) : 0;
+  ProfScope ps(ctx, st, "grad_scale");
+  hipLaunchKernelGGL(gh_absmax_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(dY), n4, blockmax);
+  if (rowscale) hipLaunchKernelGGL(gh_rsmax_kernel, dim3(nr), dim3(256), 0, st, rowscale, M, rsmax);
+  hipLaunchKernelGGL(gh_scale_kernel, dim3(1), dim3(256), 0, st, blockmax, nb, rsmax, nr, scale);
+  NG_HIP(ctx, hipGetLastError());
+  *scale_out = scale;
+  return NG_OK;
+}
 
 // Epilogue of one 32-row block for the kernels below: the lane holds, for ONE row m, NJ x 4 groups of 4 consecutive
 // columns (acc[j][4q..4q+3] -> column n0 + 32 j + 8 q + (0..3)).  All loads (bias, residual) are issued BEFORE the first
@@ -123,11 +230,11 @@ __device__ __forceinline__ void gx_epilogue_block(const GxArgs& a, const f32x16 
 }
 
 template <bool GRAD, int NBW>
-__global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_h2_fwd_kernel(GxArgs a) {
   constexpr int WCHUNK = gx_wchunk(NBW), BN = 64 * NBW;
   extern __shared__ __attribute__((aligned(16))) char smem_gx[];
-  char* sX = smem_gx;                       // [3][128][80 B]
-  char* sW = smem_gx + 3 * GX_XPLANE;       // [4][2][3][1 KB]
+  char* sX = smem_gx;                       // [2][128][80 B]
+  char* sW = smem_gx + 2 * GX_XPLANE;       // [2 NBW][2][2][1 KB]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nh = wave & 1, mh = wave >> 1;
@@ -142,7 +249,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
       const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / BN) * KT * WCHUNK), 0x00020000);
 
   const float* sp = GRAD && a.Sin ? a.Sin + std::min<int64_t>(m0 + xr, a.M - 1) * a.K + 16 * xh : nullptr;
-  const float rsi = GRAD && a.rs_in ? a.rs_in[std::min<int64_t>(m0 + xr, a.M - 1)] : 1.0f;
+  const float gS = GRAD && a.gscale ? a.gscale[0] : 1.0f;          // power of two (gemm_grad_scale)
+  const float oscale = GX_WINV * (GRAD && a.gscale ? a.gscale[1] : 1.0f);
+  const float rsi = gS * (GRAD && a.rs_in ? a.rs_in[std::min<int64_t>(m0 + xr, a.M - 1)] : 1.0f);
   float4 xv[4], sv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -161,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
 #pragma unroll 1
   for (int kt = 0; kt < KT; ++kt) {
     NG_LDS_BARRIER();                       // the previous step's fragment reads are done
-    // W pieces of this step: one-KB wave copies, 3 NBW per wave
+    // W pieces of this step: one-KB wave copies, 2 NBW per wave
 #pragma unroll
-    for (int c = 0; c < 3 * NBW; ++c) {
+    for (int c = 0; c < 2 * NBW; ++c) {
       const int kb = wave + 4 * c;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sW + kb * 1024), 16,
                                                lane * 16, (ct * KT + kt) * WCHUNK + kb * 1024, 0, 0);
@@ -182,16 +291,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] *= rsi;
       }
-      unsigned h[8], m[8], l[8];
+      unsigned h[8], l[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+      for (int j = 0; j < 8; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
       char* d = sX + xr * GX_XROW + 32 * xh;
       *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
       *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
-      *reinterpret_cast<u32x4*>(d + GX_XPLANE) = u32x4{m[0], m[1], m[2], m[3]};
-      *reinterpret_cast<u32x4*>(d + GX_XPLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
-      *reinterpret_cast<u32x4*>(d + 2 * GX_XPLANE) = u32x4{l[0], l[1], l[2], l[3]};
-      *reinterpret_cast<u32x4*>(d + 2 * GX_XPLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+      *reinterpret_cast<u32x4*>(d + GX_XPLANE) = u32x4{l[0], l[1], l[2], l[3]};
+      *reinterpret_cast<u32x4*>(d + GX_XPLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W copies has landed
     NG_LDS_BARRIER();
@@ -207,22 +314,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 wa[NBW][3], xb[2][3];
+      u32x4 wa[NBW][2], xb[2][2];
 #pragma unroll
       for (int j = 0; j < NBW; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          wa[j][p] = *reinterpret_cast<const u32x4*>(sW + (((NBW * nh + j) * 2 + ks) * 3 + p) * 1024 + lane * 16);
+        for (int p = 0; p < 2; ++p)
+          wa[j][p] = *reinterpret_cast<const u32x4*>(sW + (((NBW * nh + j) * 2 + ks) * 2 + p) * 1024 + lane * 16);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 2; ++p)
           xb[i][p] = *reinterpret_cast<const u32x4*>(sX + p * GX_XPLANE + (32 * (2 * mh + i) + l31) * GX_XROW +
                                                      (16 * ks + 8 * half) * 2);
 #pragma unroll
       for (int j = 0; j < NBW; j += 2)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) mma6_2a(wa[j], wa[j + 1], xb[i], acc[j][i], acc[j + 1][i]);
+        for (int i = 0; i < 2; ++i) mma3_2a(wa[j], wa[j + 1], xb[i], acc[j][i], acc[j + 1][i]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -235,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
     f32x16 blk[NBW];
 #pragma unroll
     for (int j = 0; j < NBW; ++j) blk[j] = acc[j][i];
-    gx_epilogue_block<NBW>(a, blk, m, BN * ct + 32 * NBW * nh + 4 * half, a.rowscale ? a.rowscale[m] : 1.0f);
+    gx_epilogue_block<NBW>(a, blk, m, BN * ct + 32 * NBW * nh + 4 * half, oscale * (a.rowscale ? a.rowscale[m] : 1.0f));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -250,10 +357,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwd_kernel(GxArgs a) {
 // 16-wide k-half ahead (48 MFMAs = 1.5k cycles of cover), no LDS, no DMA.  Only the X piece planes go through LDS, in a
 // two-stage ring (2 x 30 KB): ONE barrier per 32-wide k-step, X(kt+1) is split while step kt multiplies and X(kt+2)
 // is on its way from HBM.  256 threads, two workgroups per CU.
-constexpr int G4_LDS = 2 * 3 * GX_XPLANE;                 // 61,440
+constexpr int G4_LDS = 2 * 2 * GX_XPLANE;                 // 40,960
 
 template <bool GRAD>
-__global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_h2_fwdr_kernel(GxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_g4[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int nq = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,7 +374,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
   const int64_t xrow = std::min<int64_t>(m0 + xr, a.M - 1);
   const float* xp = a.X + xrow * a.K + 16 * xh;
   const float* sp = GRAD && a.Sin ? a.Sin + xrow * a.K + 16 * xh : nullptr;
-  const float rsi = GRAD && a.rs_in ? a.rs_in[xrow] : 1.0f;
+  const float gS = GRAD && a.gscale ? a.gscale[0] : 1.0f;          // power of two (gemm_grad_scale)
+  const float oscale = GX_WINV * (GRAD && a.gscale ? a.gscale[1] : 1.0f);
+  const float rsi = gS * (GRAD && a.rs_in ? a.rs_in[xrow] : 1.0f);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / 256) * KT * WCHUNK), 0x00020000);
 
@@ -295,26 +404,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] *= rsi;
     }
-    unsigned h[8], m[8], l[8];
+    unsigned h[8], l[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+    for (int j = 0; j < 8; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
     char* d = sX + xr * GX_XROW + 32 * xh;
     *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
-    *reinterpret_cast<u32x4*>(d + GX_XPLANE) = u32x4{m[0], m[1], m[2], m[3]};
-    *reinterpret_cast<u32x4*>(d + GX_XPLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
-    *reinterpret_cast<u32x4*>(d + 2 * GX_XPLANE) = u32x4{l[0], l[1], l[2], l[3]};
-    *reinterpret_cast<u32x4*>(d + 2 * GX_XPLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+    *reinterpret_cast<u32x4*>(d + GX_XPLANE) = u32x4{l[0], l[1], l[2], l[3]};
+    *reinterpret_cast<u32x4*>(d + GX_XPLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
   };
   // W^T fragments of the k-half (kt, ks) for this wave's two 32-column blocks
-  auto w_request = [&](u32x4 (&wa)[2][3], int i, int ks) {
+  auto w_request = [&](u32x4 (&wa)[2][2], int i, int ks) {
     const int ktc = kstep(i);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < 2; ++p) {
         const auto raw = __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, lane * 16, (ct * KT + ktc) * WCHUNK + (((2 * nq + j) * 2 + ks) * 3 + p) * 1024, 0);
+            wrs, lane * 16, (ct * KT + ktc) * WCHUNK + (((2 * nq + j) * 2 + ks) * 2 + p) * 1024, 0);
         wa[j][p] = __builtin_bit_cast(u32x4, raw);
       }
   };
@@ -327,18 +434,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-  auto multiply = [&](const char* sX, const u32x4 (&wa)[2][3], int ks) {
+  auto multiply = [&](const char* sX, const u32x4 (&wa)[2][2], int ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      u32x4 xb[3];
+      u32x4 xb[2];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 2; ++p)
         xb[p] = *reinterpret_cast<const u32x4*>(sX + p * GX_XPLANE + (32 * i + l31) * GX_XROW + (16 * ks + 8 * half) * 2);
-      mma6_2a(wa[0], wa[1], xb, acc[0][i], acc[1][i]);
+      mma3_2a(wa[0], wa[1], xb, acc[0][i], acc[1][i]);
     }
   };
 
-  u32x4 w0[2][3], w1[2][3];
+  u32x4 w0[2][2], w1[2][2];
   x_request(0);
   w_request(w0, 0, 0);
   x_fill(smem_g4);
@@ -346,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
   NG_LDS_BARRIER();
 #pragma unroll 1
   for (int kt = 0; kt < KT; ++kt) {
-    const char* cur = smem_g4 + (kt & 1) * (3 * GX_XPLANE);
-    char* nxt = smem_g4 + ((kt + 1) & 1) * (3 * GX_XPLANE);
+    const char* cur = smem_g4 + (kt & 1) * (2 * GX_XPLANE);
+    char* nxt = smem_g4 + ((kt + 1) & 1) * (2 * GX_XPLANE);
     w_request(w1, kt, 1);
     if (kt + 1 < KT) { x_fill(nxt); x_request(kt + 2); }
     multiply(cur, w0, 0);
@@ -361,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
   // epilogue: lane holds, for row m = m0 + 32 i + l31, columns n = 256 ct + 32 (2 nq + j) + 8 q + 4 half + (0..3)
   float rsv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rsv[i] = a.rowscale ? a.rowscale[std::min<int64_t>(m0 + 32 * i + l31, a.M - 1)] : 1.0f;
+  for (int i = 0; i < 4; ++i) rsv[i] = oscale * (a.rowscale ? a.rowscale[std::min<int64_t>(m0 + 32 * i + l31, a.M - 1)] : 1.0f);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + 32 * i + l31;
@@ -377,12 +484,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_fwdr_kernel(GxArgs a) {
 // but everything is sized for latency instead of reuse: a 12-MFMA k-half covers 0.2 us, an L2 round trip takes three
 // times that and a first touch of X more, so the fragments run THREE k-halves ahead (ring of four) and X moves in
 // 128-wide k-tiles (one barrier and one prefetch per 96 MFMAs of a wave), split into a two-stage LDS ring.
-constexpr int GS_ROW = 272;                      // bytes per row of an X piece plane: 128 bf16 + 16 (b128 rows conflict-free)
+constexpr int GS_ROW = 272;                      // bytes per row of an X piece plane: 128 fp16 + 16 (b128 rows conflict-free)
 constexpr int GS_PLANE = 32 * GS_ROW;            // 8,704
-constexpr int GS_LDS = 2 * 3 * GS_PLANE;         // 52,224
+constexpr int GS_LDS = 2 * 2 * GS_PLANE;         // 34,816
 
 template <bool GRAD>
-__global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_h2_short_kernel(GxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_gs[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int nq = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,7 +503,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
   const int64_t xrow = std::min<int64_t>(m0 + xr, a.M - 1);
   const float* xp = a.X + xrow * a.K + 16 * xc;
   const float* sp = GRAD && a.Sin ? a.Sin + xrow * a.K + 16 * xc : nullptr;
-  const float rsi = GRAD && a.rs_in ? a.rs_in[xrow] : 1.0f;
+  const float gS = GRAD && a.gscale ? a.gscale[0] : 1.0f;          // power of two (gemm_grad_scale)
+  const float oscale = GX_WINV * (GRAD && a.gscale ? a.gscale[1] : 1.0f);
+  const float rsi = gS * (GRAD && a.rs_in ? a.rs_in[xrow] : 1.0f);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)(a.N / 256) * KT * WCHUNK), 0x00020000);
 
@@ -422,27 +531,25 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] *= rsi;
     }
-    unsigned h[8], m[8], l[8];
+    unsigned h[8], l[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+    for (int j = 0; j < 8; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
     char* d = sX + xr * GS_ROW + 32 * xc;
     *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
-    *reinterpret_cast<u32x4*>(d + GS_PLANE) = u32x4{m[0], m[1], m[2], m[3]};
-    *reinterpret_cast<u32x4*>(d + GS_PLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
-    *reinterpret_cast<u32x4*>(d + 2 * GS_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
-    *reinterpret_cast<u32x4*>(d + 2 * GS_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+    *reinterpret_cast<u32x4*>(d + GS_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
+    *reinterpret_cast<u32x4*>(d + GS_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
   };
   // W^T fragments of k-half q (= 32-wide step q >> 1, half q & 1) for this wave's two 32-column blocks; requests
   // past the end re-read the last half (never multiplied)
-  auto w_request = [&](u32x4 (&wa)[2][3], int q) {
+  auto w_request = [&](u32x4 (&wa)[2][2], int q) {
     const int qc = std::min(q, 2 * KT - 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < 2; ++p) {
         const auto raw = __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, lane * 16, (ct * KT + (qc >> 1)) * WCHUNK + (((2 * nq + j) * 2 + (qc & 1)) * 3 + p) * 1024, 0);
+            wrs, lane * 16, (ct * KT + (qc >> 1)) * WCHUNK + (((2 * nq + j) * 2 + (qc & 1)) * 2 + p) * 1024, 0);
         wa[j][p] = __builtin_bit_cast(u32x4, raw);
       }
   };
@@ -453,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  u32x4 w[4][2][3];
+  u32x4 w[4][2][2];
   x_request(0);
   w_request(w[0], 0); w_request(w[1], 1); w_request(w[2], 2);
   x_fill(smem_gs);
@@ -461,17 +568,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
   NG_LDS_BARRIER();
 #pragma unroll 1
   for (int t = 0; t < NT; ++t) {
-    const char* cur = smem_gs + (t & 1) * (3 * GS_PLANE);
-    char* nxt = smem_gs + ((t + 1) & 1) * (3 * GS_PLANE);
+    const char* cur = smem_gs + (t & 1) * (2 * GS_PLANE);
+    char* nxt = smem_gs + ((t + 1) & 1) * (2 * GS_PLANE);
 #pragma unroll
     for (int hh = 0; hh < 8; ++hh) {
       w_request(w[(hh + 3) & 3], 8 * t + hh + 3);
       if (hh == 0 && t + 1 < NT) { x_fill(nxt); x_request(t + 2); }
-      u32x4 xb[3];
+      u32x4 xb[2];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 2; ++p)
         xb[p] = *reinterpret_cast<const u32x4*>(cur + p * GS_PLANE + l31 * GS_ROW + (16 * hh + 8 * half) * 2);
-      mma6_2a(w[hh & 3][0], w[hh & 3][1], xb, acc[0], acc[1]);
+      mma3_2a(w[hh & 3][0], w[hh & 3][1], xb, acc[0], acc[1]);
       __builtin_amdgcn_sched_barrier(0);
     }
     NG_LDS_BARRIER();
@@ -479,22 +586,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_short_kernel(GxArgs a) {
 
   // epilogue: lane holds, for row m = m0 + l31, columns n = 256 ct + 32 (2 nq + j) + 8 q + 4 half + (0..3)
   const int64_t m = m0 + l31;
-  if (m < a.M) gx_epilogue_block<2>(a, acc, m, 256 * ct + 64 * nq + 4 * half, a.rowscale ? a.rowscale[m] : 1.0f);
+  if (m < a.M) gx_epilogue_block<2>(a, acc, m, 256 * ct + 64 * nq + 4 * half, oscale * (a.rowscale ? a.rowscale[m] : 1.0f));
 }
 
 // the short kernel: N % 256 (its column tiling), K % 128 (its k-tiles)
 static bool gx_short_ok(int K, int N) { return N % 256 == 0 && K % 128 == 0 && !sw().gemm_4wave; }
 
-bool gemm_x3_fwd_ok(int64_t M, int K, int N) {
+bool gemm_h2_fwd_ok(int64_t M, int K, int N) {
   if (sw().gemm_math_fp32) return false;
   const bool tall = M >= 4096, short_op = M >= 256 && gx_short_ok(K, N);
-  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && (tall || short_op) && (int64_t)N * K * 6 < ((int64_t)1 << 31);
+  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && (tall || short_op) && (int64_t)N * K * 4 < ((int64_t)1 << 31);
 }
 
 static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int trans, bool grad, const char* tag) {
   const int nbw = a.N % 256 == 0 ? 4 : 2;          // 256-column tiles when N allows
   const int BN = 64 * nbw;
-  const size_t img_bytes = (size_t)a.N * a.K * 6;  // three bf16 pieces per weight
+  const size_t img_bytes = (size_t)a.N * a.K * 4;  // two fp16 pieces per weight
   bool have = false;
   char* img = (char*)cached_image(ctx, W, 3 + 16 * trans + 32 * nbw, img_bytes, &have);
   if (!img) img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
@@ -511,23 +618,23 @@ static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int
   if (gx_short_ok(a.K, a.N) && cdiv(a.M, GX_BM) * (a.N / BN) * 2 <= ctx->num_cu) {
     // fewer 128-row tiles than half the CUs
     const dim3 grid1((unsigned)cdiv(a.M, 32), (unsigned)(a.N / 256));
-    if (grad) hipLaunchKernelGGL((gemm_x3_short_kernel<true>), grid1, dim3(256), GS_LDS, st, a);
-    else hipLaunchKernelGGL((gemm_x3_short_kernel<false>), grid1, dim3(256), GS_LDS, st, a);
+    if (grad) hipLaunchKernelGGL((gemm_h2_short_kernel<true>), grid1, dim3(256), GS_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_h2_short_kernel<false>), grid1, dim3(256), GS_LDS, st, a);
   } else if (nbw == 4 && !sw().gemm_4wave) {
-    if (grad) hipLaunchKernelGGL((gemm_x3_fwdr_kernel<true>), grid, dim3(256), G4_LDS, st, a);
-    else hipLaunchKernelGGL((gemm_x3_fwdr_kernel<false>), grid, dim3(256), G4_LDS, st, a);
+    if (grad) hipLaunchKernelGGL((gemm_h2_fwdr_kernel<true>), grid, dim3(256), G4_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_h2_fwdr_kernel<false>), grid, dim3(256), G4_LDS, st, a);
   } else if (nbw == 4) {
-    if (grad) hipLaunchKernelGGL((gemm_x3_fwd_kernel<true, 4>), grid, dim3(256), gx_lds(4), st, a);
-    else hipLaunchKernelGGL((gemm_x3_fwd_kernel<false, 4>), grid, dim3(256), gx_lds(4), st, a);
+    if (grad) hipLaunchKernelGGL((gemm_h2_fwd_kernel<true, 4>), grid, dim3(256), gx_lds(4), st, a);
+    else hipLaunchKernelGGL((gemm_h2_fwd_kernel<false, 4>), grid, dim3(256), gx_lds(4), st, a);
   } else {
-    if (grad) hipLaunchKernelGGL((gemm_x3_fwd_kernel<true, 2>), grid, dim3(256), gx_lds(2), st, a);
-    else hipLaunchKernelGGL((gemm_x3_fwd_kernel<false, 2>), grid, dim3(256), gx_lds(2), st, a);
+    if (grad) hipLaunchKernelGGL((gemm_h2_fwd_kernel<true, 2>), grid, dim3(256), gx_lds(2), st, a);
+    else hipLaunchKernelGGL((gemm_h2_fwd_kernel<false, 2>), grid, dim3(256), gx_lds(2), st, a);
   }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
 
-int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
+int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag) {
   GxArgs a{};
   a.M = M; a.K = K; a.N = N; a.X = X; a.bias = b; a.rowscale = rowscale; a.R = R; a.Y = Y; a.S = S; a.act = act;
@@ -536,17 +643,22 @@ int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, c
 
 // dX[m][k] = (add ? add[m][k] : 0) + sum_n dP[m][n] W[k][n],  dP = dY * act'(S) * rowscale   (dense_dx's contract);
 // here the contraction runs over Nout and the output has Kin columns
-int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
-               const float* rowscale, const float* W, const float* add, float* dX, const char* tag) {
+int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
+               const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag) {
   GxArgs a{};
   a.M = M; a.K = Nout; a.N = Kin; a.X = dY; a.R = add; a.Y = dX; a.act = NG_ACT_NONE;
   a.Sin = act == NG_ACT_NONE ? nullptr : S; a.rs_in = rowscale; a.act_in = act;
+  if (!gscale) {
+    int rc = gemm_grad_scale(ctx, st, dY, M, Nout, rowscale, &gscale);
+    if (rc) return rc;
+  }
+  a.gscale = gscale;
   return gx_launch(ctx, st, a, W, 1, true, tag);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // dW[k][n] = sum_m X[m][k] dP[m][n]   (dP = dY * act'(S) * rowscale), the contraction runs over the ROWS of both
-// operands: both live in LDS as bf16 piece images [32 rows][128 + 8] and are read as COLUMNS with ds_read_b64_tr_b16
+// operands: both live in LDS as fp16 piece images [32 rows][128 + 8] and are read as COLUMNS with ds_read_b64_tr_b16
 // (rows stored permuted so that the four rows of a read sit 16 banks apart — see edge_bwd_x3.hip).  256 threads, output
 // tile 128 (k) x 128 (n), 32 rows per step, the rows split over blockIdx.z into partials [z][K][N] that the caller
 // reduces (dense_dw).  MFMA: A = dP columns (rows n of D), B = X columns (columns k of D): a lane ends with 4
@@ -554,7 +666,7 @@ int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int ac
 typedef short gx_s16x4 __attribute__((ext_vector_type(4)));
 constexpr int GT_ROWB = 272;                    // image row stride (bytes)
 constexpr int GT_PLANE = 32 * GT_ROWB;          // 8,704
-constexpr int GT_LDS = 2 * 3 * GT_PLANE;        // 52,224
+constexpr int GT_LDS = 2 * 2 * GT_PLANE;        // 34,816
 
 struct GtArgs {
   int64_t M, rows_per_z;
@@ -565,6 +677,7 @@ struct GtArgs {
   const float* rowscale;   // may be nullptr
   int act;
   float* partial;          // [nz][K][N]
+  const float* gscale;     // {S, 1/S} of dP (device memory)
 };
 
 __device__ __forceinline__ u32x4 gt_tr_frag(const char* p) {
@@ -575,22 +688,20 @@ __device__ __forceinline__ u32x4 gt_tr_frag(const char* p) {
 }
 
 __device__ __forceinline__ void gt_store16(char* img, int prow, int col0, const float (&v)[16]) {
-  unsigned h[8], m[8], l[8];
+  unsigned h[8], l[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+  for (int j = 0; j < 8; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
   char* d = img + prow * GT_ROWB + col0 * 2;
   *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
   *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
-  *reinterpret_cast<u32x4*>(d + GT_PLANE) = u32x4{m[0], m[1], m[2], m[3]};
-  *reinterpret_cast<u32x4*>(d + GT_PLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
-  *reinterpret_cast<u32x4*>(d + 2 * GT_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
-  *reinterpret_cast<u32x4*>(d + 2 * GT_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+  *reinterpret_cast<u32x4*>(d + GT_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
+  *reinterpret_cast<u32x4*>(d + GT_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_h2_dw_kernel(GtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_gt[];
-  char* sXi = smem_gt;                    // X image  [3][32][272 B]
-  char* sPi = smem_gt + 3 * GT_PLANE;     // dP image
+  char* sXi = smem_gt;                    // X image  [2][32][272 B]
+  char* sPi = smem_gt + 2 * GT_PLANE;     // dP image
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nh = wave & 1, kh = wave >> 1;
@@ -598,6 +709,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
   const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_z;
   const int64_t r1 = std::min<int64_t>(r0 + a.rows_per_z, a.M);
 
+  const float gS = a.gscale[0], gI = a.gscale[1];       // dP is split as S * dP, the partial is written as acc / S
   // loader: thread -> row tid >> 3 of the 32-row step, 16 columns at 16 (tid & 7)
   const int lr = tid >> 3, lc = 16 * (tid & 7);
   const int e16 = lr & 15;
@@ -608,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
     const int64_t rc = ok ? row : a.M - 1;
     const float* xp = a.X + rc * a.K + k0 + lc;
     const float* dp = a.dY + rc * a.N + n0 + lc;
-    const float rs = ok ? (a.rowscale ? a.rowscale[rc] : 1.0f) : 0.0f;     // rows past the end contribute zero
+    const float rs = ok ? gS * (a.rowscale ? a.rowscale[rc] : 1.0f) : 0.0f;     // rows past the end contribute zero
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 x = *reinterpret_cast<const float4*>(xp + 4 * i);
@@ -645,16 +757,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
     load(rb + 32 + lr);                   // next step (rows past r1 load row M-1 and are zeroed)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 pa[2][3], xb[2][3];
+      u32x4 pa[2][2], xb[2][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < 2; ++p) {
           pa[j][p] = gt_tr_frag(sPi + p * GT_PLANE + 16 * ks * GT_ROWB + lane_off + 64 * (2 * nh + j));
           xb[j][p] = gt_tr_frag(sXi + p * GT_PLANE + 16 * ks * GT_ROWB + lane_off + 64 * (2 * kh + j));
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) mma6_2a(pa[0], pa[1], xb[i], acc[0][i], acc[1][i]);
+      for (int i = 0; i < 2; ++i) mma3_2a(pa[0], pa[1], xb[i], acc[0][i], acc[1][i]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -669,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + 32 * (2 * nh + j) + 8 * q + 4 * half;
         *reinterpret_cast<float4*>(part + (int64_t)k * a.N + n) =
-            make_float4(acc[j][i][4 * q + 0], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+            make_float4(gI * acc[j][i][4 * q + 0], gI * acc[j][i][4 * q + 1], gI * acc[j][i][4 * q + 2], gI * acc[j][i][4 * q + 3]);
       }
   }
 }
@@ -679,9 +791,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_dw_kernel(GtArgs a) {
 // CU.  Same images / transposing reads as above at twice the tile edge: per 32-row step a wave issues 96 MFMAs for the
 // same 32 values split and 2 barriers (the 128 x 128 kernel: 48), and every operand row is read by half as many
 // workgroups (the aggregate A [N, 768] of the MPLayer weight gradient once instead of twice, dP 3 x instead of 6 x).
-constexpr int GT8_ROWB = 528;                    // image row stride (bytes): 256 bf16 + 16, 132 dwords = 4 mod 64 banks
+constexpr int GT8_ROWB = 528;                    // image row stride (bytes): 256 fp16 + 16, 132 dwords = 4 mod 64 banks
 constexpr int GT8_PLANE = 32 * GT8_ROWB;         // 16,896
-constexpr int GT8_LDS = 2 * 3 * GT8_PLANE;       // 101,376
+constexpr int GT8_LDS = 2 * 2 * GT8_PLANE;       // 67,584
 
 __device__ __forceinline__ u32x4 gt8_tr_frag(const char* p) {
   const gx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gx_s16x4*)p);
@@ -691,22 +803,20 @@ __device__ __forceinline__ u32x4 gt8_tr_frag(const char* p) {
 }
 
 __device__ __forceinline__ void gt8_store16(char* img, int prow, int col0, const float (&v)[16]) {
-  unsigned h[8], m[8], l[8];
+  unsigned h[8], l[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) split3_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+  for (int j = 0; j < 8; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
   char* d = img + prow * GT8_ROWB + col0 * 2;
   *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
   *reinterpret_cast<u32x4*>(d + 16) = u32x4{h[4], h[5], h[6], h[7]};
-  *reinterpret_cast<u32x4*>(d + GT8_PLANE) = u32x4{m[0], m[1], m[2], m[3]};
-  *reinterpret_cast<u32x4*>(d + GT8_PLANE + 16) = u32x4{m[4], m[5], m[6], m[7]};
-  *reinterpret_cast<u32x4*>(d + 2 * GT8_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
-  *reinterpret_cast<u32x4*>(d + 2 * GT8_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
+  *reinterpret_cast<u32x4*>(d + GT8_PLANE) = u32x4{l[0], l[1], l[2], l[3]};
+  *reinterpret_cast<u32x4*>(d + GT8_PLANE + 16) = u32x4{l[4], l[5], l[6], l[7]};
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_x3_dw8_kernel(GtArgs a) {
+__global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_gt8[];
-  char* sXi = smem_gt8;                    // X image  [3][32][528 B]
-  char* sPi = smem_gt8 + 3 * GT8_PLANE;    // dP image
+  char* sXi = smem_gt8;                    // X image  [2][32][528 B]
+  char* sPi = smem_gt8 + 2 * GT8_PLANE;    // dP image
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nh = wave & 1, kh = wave >> 1;           // n-blocks 4 nh .. 4 nh + 3, k-blocks 2 kh, 2 kh + 1
@@ -714,6 +824,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_dw8_kernel(GtArgs a) {
   const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_z;
   const int64_t r1 = std::min<int64_t>(r0 + a.rows_per_z, a.M);
 
+  const float gS = a.gscale[0], gI = a.gscale[1];       // dP is split as S * dP, the partial is written as acc / S
   // loader: thread -> row tid >> 4 of the 32-row step, 16 columns at 16 (tid & 15)
   const int lr = tid >> 4, lc = 16 * (tid & 15);
   const int e16 = lr & 15;
@@ -724,7 +835,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_dw8_kernel(GtArgs a) {
     const int64_t rc = ok ? row : a.M - 1;
     const float* xp = a.X + rc * a.K + k0 + lc;
     const float* dp = a.dY + rc * a.N + n0 + lc;
-    const float rs = ok ? (a.rowscale ? a.rowscale[rc] : 1.0f) : 0.0f;     // rows past the end contribute zero
+    const float rs = ok ? gS * (a.rowscale ? a.rowscale[rc] : 1.0f) : 0.0f;     // rows past the end contribute zero
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 x = *reinterpret_cast<const float4*>(xp + 4 * i);
@@ -760,20 +871,20 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_dw8_kernel(GtArgs a) {
     load(rb + 32 + lr);                   // next step (rows past r1 load row M-1 and are zeroed)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 pa[4][3];
+      u32x4 pa[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 2; ++p)
           pa[j][p] = gt8_tr_frag(sPi + p * GT8_PLANE + 16 * ks * GT8_ROWB + lane_off + 64 * (4 * nh + j));
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        u32x4 xb[3];
+        u32x4 xb[2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 2; ++p)
           xb[p] = gt8_tr_frag(sXi + p * GT8_PLANE + 16 * ks * GT8_ROWB + lane_off + 64 * (2 * kh + i));
-        mma6_2a(pa[0], pa[1], xb, acc[0][i], acc[1][i]);
-        mma6_2a(pa[2], pa[3], xb, acc[2][i], acc[3][i]);
+        mma3_2a(pa[0], pa[1], xb, acc[0][i], acc[1][i]);
+        mma3_2a(pa[2], pa[3], xb, acc[2][i], acc[3][i]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -789,32 +900,38 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_dw8_kernel(GtArgs a) {
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + 32 * (4 * nh + j) + 8 * q + 4 * half;
         *reinterpret_cast<float4*>(part + (int64_t)k * a.N + n) =
-            make_float4(acc[j][i][4 * q + 0], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+            make_float4(gI * acc[j][i][4 * q + 0], gI * acc[j][i][4 * q + 1], gI * acc[j][i][4 * q + 2], gI * acc[j][i][4 * q + 3]);
       }
   }
 }
 
-bool gemm_x3_dw8_ok(int64_t M, int Kin, int Nout) {
+bool gemm_h2_dw8_ok(int64_t M, int Kin, int Nout) {
   return !sw().gemm_math_fp32 && !sw().gemm_4wave && Kin % 256 == 0 && Nout % 256 == 0 && M >= 4096;
 }
 
-bool gemm_x3_dw_ok(int64_t M, int Kin, int Nout) {
+bool gemm_h2_dw_ok(int64_t M, int Kin, int Nout) {
   if (sw().gemm_math_fp32) return false;
   return Kin % 128 == 0 && Nout % 128 == 0 && M >= 4096;
 }
 
 // partial[z][Kin][Nout], z < nz, rows [z * rows_per_z, ...): same partial layout as the f32-input dense_dw GEMM
-int gemm_x3_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
-               const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const char* tag) {
+int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
+               const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const float* gscale,
+               const char* tag) {
+  if (!gscale) {
+    int rc = gemm_grad_scale(ctx, st, dY, M, Nout, rowscale, &gscale);
+    if (rc) return rc;
+  }
   GtArgs a;
+  a.gscale = gscale;
   a.M = M; a.rows_per_z = rows_per_z; a.K = Kin; a.N = Nout; a.X = X; a.dY = dY; a.S = S; a.rowscale = rowscale;
   a.act = act; a.partial = partial;
   ProfScope ps(ctx, st, tag);
-  if (gemm_x3_dw8_ok(M, Kin, Nout))
-    hipLaunchKernelGGL(gemm_x3_dw8_kernel, dim3((unsigned)(Kin / 256), (unsigned)(Nout / 256), (unsigned)nz), dim3(512),
+  if (gemm_h2_dw8_ok(M, Kin, Nout))
+    hipLaunchKernelGGL(gemm_h2_dw8_kernel, dim3((unsigned)(Kin / 256), (unsigned)(Nout / 256), (unsigned)nz), dim3(512),
                        GT8_LDS, st, a);
   else
-    hipLaunchKernelGGL(gemm_x3_dw_kernel, dim3((unsigned)(Kin / 128), (unsigned)(Nout / 128), (unsigned)nz), dim3(256), GT_LDS,
+    hipLaunchKernelGGL(gemm_h2_dw_kernel, dim3((unsigned)(Kin / 128), (unsigned)(Nout / 128), (unsigned)nz), dim3(256), GT_LDS,
                        st, a);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;

@@ -128,7 +128,7 @@ int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act
               float* S, const char* tag) {
   NG_REQUIRE(ctx, Kin % 8 == 0 && Nout % 4 == 0, "dense_fwd: Kin%8, Nout%4");
   if (M == 0) return NG_OK;
-  if (gemm_x3_fwd_ok(M, Kin, Nout)) return gemm_x3_fwd(ctx, st, M, Kin, Nout, act, X, W, b, rowscale, R, Y, S, tag);
+  if (gemm_h2_fwd_ok(M, Kin, Nout)) return gemm_h2_fwd(ctx, st, M, Kin, Nout, act, X, W, b, rowscale, R, Y, S, tag);
   ProfScope ps(ctx, st, tag);
   LoadPlain lq{X, M, Kin, Kin};
   LoadPlain lp{W, Kin, Nout, Nout};
@@ -146,10 +146,10 @@ int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act
 
 int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY,
              const float* S, const float* rowscale, const float* W, const float* add, float* dX,
-             const char* tag) {
+             const char* tag, const float* gscale) {
   NG_REQUIRE(ctx, Nout % 8 == 0 && Kin % 4 == 0, "dense_dx: Nout%8, Kin%4");
   if (M == 0) return NG_OK;
-  if (gemm_x3_fwd_ok(M, Nout, Kin)) return gemm_x3_dx(ctx, st, M, Kin, Nout, act, dY, S, rowscale, W, add, dX, tag);
+  if (gemm_h2_fwd_ok(M, Nout, Kin)) return gemm_h2_dx(ctx, st, M, Kin, Nout, act, dY, S, rowscale, W, add, dX, gscale, tag);
   ProfScope ps(ctx, st, tag);
   LoadGradAct lq{dY, act == NG_ACT_NONE ? nullptr : S, rowscale, M, Nout, act};
   LoadPlain lp{W, Kin, Nout, Nout};  // [k_out][n]: K-contiguous along the contraction n
@@ -162,6 +162,10 @@ int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   return NG_OK;
 }
 
+bool dense_grad_uses_h2(int64_t M, int Kin, int Nout) {
+  return M > 0 && gemm_h2_fwd_ok(M, Nout, Kin) && gemm_h2_dw_ok(M, Kin, Nout);
+}
+
 struct DwPlan {
   int64_t nz, k_chunk, cs_blocks, cs_rows;
   bool big_n;
@@ -170,7 +174,7 @@ struct DwPlan {
 static DwPlan dw_plan(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
   DwPlan p;
   p.big_n = Nout > 64;
-  const bool t256 = gemm_x3_dw8_ok(M, Kin, Nout);       // 256 x 256 tiles, one workgroup per CU
+  const bool t256 = gemm_h2_dw8_ok(M, Kin, Nout);       // 256 x 256 tiles, one workgroup per CU
   const int BMo = t256 ? 256 : 128, BNo = t256 ? 256 : (p.big_n ? 128 : 64);
   const int64_t tiles = cdiv(Kin, BMo) * cdiv(Nout, BNo);
   // split the contraction (rows) so that ~2 workgroups per CU (one for the 256-tiles) are in flight
@@ -191,7 +195,7 @@ size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool h
 
 int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
              const float* dY, const float* S, const float* rowscale, float* dW, float* db,
-             int w_map, int F, int E, float* scratch, const char* tag) {
+             int w_map, int F, int E, float* scratch, const char* tag, const float* gscale) {
   if (act == NG_ACT_NONE) S = nullptr;
   NG_REQUIRE(ctx, Kin % 4 == 0 && Nout % 4 == 0, "dense_dw: Kin%4, Nout%4");
   const int64_t n_elem = (int64_t)Kin * Nout;
@@ -203,8 +207,8 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   const DwPlan p = dw_plan(ctx, M, Kin, Nout, db != nullptr);
   float* partial = scratch;
   float* cs_partial = scratch + p.nz * n_elem;
-  if (gemm_x3_dw_ok(M, Kin, Nout)) {
-    int rc = gemm_x3_dw(ctx, st, M, Kin, Nout, act, X, dY, S, rowscale, partial, (int)p.nz, p.k_chunk, tag);
+  if (gemm_h2_dw_ok(M, Kin, Nout)) {
+    int rc = gemm_h2_dw(ctx, st, M, Kin, Nout, act, X, dY, S, rowscale, partial, (int)p.nz, p.k_chunk, gscale, tag);
     if (rc) return rc;
   } else {
     ProfScope ps(ctx, st, tag);

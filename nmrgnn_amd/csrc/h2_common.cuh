@@ -4,7 +4,7 @@
 // product a*b is taken as  al*bh + ah*bl + ah*bh  (smallest first), every piece product exact in the fp32 accumulator
 // of v_mfma_f32_32x32x16_f16 (11 x 11 significand bits).  Dropped: al*bl <= 2^-22 |a||b| and the residuals — the size
 // of an fp32 rounding of the product.  Three matrix instructions per fp32 multiply instead of the six of the exact
-// three-piece bf16 split (x3_common.cuh), and a two-instruction residual (v_fma_mix_f32 + v_cvt_pk_f16_f32).
+// three-piece bf16 split (x3_common.cuh), and a shorter residual (one conversion back, one subtraction, one v_cvt_pk_f16_f32 instead of two of each).
 // Range: fp16 pieces need |x| < 65504 (activations: unscaled; gradients: scaled by a power of two per launch, see
 // edge_bwd_h2.hip); below 2^-14 the l piece is a subnormal the matrix pipe honours (tools/ubench/mfma_f16.hip), so the
 // absolute representation error never exceeds max(2^-25, 2^-22 |x|).
@@ -27,8 +27,7 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
 __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
   h = cvt_pk_f16(x0, x1);
   const f16x2_cvt hv = __builtin_bit_cast(f16x2_cvt, h);
-  const float r0 = __builtin_fmaf((float)hv[0], -1.0f, x0);     // v_fma_mix_f32: conversion inside the fma, exact result
-  const float r1 = __builtin_fmaf((float)hv[1], -1.0f, x1);
+  const float r0 = x0 - (float)hv[0], r1 = x1 - (float)hv[1];     // exact (v_cvt_f32_f16 x2 + v_pk_add_f32)
   l = cvt_pk_f16(r0, r1);
 }
 

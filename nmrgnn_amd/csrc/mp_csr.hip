@@ -6,7 +6,7 @@
 // atom,  dist[p] = distance;  edge features e[nnz][E] come from ng_edge_mlp_fwd on the flat dist array.
 //
 //   forward    A[i][n][:]  = sum_{p in row i} e[p][n] * h[col[p]][:]           (gather, this file)
-//              h'          = act(v * A Wp) (+ h)                               (GEMM, gemm_ops / gemm_x3)
+//              h'          = act(v * A Wp) (+ h)                               (GEMM, gemm_ops / gemm_h2)
 //   backward   dP = dH*act'(S)*v ; dw = A^T dP ; dA = dP Wp^T                  (GEMMs)
 //              de[p][n]   (+)= <dA[row(p)][n][:], h[col[p]][:]>                (gather-dot, this file)
 //              dh[t][:]    = dH[t][:] + sum_{q in csc[t]} sum_n e[p_q][n] dA[row(p_q)][n][:]   (pull scatter, this file)
@@ -20,6 +20,7 @@
 
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
+#include "reduce.cuh"
 
 namespace ng {
 
@@ -394,10 +395,13 @@ int csr_scatter_pull(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
 
 // dP[i][m] = dH[i][m] * act'(S[i][m]) * v[i]   (SURVEY App. B), formed ONCE per layer: the dA GEMM, the three k-tiles of
 // the dw GEMM and (before) their loaders each recomputed it from dH and S — a third of the dw GEMM's 1.2 GB of reads
-__global__ void mp_dp_kernel(int64_t N, int F, int act, const float* __restrict__ dH, const float* __restrict__ S,
-                             const float* __restrict__ v, float* __restrict__ dP) {
+// blockmax (optional): max |dP| per block, the input of the fp16 GEMMs' power-of-two gradient scale (gemm_h2.hip)
+__global__ __launch_bounds__(256) void mp_dp_kernel(int64_t N, int F, int act, const float* __restrict__ dH,
+                                                    const float* __restrict__ S, const float* __restrict__ v,
+                                                    float* __restrict__ dP, float* __restrict__ blockmax) {
   const int c4n = F / 4;
   const int64_t total = N * c4n;
+  float amax = 0.f;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / c4n;
     float4 d = reinterpret_cast<const float4*>(dH)[t];
@@ -409,7 +413,9 @@ __global__ void mp_dp_kernel(int64_t N, int F, int act, const float* __restrict_
     const float r = v[i];
     d.x *= r; d.y *= r; d.z *= r; d.w *= r;
     reinterpret_cast<float4*>(dP)[t] = d;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
   }
+  if (blockmax) block_max_store(amax, blockmax);
 }
 
 // generic MPLayer forward over (row_ptr | K) lists: repack w, aggregate, GEMM with the epilogue of layers.py:42 + model.py:167
@@ -452,16 +458,26 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
     if (rc) return rc;
     A_save = Ar;
   }
+  // the same dP feeds both products; its power-of-two scale (gemm_h2.hip) comes from block maxima the dP kernel
+  // writes on the side — no extra pass over the tensor
+  const float* gsc = nullptr;
   if (N > 0) {
     ProfScope ps(ctx, st, "mp_dP");
     const int64_t work = N * (F / 4);
-    hipLaunchKernelGGL(mp_dp_kernel, dim3((unsigned)std::min<int64_t>(cdiv(work, 256), 256 * 16)), dim3(256), 0, st, N, F,
-                       act, dh_out, act == NG_ACT_NONE ? nullptr : s_save, inv_degree, dP);
+    int cap = 0;
+    float* bmax = dense_grad_uses_h2(N, (int)KF, F) ? gemm_grad_blockmax(ctx, &cap) : nullptr;
+    const int nblk = (int)std::min<int64_t>(cdiv(work, 256), 256 * 16);
+    hipLaunchKernelGGL(mp_dp_kernel, dim3((unsigned)nblk), dim3(256), 0, st, N, F, act, dh_out,
+                       act == NG_ACT_NONE ? nullptr : s_save, inv_degree, dP, bmax);
     NG_HIP(ctx, hipGetLastError());
+    if (bmax) {
+      rc = gemm_grad_scale_from_blocks(ctx, st, nblk, &gsc);
+      if (rc) return rc;
+    }
   }
-  rc = dense_dw(ctx, st, N, (int)KF, F, NG_ACT_NONE, A_save, dP, nullptr, nullptr, dw, nullptr, 1, F, E, scr, "mp_dw");
+  rc = dense_dw(ctx, st, N, (int)KF, F, NG_ACT_NONE, A_save, dP, nullptr, nullptr, dw, nullptr, 1, F, E, scr, "mp_dw", gsc);
   if (rc) return rc;
-  rc = dense_dx(ctx, st, N, (int)KF, F, NG_ACT_NONE, dP, nullptr, nullptr, Wp, nullptr, dA, "mp_dA");
+  rc = dense_dx(ctx, st, N, (int)KF, F, NG_ACT_NONE, dP, nullptr, nullptr, Wp, nullptr, dA, "mp_dA", gsc);
   if (rc) return rc;
   rc = csr_edge_grad(ctx, st, N, K, F, E, h, row_ptr, col, dA, de, de_accum);
   if (rc) return rc;

@@ -25,6 +25,8 @@ struct ng_ctx {
   // second, independent scratch for leaf kernels whose callers already hold pointers into `ws`
   void* aux = nullptr;
   size_t aux_bytes = 0;
+  // NG_SMALL_BYTES that never move (device scalars handed from one launch to later ones: gradient scales of the fp16 GEMMs)
+  void* small = nullptr;
   // optional per-kernel hipEvent bracketing
   bool prof = false;
   std::vector<ng_prof_rec> recs;
@@ -97,6 +99,8 @@ inline int fail(ng_ctx* ctx, int code, const std::string& msg) {
 // scratch: returns nullptr on failure (error string set)
 void* workspace(ng_ctx* ctx, size_t bytes);
 void* aux_workspace(ng_ctx* ctx, size_t bytes);
+constexpr size_t NG_SMALL_BYTES = 64 * 1024;
+void* small_scratch(ng_ctx* ctx);      // NG_SMALL_BYTES, allocated once per context, address stable until ng_ctx_destroy
 // Frozen-weight image cache.  Returns nullptr when the cache is off (pack into scratch as before); otherwise a
 // persistent buffer of `bytes` for (src, kind) with *valid = true when it already holds the image of the current
 // weights (skip the pack launch).  kinds: 1 MPLayer Wp, 2 edge x3 image, 3 GEMM x3 image, 4 window fragments, 5 FC fragments

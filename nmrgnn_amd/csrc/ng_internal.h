@@ -11,24 +11,36 @@ int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act
 // dX[m][k] = (add ? add[m][k] : 0) + sum_n dP[m][n] W[k][n];  dP = dY * act'(S) * rowscale
 int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY,
              const float* S, const float* rowscale, const float* W, const float* add, float* dX,
-             const char* tag = "dense_dx");
+             const char* tag = "dense_dx", const float* gscale = nullptr);
 // dW[k][n] = sum_m X[m][k] dP[m][n]  (+ db[n] = sum_m dP[m][n] when db != nullptr)
 // w_map = 0: dW stored [Kin][Nout];  w_map = 1: MPLayer layout, k = n_e*F + l -> dw[l][m][n_e]
 int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
              const float* dY, const float* S, const float* rowscale, float* dW, float* db,
-             int w_map, int F, int E, float* scratch, const char* tag = "dense_dw");
+             int w_map, int F, int E, float* scratch, const char* tag = "dense_dw", const float* gscale = nullptr);
 size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db);
 
-// split-operand forward GEMM on the bf16 matrix pipe (gemm_x3.hip); same contract as dense_fwd
-bool gemm_x3_fwd_ok(int64_t M, int K, int N);
-int gemm_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
+// split-operand GEMMs on the fp16 matrix pipe (gemm_h2.hip: two fp16 pieces per fp32 operand); same contracts as
+// dense_fwd / dense_dx / dense_dw.  Gradient operands are split as S * dP with a power of two S (gemm_grad_scale: one
+// pass over dY); gscale = nullptr makes the call compute it, callers that feed the same dP to dx and dw compute it once.
+bool gemm_h2_fwd_ok(int64_t M, int K, int N);
+int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag);
-bool gemm_x3_dw_ok(int64_t M, int Kin, int Nout);
-bool gemm_x3_dw8_ok(int64_t M, int Kin, int Nout);      // 256 x 256 output tiles, one 8-wave workgroup per CU
-int gemm_x3_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
-               const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const char* tag);
-int gemm_x3_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
-               const float* rowscale, const float* W, const float* add, float* dX, const char* tag);
+bool gemm_h2_dw_ok(int64_t M, int Kin, int Nout);
+bool gemm_h2_dw8_ok(int64_t M, int Kin, int Nout);      // 256 x 256 output tiles, one 8-wave workgroup per CU
+int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
+               const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const float* gscale,
+               const char* tag);
+int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
+               const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag);
+// {S, 1/S} for the gradient tensor dY [M][N] (and its row scale); *scale_out stays valid until the next call
+int gemm_grad_scale(ng_ctx* ctx, hipStream_t st, const float* dY, int64_t M, int N, const float* rowscale,
+                    const float** scale_out);
+// for kernels that PRODUCE a gradient tensor: write max|dP| of every block to blockmax[blockIdx.x] (<= capacity blocks,
+// reduce.cuh: block_max_store), then gemm_grad_scale_from_blocks — no extra pass over the tensor
+float* gemm_grad_blockmax(ng_ctx* ctx, int* capacity);
+int gemm_grad_scale_from_blocks(ng_ctx* ctx, hipStream_t st, int nblocks, const float** scale_out);
+// true when dense_dx / dense_dw of this shape run on gemm_h2 (i.e. a shared gscale is worth computing)
+bool dense_grad_uses_h2(int64_t M, int Kin, int Nout);
 
 // fused persistent edge path (edge_fused.hip), edge_hidden_size == 128, edge_fc_layers == 4
 bool edge_fused_supported(int H, int E, int Le);

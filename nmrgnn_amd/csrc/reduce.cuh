@@ -7,6 +7,16 @@
 
 namespace ng {
 
+// blockmax[blockIdx.x] = max over the 256-thread block of m (m >= 0).  max is exact and order-free.
+__device__ __forceinline__ void block_max_store(float m, float* __restrict__ blockmax) {
+  __shared__ float bm_red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) bm_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(bm_red[0], bm_red[1]), fmaxf(bm_red[2], bm_red[3]));
+}
+
 // out[map(idx)] = sum_z partial[z][idx].   One 1024-thread block per 64 consecutive elements; the
 // 16 waves split z, so every lane has nz/16 independent, fully coalesced loads in flight (the
 // one-thread-per-element form was latency-bound: 60-120 us for a 12K-element gradient).

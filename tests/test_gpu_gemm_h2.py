@@ -1,4 +1,5 @@
-"""ng_dense_fwd on the split-operand tile GEMM (gemm_x3.hip; shapes K % 32 == 0, N % 128 == 0, M >= 4096) against float64
+"""ng_dense_fwd / ng_dense_bwd on the split-operand tile GEMMs (gemm_h2.hip: two fp16 pieces per fp32 operand, three
+piece products; shapes K % 32 == 0, N % 128 == 0, M >= 4096) against float64
 and against the f32-input MFMA GEMM (NG_GEMM_MATH=fp32): bias, activation, residual, saved activation, ragged M."""
 import ctypes as C
 
@@ -27,7 +28,7 @@ def test_dense_fwd_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, resid
     y_ref = s_ref + (X if residual else 0)
     mag = (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)).max()
     out = {}
-    for math in ("bf16x3", "fp32"):
+    for math in ("f16x2", "fp32"):
         monkeypatch.setenv("NG_GEMM_MATH", math)
         tX, tW, tb = (torch.from_numpy(a).to(gpu_device) for a in (X, W, b))
         Y = torch.full((M, N), 7.0, device=gpu_device)
@@ -42,7 +43,7 @@ def test_dense_fwd_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, resid
         assert np.isfinite(y).all(), k
         assert np.abs(y - y_ref).max() < 2e-6 * mag, k
         assert np.abs(s - s_ref).max() < 2e-6 * mag, k
-    e3 = np.sqrt(((out["bf16x3"][0] - y_ref) ** 2).mean())
+    e3 = np.sqrt(((out["f16x2"][0] - y_ref) ** 2).mean())
     e1 = np.sqrt(((out["fp32"][0] - y_ref) ** 2).mean())
     assert e3 < 1.5 * e1 + 1e-8, (e3, e1)
 
@@ -68,7 +69,7 @@ def test_dense_bwd_dx_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, re
     dW_ref = X.astype(np.float64).T @ dP
     mag = (np.abs(dP) @ np.abs(W.astype(np.float64)).T).max()
     res = {}
-    for math in ("bf16x3", "fp32"):
+    for math in ("f16x2", "fp32"):
         monkeypatch.setenv("NG_GEMM_MATH", math)
         tX, tW, tS, tdY = (torch.from_numpy(a).to(gpu_device) for a in (X, W, s, dY))
         dX = torch.full((M, K), 7.0, device=gpu_device)
@@ -85,6 +86,41 @@ def test_dense_bwd_dx_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, re
         magw = (np.abs(X).astype(np.float64).T @ np.abs(dP)).max()
         assert np.abs(dW.cpu().numpy() - dW_ref).max() < 2e-6 * magw, math
         assert np.abs(db.cpu().numpy() - dP.sum(0)).max() < 2e-6 * np.abs(dP).sum(0).max(), math
-    e3 = np.sqrt(((res["bf16x3"] - dX_ref) ** 2).mean())
+    e3 = np.sqrt(((res["f16x2"] - dX_ref) ** 2).mean())
     e1 = np.sqrt(((res["fp32"] - dX_ref) ** 2).mean())
     assert e3 < 1.5 * e1 + 1e-8, (e3, e1)
+
+
+@pytest.mark.parametrize("shift", [-60, -24, -7, 11, 40])
+def test_dense_bwd_gradient_scale_is_exact(gpu_device, monkeypatch, shift):
+    """The fp16-piece GEMMs split a gradient operand as S * dP with a power of two S taken from max|dY| (gemm_grad_scale),
+    so that tiny gradients (loss scaling, 1/N) neither underflow the pieces nor large ones overflow them.  Property:
+    dY * 2^shift gives dX * 2^shift and dW * 2^shift bit for bit."""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    M, K, N, act = 5000, 256, 256, 1
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
+    s = softplus(X.astype(np.float64) @ W.astype(np.float64)).astype(np.float32)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    monkeypatch.setenv("NG_GEMM_MATH", "f16x2")
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+
+    def run(dy):
+        tX, tW, tS, tdY = (torch.from_numpy(a).to(gpu_device) for a in (X, W, s, dy))
+        dX = torch.empty((M, K), device=gpu_device)
+        dW = torch.empty((K, N), device=gpu_device)
+        db = torch.empty((N,), device=gpu_device)
+        ctx.check(ctx.lib.ng_dense_bwd(ctx.handle, st, M, K, N, act, 0, ptr(tX), ptr(tW), ptr(tS), ptr(tdY), ptr(dX),
+                                       ptr(dW), ptr(db)), "ng_dense_bwd")
+        torch.cuda.synchronize()
+        return dX.cpu().numpy().astype(np.float64), dW.cpu().numpy().astype(np.float64)
+
+    base = run(dY)
+    moved = run((dY.astype(np.float64) * 2.0 ** shift).astype(np.float32))
+    for a, b in zip(moved, base):
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b * 2.0 ** shift)

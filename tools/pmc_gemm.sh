@@ -10,7 +10,7 @@ val = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob("gpurun_out/pmc_gemm*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm_x3" not in k: continue
+        if "gemm_h2" not in k: continue
         if int(r["Grid_Size"]) < 200000: continue
         k = k.split("(")[0]
         val[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
