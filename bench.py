@@ -40,15 +40,12 @@ import torch
 import torch.distributed as dist
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_MFMA_BF16_TFLOPS = 2516.6  # dense bf16: 256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz
-PEAK_MFMA_F16_TFLOPS = 2516.6   # dense fp16: same rate as bf16 (tools/ubench/mfma_f16.hip measures both)
-# kernels that run fp32 arithmetic on the bf16 pipe (three-way operand split, 6 piece products per multiply):
-# priced with their ALGORITHMIC fp32 flops against bf16 peak / 6
-X3_KERNELS = {"edge_fwd_x3", "edge_bwd_x3"}
-# kernels that run it on the fp16 pipe with two pieces per operand, 3 piece products per multiply (the default edge
-# kernels): ALGORITHMIC fp32 flops against fp16 peak / 3.  The matrix pipe then does half the work of the x3 kernels for
-# the same algorithmic flops, so `frac` (matrix-pipe share of the kernel time) is LOWER for a FASTER kernel: the
-# remainder is VALU issue time (softplus, splits, RBF), which adds to matrix time on a gfx950 SIMD.
+PEAK_MFMA_F16_TFLOPS = 2516.6   # dense fp16 (= bf16): 256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; tools/ubench/mfma_f16.hip
+# kernels that run fp32 arithmetic on the fp16 pipe with two pieces per operand, 3 piece products per multiply (the
+# default edge kernels): ALGORITHMIC fp32 flops against fp16 peak / 3.  Round 2 started with three bf16 pieces and 6
+# products (peak / 6): the matrix pipe now does half the work for the same algorithmic flops, so `frac` (matrix-pipe
+# share of the kernel time) is LOWER for a FASTER kernel: the remainder is VALU issue time (softplus, splits, RBF),
+# which adds to matrix time on a gfx950 SIMD.
 H2_KERNELS = {"edge_fwd_h2", "edge_bwd_h2"}
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 achievable
 
@@ -67,10 +64,6 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C):
         # fused edge kernels (edge_fused.hip)
         "edge_fused_fwd": ("mfma", 2.0 * ne * ((Le - 1) * H * H + H * E),
                            f4 * ne * (1 + 1 + E + (Le - 1) * H)),
-        "edge_fwd_x3": ("mfma", 2.0 * ne * ((Le - 1) * H * H + H * E),
-                        f4 * ne * (1 + 1 + E + (Le - 1) * H)),
-        "edge_bwd_x3": ("mfma", 2.0 * ne * ((2 * (Le - 1) - 1) * H * H + 2 * H * E),
-                        f4 * ne * (1 + 1 + E + (Le - 1) * H)),
         "edge_fwd_h2": ("mfma", 2.0 * ne * ((Le - 1) * H * H + H * E),
                         f4 * ne * (1 + 1 + E + (Le - 1) * H)),
         "edge_bwd_h2": ("mfma", 2.0 * ne * ((2 * (Le - 1) - 1) * H * H + 2 * H * E),
@@ -204,7 +197,6 @@ X3_GEMM_TAGS = {"mp_update_fwd", "mp_dw", "mp_dA", "dense_fwd", "dense_dx", "den
                 "edge_dense_dx", "edge_dense_dw"}
 # kernel tag -> the source files whose content decides whether a committed PMC number still describes it
 KERNEL_SOURCES = {
-    "edge_fwd_x3": ["edge_fwd_x3.hip", "x3_common.cuh"], "edge_bwd_x3": ["edge_bwd_x3.hip", "x3_common.cuh"],
     "edge_fwd_h2": ["edge_fwd_h2.hip", "h2_common.cuh"], "edge_bwd_h2": ["edge_bwd_h2.hip", "h2_common.cuh"],
     "edge_fused_fwd": ["edge_fused.hip"], "edge_fused_bwd": ["edge_fused_bwd.hip"],
     "mp_win_fwd": ["mp_win.hip"], "mp_win_bwd_edge": ["mp_win_bwd.hip"], "mp_win_bwd_node": ["mp_win_bwd.hip"],
@@ -266,16 +258,12 @@ def roofline_rows(prof, psteps, work, x3_gemm):
             bound, fl, by = work[name]
             if bound == "mfma":
                 ach = fl / (avg_ms * 1e-3) / 1e12
-                on_x3 = name in X3_KERNELS
                 on_h2 = name in H2_KERNELS or (x3_gemm and name in X3_GEMM_TAGS)
-                peak = (PEAK_MFMA_F16_TFLOPS / 3.0 if on_h2 else
-                        PEAK_MFMA_BF16_TFLOPS / 6.0 if on_x3 else PEAK_MFMA_F32_TFLOPS)
+                peak = PEAK_MFMA_F16_TFLOPS / 3.0 if on_h2 else PEAK_MFMA_F32_TFLOPS
                 row.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
                 if on_h2:
                     row["peak_note"] = ("fp32-equivalent: fp16 dense peak 2516.6 / 3 piece products; achieved is "
                                         f"{ach / PEAK_MFMA_F32_TFLOPS:.2f}x the f32-input MFMA peak (157.3)")
-                elif on_x3:
-                    row["peak_note"] = "fp32-equivalent: bf16 dense peak 2516.6 / 6 piece products"
             else:
                 ach = by / (avg_ms * 1e-3) / 1e9
                 row.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
@@ -452,12 +440,9 @@ def main():
                                   "a real epoch pays it once per batch"},
         "loss": final_loss,
         "matrix_math": ("f32-input MFMA everywhere" if os.environ.get("NG_EDGE_MATH", "") == "fp32" else
-                        "edge MLP forward and backward: bf16 MFMA on fp32 operands split exactly into 3 bf16 pieces, "
-                        "6 piece products per multiply, fp32 accumulate; all other contractions: f32-input MFMA"
-                        if os.environ.get("NG_EDGE_MATH", "") == "bf16x3" else
                         "edge MLP forward and backward: fp16 MFMA on fp32 operands split into 2 fp16 pieces (22-24 "
                         "significand bits), 3 piece products per multiply, fp32 accumulate; error against float64 at or "
-                        "below the f32-input MFMA kernels' (tests/test_gpu_edge_x3.py); all other contractions: "
+                        "below the f32-input MFMA kernels' (tests/test_gpu_edge_h2.py); all other contractions: "
                         "f32-input MFMA"),
     }
 

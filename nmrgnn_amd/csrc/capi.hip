@@ -17,7 +17,6 @@ static bool env_is(const char* name, const char* value) {
 static void load_switches() {
   Switches s;
   s.edge_math_fp32 = env_is("NG_EDGE_MATH", "fp32");
-  s.edge_math_bf16x3 = env_is("NG_EDGE_MATH", "bf16x3");
   s.edge_bwd_math_fp32 = env_is("NG_EDGE_BWD_MATH", "fp32");
   s.gemm_math_fp32 = env_is("NG_GEMM_MATH", "fp32");
   s.edge_layered = env_is("NG_EDGE_PATH", "layered");

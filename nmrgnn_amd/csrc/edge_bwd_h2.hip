@@ -1,7 +1,7 @@
 // Fused persistent backward of the edge path on the fp16 matrix pipe with two-piece split fp32 operands
-// (h2_common.cuh: three piece products per multiply).  Default since late round 2; same math, phases, tile loop,
-// workgroup partials and reduction kernel as edge_bwd_x3.hip (exact three-piece bf16 split, NG_EDGE_MATH=bf16x3) and
-// edge_fused_bwd.hip (f32-input MFMA, NG_EDGE_MATH=fp32).  Backward of nmrgnn/model.py:251-261, SURVEY App. B.
+// (h2_common.cuh: three piece products per multiply).  Default; same math, phases, workgroup partials and reduction
+// kernel as edge_fused_bwd.hip (f32-input MFMA, NG_EDGE_MATH=fp32).  Backward of nmrgnn/model.py:251-261, SURVEY App. B.
+// (Until late round 2: exact three-piece bf16 split, six piece products, images 152 KB.)
 //
 //   A:  dE = S*m*de ;  G3 = (dE Wo^T) * s'(Z3)   [VALU]      dWo += Z3^T dE, dbo += sum dE   [VALU, fp32]
 //   B:  dW3 += Z2^T G3 ; db3 += colsum G3 ; dZ2 = G3 W3^T ; G2 = dZ2 * s'(Z2)
@@ -573,14 +573,21 @@ __global__ __launch_bounds__(128) void hx_scale_kernel(const float* __restrict__
 }
 
 // Buffer offsets inside the kernel are 32-bit (one resource per array, 512 B of tape per edge), so one LAUNCH covers
-// at most HX_SEG_EDGES edges (the segment size of edge_bwd_x3.hip: edge_bwd_x3_segments); longer edge lists run as
-// several launches over consecutive segments, each with its own rows of the partial buffer.
+// at most HX_SEG_EDGES edges; longer edge lists run as several launches over consecutive segments (a multiple of the
+// 64-edge tile and of the 32-edge tape group), each with its own rows of the partial buffer.
 constexpr int64_t HX_SEG_EDGES = ((int64_t)1 << 23) - 256;
+int edge_bwd_h2_segments(int64_t n_edges) { return (int)std::max<int64_t>(1, cdiv(n_edges, HX_SEG_EDGES)); }
+
+bool edge_bwd_h2_supported(int E, int64_t n_edges) { (void)n_edges; return E >= 1 && E <= 4; }
+
+bool edge_tape_blocked(int E, int64_t n_edges) {
+  return edge_split_enabled() && !sw().edge_bwd_math_fp32 && edge_bwd_h2_supported(E, n_edges);
+}
 constexpr size_t HX_WT_BYTES = (size_t)2 * 4 * 8 * 2 * 1024;
 
 size_t edge_bwd_h2_ws_bytes() { return HX_WT_BYTES + (size_t)(HX_SCALE_BLOCKS + 2) * 4; }
 
-// wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_x3_segments(n_edges) * grid][part_stride]
+// wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_h2_segments(n_edges) * grid][part_stride]
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
                        char* wt_img, float* partial, int part_stride, int grid, int tape_blocked) {
@@ -594,7 +601,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     hipLaunchKernelGGL(hx_scale_kernel, dim3(1), dim3(128), 0, st, blockmax, nb, W[1], W[2], W[3], E, scale);
     NG_HIP(ctx, hipGetLastError());
   }
-  const int nseg = edge_bwd_x3_segments(n_edges);
+  const int nseg = edge_bwd_h2_segments(n_edges);
   for (int sg = 0; sg < nseg; ++sg) {
     const int64_t e0 = (int64_t)sg * HX_SEG_EDGES;
     EdgeBwdH2Args a;

@@ -32,32 +32,22 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   } while (0)
 
 namespace ng {
-// forward on the bf16 matrix pipe with three-way operand splitting (edge_fwd_x3.hip); NG_EDGE_MATH=bf16x3
-bool edge_x3_enabled();
-// two-piece fp16 split (edge_fwd_h2.hip): the default; same tape layouts as edge_x3_fwd
+// Edge path on the fp16 matrix pipe with two-piece split fp32 operands (edge_fwd_h2.hip, edge_bwd_h2.hip): the default;
+// NG_EDGE_MATH=fp32 selects the f32-input MFMA kernels (edge_fused.hip, edge_fused_bwd.hip)
+bool edge_split_enabled();
 int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
                 float* z_save);
-int edge_x3_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
-                const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
-                float* z_save);
-}  // namespace ng
-
-namespace ng {
-// backward on the bf16 matrix pipe with split operands (edge_bwd_x3.hip); partial layout of edge_fused_bwd.hip
-bool edge_bwd_x3_supported(int E, int64_t n_edges);
-int edge_bwd_x3_segments(int64_t n_edges);
+bool edge_bwd_h2_supported(int E, int64_t n_edges);
+int edge_bwd_h2_segments(int64_t n_edges);
 // Layout of the saved-activation tape z_save[Le-1][n_edges][128] between the edge forward and backward:
 // false: row-major.  true (both directions run the split-operand kernels): inside every FULL group of 32 consecutive
 // edges the 32 x 128 block is stored in the kernels' register layout, float index ((bo*4 + q)*64 + hf*32 + r)*4 + j for
 // edge r, feature 32 bo + 8 q + 4 hf + j; a last partial group stays row-major.  Same footprint either way.
 bool edge_tape_blocked(int E, int64_t n_edges);
-size_t edge_bwd_x3_ws_bytes();
-int edge_bwd_x3_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
-                       const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked);
-// the same contract on the fp16 pipe with two-piece operands (edge_bwd_h2.hip): the default
 size_t edge_bwd_h2_ws_bytes();
+// wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_h2_segments(n_edges) * grid][part_stride] in the
+// layout of edge_fused_bwd.hip
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
                        char* wt_img, float* partial, int part_stride, int grid, int tape_blocked);

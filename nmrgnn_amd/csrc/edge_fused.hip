@@ -298,9 +298,7 @@ bool edge_fused_supported(int H, int E, int Le) { return H == FH && Le == 4 && E
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* const* b, float* e_out, float* z_save) {
-  if (edge_x3_enabled() && !sw().edge_math_bf16x3)
-    return edge_h2_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
-  if (edge_x3_enabled()) return edge_x3_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
+  if (edge_split_enabled()) return edge_h2_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
   float* Wpk = (float*)workspace(ctx, (pk_floats + FH) * 4);

@@ -371,8 +371,8 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
   const size_t pk_floats = (size_t)3 * FH * FH;
-  const int nseg = edge_bwd_x3_segments(n_edges);      // launches of the split-operand kernel (1 below 8.4 M edges)
-  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)nseg * grid * stride) * 4 + std::max(edge_bwd_x3_ws_bytes(), edge_bwd_h2_ws_bytes()));
+  const int nseg = edge_bwd_h2_segments(n_edges);      // launches of the split-operand kernel (1 below 8.4 M edges)
+  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)nseg * grid * stride) * 4 + edge_bwd_h2_ws_bytes());
   if (!ws) return NG_ERR_NOMEM;
   float* Wpk = ws;
   float* WpkT = ws + pk_floats;
@@ -385,17 +385,15 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.WpkT = WpkT; a.Wo = W[3]; a.z_save = z_save; a.de = de;
   a.partial = partial; a.part_stride = stride;
   const size_t lds = (size_t)(3 * FTM * FLD + FH * FMAX_E + FTM * FMAX_E + 2 * FTM + FH) * 4;
-  // default: split-operand kernel on the 16-bit matrix pipe (edge_bwd_h2.hip / edge_bwd_x3.hip); NG_EDGE_MATH=fp32 (both directions) or
+  // default: split-operand kernel on the 16-bit matrix pipe (edge_bwd_h2.hip); NG_EDGE_MATH=fp32 (both directions) or
   // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
   // tape_layout: what the forward that wrote z_save reported (ng_edge_tape_layout), -1 = decide as the forward would
   // now.  A blocked tape can only be read by the split-operand kernel; that kernel reads row-major tapes as well.
   const bool blocked = tape_layout < 0 ? edge_tape_blocked(E, n_edges) : tape_layout == 1;
-  if (blocked && !edge_bwd_x3_supported(E, n_edges)) return fail(ctx, NG_ERR_INVALID, "edge_mlp_bwd: blocked tape for an unsupported shape");
+  if (blocked && !edge_bwd_h2_supported(E, n_edges)) return fail(ctx, NG_ERR_INVALID, "edge_mlp_bwd: blocked tape for an unsupported shape");
   int n_part = grid;
   if (blocked || edge_tape_blocked(E, n_edges)) {
-    // two-piece fp16 split (edge_bwd_h2.hip) unless NG_EDGE_MATH=bf16x3 asks for the exact three-piece bf16 kernel
-    auto launch = sw().edge_math_bf16x3 ? edge_bwd_x3_launch : edge_bwd_h2_launch;
-    int rc3 = launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
+    int rc3 = edge_bwd_h2_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
                      (char*)(partial + (size_t)nseg * grid * stride), partial, stride, grid, blocked ? 1 : 0);
     if (rc3) return rc3;
     n_part = nseg * grid;

@@ -1,18 +1,17 @@
 // Fused edge forward on the fp16 matrix pipe with fp32-grade arithmetic: every fp32 operand split into TWO fp16
-// pieces, three piece products per multiply (h2_common.cuh).  Default since late round 2; NG_EDGE_MATH=bf16x3 selects
-// the exact three-piece bf16 kernel (edge_fwd_x3.hip, six products), NG_EDGE_MATH=fp32 the f32-input MFMA kernel.
+// pieces, three piece products per multiply (h2_common.cuh).  Default; NG_EDGE_MATH=fp32 selects the f32-input MFMA
+// kernel (edge_fused.hip).  Until late round 2 this kernel used the exact three-piece bf16 split (six products).
 // Reference: nmrgnn/model.py:251-261 + nmrgnn/layers.py:137-140 + nmrgnn/model.py:132-138.
 //
 // Why.  Matrix time and VALU time ADD on a gfx950 SIMD, and the three-piece kernel sits on that sum:
 // 616 MFMAs + ~3200 VALU instructions per wave and 256-edge tile.  Two fp16 pieces carry 22-24 significand bits —
-// fp32's 24 — so three products (lh + hl + hh) reach fp32-level error with HALF the matrix instructions, and the
-// residual of a split is one v_fma_mix_f32 instead of shift / and / subtract twice.
+// fp32's 24 — so three products (lh + hl + hh) reach fp32-level error with HALF the matrix instructions, and a split
+// costs one conversion back + one subtraction + one packed conversion instead of two of each.
 //
-// Mapping (same as edge_fwd_x3.hip, same accumulator layout => same blocked tape).  512 threads = 8 waves, one
-// persistent workgroup per CU, 256 edges per tile; wave w owns edges [32w, 32w+32) through ALL layers:
+// Mapping.  512 threads = 8 waves, one persistent workgroup per CU, 256 edges per tile; wave w owns edges [32w, 32w+32) through ALL layers:
 //   v_mfma_f32_32x32x16_f16  D[feature][edge] += A[feature][k] * B[k][edge]
 //   A = weight pieces from LDS (ds_read_b128 of a lane-linear fragment image), B = activation pieces in VGPRs.
-// The contraction index of the next layer is permuted (x3_feat) so that a lane's 16 outputs of a block are its own
+// The contraction index of the next layer is permuted (h2_feat) so that a lane's 16 outputs of a block are its own
 // k-slots of two k-steps: softplus -> split -> pack turns accumulators into the next B operand in registers.
 //
 // Weight scale.  W pieces are taken from 2^WS * W (WS = 8, exact): the l piece of a typical weight (|W| ~ 0.1) would
@@ -328,6 +327,9 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
+
+// default for the edge path; NG_EDGE_MATH=fp32 selects the f32-input MFMA kernels of edge_fused.hip / edge_fused_bwd.hip
+bool edge_split_enabled() { return !sw().edge_math_fp32; }
 
 int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,

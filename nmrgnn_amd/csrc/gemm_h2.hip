@@ -659,7 +659,7 @@ int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int ac
 // ------------------------------------------------------------------------------------------------------------------
 // dW[k][n] = sum_m X[m][k] dP[m][n]   (dP = dY * act'(S) * rowscale), the contraction runs over the ROWS of both
 // operands: both live in LDS as fp16 piece images [32 rows][128 + 8] and are read as COLUMNS with ds_read_b64_tr_b16
-// (rows stored permuted so that the four rows of a read sit 16 banks apart — see edge_bwd_x3.hip).  256 threads, output
+// (rows stored permuted so that the four rows of a read sit 16 banks apart — see edge_bwd_h2.hip).  256 threads, output
 // tile 128 (k) x 128 (n), 32 rows per step, the rows split over blockIdx.z into partials [z][K][N] that the caller
 // reduces (dense_dw).  MFMA: A = dP columns (rows n of D), B = X columns (columns k of D): a lane ends with 4
 // consecutive n of one k.
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dw_kernel(GtArgs a) {
   // loader: thread -> row tid >> 3 of the 32-row step, 16 columns at 16 (tid & 7)
   const int lr = tid >> 3, lc = 16 * (tid & 7);
   const int e16 = lr & 15;
-  const int prow = 16 * (lr >> 4) + 4 * (e16 & 3) + (e16 >> 2);   // see bx_prow_g
+  const int prow = 16 * (lr >> 4) + 4 * (e16 & 3) + (e16 >> 2);   // see hx_prow_g in edge_bwd_h2.hip
   float xv[16], pv[16];
   auto load = [&](int64_t row) {
     const bool ok = row < r1;
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   // loader: thread -> row tid >> 4 of the 32-row step, 16 columns at 16 (tid & 15)
   const int lr = tid >> 4, lc = 16 * (tid & 15);
   const int e16 = lr & 15;
-  const int prow = 16 * (lr >> 4) + 4 * (e16 & 3) + (e16 >> 2);   // see bx_prow_g
+  const int prow = 16 * (lr >> 4) + 4 * (e16 & 3) + (e16 >> 2);   // see hx_prow_g in edge_bwd_h2.hip
   float xv[16], pv[16];
   auto load = [&](int64_t row) {
     const bool ok = row < r1;

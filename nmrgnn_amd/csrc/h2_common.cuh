@@ -3,22 +3,28 @@
 // fp32), |r| <= 2^-22 |x| (typically 2^-24: two 11-bit significands with a signed residual cover 22-23 bits), and a
 // product a*b is taken as  al*bh + ah*bl + ah*bh  (smallest first), every piece product exact in the fp32 accumulator
 // of v_mfma_f32_32x32x16_f16 (11 x 11 significand bits).  Dropped: al*bl <= 2^-22 |a||b| and the residuals — the size
-// of an fp32 rounding of the product.  Three matrix instructions per fp32 multiply instead of the six of the exact
-// three-piece bf16 split (x3_common.cuh), and a shorter residual (one conversion back, one subtraction, one v_cvt_pk_f16_f32 instead of two of each).
+// of an fp32 rounding of the product.  Three matrix instructions per fp32 multiply; the exact three-piece bf16 split
+// these kernels used until late round 2 needed six, and two conversions / subtractions per element instead of one.
 // Range: fp16 pieces need |x| < 65504 (activations: unscaled; gradients: scaled by a power of two per launch, see
 // edge_bwd_h2.hip); below 2^-14 the l piece is a subnormal the matrix pipe honours (tools/ubench/mfma_f16.hip), so the
 // absolute representation error never exceeds max(2^-25, 2^-22 |x|).
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "x3_common.cuh"
-
 namespace ng {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_cvt __attribute__((ext_vector_type(2)));
+typedef float f32x2_cvt __attribute__((ext_vector_type(2)));
 
-// two floats -> packed fp16, round to nearest even (compiler-native conversion: see the hazard note in x3_common.cuh)
+// two floats -> packed fp16, round to nearest even, through the compiler's own vector conversion and NOT inline asm:
+// LLVM's hazard recognizer does not apply the MFMA-related wait states (XDL write -> VALU, SrcC read -> VALU write, ...)
+// to instructions hidden inside an asm statement; when the scheduler interleaved asm conversions with an MFMA chain
+// (round 2, bf16 version of these kernels) ~16 % of the edges came out different from run to run by up to 6e-6
+// (tools/dbg_det.py, tests/test_gpu_determinism.py).
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{lo, hi}, f16x2_cvt));
 }

@@ -48,7 +48,6 @@ namespace ng {
 // Process-wide path switches, parsed from the environment ONCE (first use) instead of a getenv + string compare
 // on every launch; ng_reload_env() re-reads them (tests and A/B tools flip variables inside one process).
 //   NG_EDGE_MATH=fp32      edge MLP forward+backward on f32-input MFMA (default: two-piece fp16 split operands)
-//   NG_EDGE_MATH=bf16x3    edge MLP on the exact three-piece bf16 split (six piece products per multiply)
 //   NG_EDGE_BWD_MATH=fp32  only the edge backward on f32-input MFMA
 //   NG_GEMM_MATH=fp32      generic GEMMs on f32-input MFMA (default: split operands where the shape allows)
 //   NG_EDGE_PATH=layered   one launch per edge-MLP layer (any H / Le)
@@ -59,7 +58,6 @@ namespace ng {
 //   NG_KNN=serial          one lane per query atom in the kNN graph kernel
 struct Switches {
   bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
-  bool edge_math_bf16x3 = false;
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false;
   bool gemm_4wave = false;      // NG_GEMM_TILE=4wave: the un-pipelined 4-wave split-operand GEMM (A/B measurements)
@@ -103,7 +101,7 @@ constexpr size_t NG_SMALL_BYTES = 64 * 1024;
 void* small_scratch(ng_ctx* ctx);      // NG_SMALL_BYTES, allocated once per context, address stable until ng_ctx_destroy
 // Frozen-weight image cache.  Returns nullptr when the cache is off (pack into scratch as before); otherwise a
 // persistent buffer of `bytes` for (src, kind) with *valid = true when it already holds the image of the current
-// weights (skip the pack launch).  kinds: 1 MPLayer Wp, 2 edge x3 image, 3 GEMM x3 image, 4 window fragments, 5 FC fragments
+// weights (skip the pack launch).  kinds: 1 MPLayer Wp, 3 GEMM fp16-piece image, 4 window fragments, 5 FC fragments, 6 edge fp16-piece image
 void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* valid);
 
 // RAII-less profiling bracket: call begin before the launch(es), end after.

@@ -1,8 +1,7 @@
-"""Edge forward / backward on the 16-bit matrix pipe with split fp32 operands against a float64 numpy statement of
-nmrgnn/model.py:251-261 + layers.py:137-140 + model.py:132-138 — and against the f32-input MFMA kernel
-(NG_EDGE_MATH=fp32): a split path must be as close to float64 as the fp32 path is.
-  f16x2  (default, edge_fwd_h2.hip): two fp16 pieces, three piece products per multiply
-  bf16x3 (edge_fwd_x3.hip / edge_bwd_x3.hip): exact three-piece bf16 split, six piece products"""
+"""Edge forward / backward on the fp16 matrix pipe with two-piece split fp32 operands (edge_fwd_h2.hip, edge_bwd_h2.hip:
+three piece products per multiply, fp32 accumulate) against a float64 numpy statement of nmrgnn/model.py:251-261 +
+layers.py:137-140 + model.py:132-138 — and against the f32-input MFMA kernels (NG_EDGE_MATH=fp32): the split path must be
+as close to float64 as the fp32 path is."""
 import ctypes as C
 
 import numpy as np
@@ -85,13 +84,13 @@ def test_edge_forward_split_vs_float64(gpu_device, monkeypatch, n, E, save):
     e_ref, z_ref = ref_edge(f32(d_src), f32(d_eff), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws],
                             [f32(b) for b in bs])
     out = {}
-    for math in ("f16x2", "bf16x3", "fp32"):
+    for math in ("f16x2", "fp32"):
         monkeypatch.setenv("NG_EDGE_MATH", math)
         out[math] = run_gpu(gpu_device, d_src, d_eff, centers, gap, Ws, bs, E, save)
     # the output layer is a 128-term dot product: its rounding error scales with sum |z||W|, not with the result
     mag = (np.abs(z_ref[2]) @ np.abs(f32(Ws[3])) + np.abs(f32(bs[3]))).max()
     err = {k: np.abs(v[0] - e_ref) for k, v in out.items()}
-    for split in ("f16x2", "bf16x3"):
+    for split in ("f16x2",):
         assert err[split].max() < 1e-6 * mag, (split, err[split].max(), err["fp32"].max(), mag)
         assert np.sqrt((err[split] ** 2).mean()) < 2e-7 * mag, split
         if save:
@@ -184,14 +183,14 @@ def test_edge_backward_split_vs_float64(gpu_device, monkeypatch, n, E):
         mag_dW[l], mag_db[l] = np.abs(xs[l]).T @ np.abs(G), np.abs(G).sum(0)
         g = G @ Wf[l].T
     out = {}
-    for math in ("f16x2", "bf16x3", "fp32"):
+    for math in ("f16x2", "fp32"):
         monkeypatch.setenv("NG_EDGE_MATH", math)
         out[math] = run_gpu_bwd(gpu_device, d_src, d_eff, centers, gap, Ws, zs32, de, E)
     for l in range(4):
         for name, ref, mag, k in (("dW", ref_dW[l], mag_dW[l], 0), ("db", ref_db[l], mag_db[l], 1)):
             scale = max(mag.max(), 1e-6)
             err = {mth: np.abs(o[k][l] - ref).max() / scale for mth, o in out.items()}
-            for split in ("f16x2", "bf16x3"):
+            for split in ("f16x2",):
                 assert err[split] < 1e-6, (split, name, l, err)                 # ~16 fp32 roundings of the term scale
                 assert err[split] < 4.0 * err["fp32"] + 1e-7, (split, name, l, err)
 

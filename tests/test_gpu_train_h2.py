@@ -28,12 +28,11 @@ def _run(gpu_device, monkeypatch, math, steps=12):
     return np.array(losses), eng.params.flat.detach().cpu().numpy().astype(np.float64)
 
 
-@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
-def test_training_trajectories_coincide(gpu_device, monkeypatch, split):
-    """f16x2: the default two-piece fp16 kernels (edge_fwd_h2 / edge_bwd_h2); bf16x3: the exact three-piece ones"""
-    l_x3, p_x3 = _run(gpu_device, monkeypatch, split)
+def test_training_trajectories_coincide(gpu_device, monkeypatch):
+    """f16x2: the default two-piece fp16 kernels (edge_fwd_h2 / edge_bwd_h2)"""
+    l_h2, p_h2 = _run(gpu_device, monkeypatch, "f16x2")
     l_32, p_32 = _run(gpu_device, monkeypatch, "fp32")
     assert l_32[-1] < l_32[0]                                   # it trains
-    assert np.max(np.abs(l_x3 - l_32) / np.abs(l_32)) < 2e-5, (l_x3, l_32)
+    assert np.max(np.abs(l_h2 - l_32) / np.abs(l_32)) < 2e-5, (l_h2, l_32)
     # Adam normalises every update to ~lr, so rounding-level gradient differences move a weight by << lr per step
-    assert np.max(np.abs(p_x3 - p_32)) < 12 * 1e-3 * 0.05
+    assert np.max(np.abs(p_h2 - p_32)) < 12 * 1e-3 * 0.05

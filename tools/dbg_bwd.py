@@ -1,9 +1,9 @@
-"""per-layer error of the split-operand edge backward vs float64 (debug aid; same setup as tests/test_gpu_edge_x3.py)"""
+"""per-layer error of the split-operand edge backward vs float64 (debug aid; same setup as tests/test_gpu_edge_h2.py)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
-import test_gpu_edge_x3 as T
+import test_gpu_edge_h2 as T
 H = T.H
 dev = torch.device("cuda", 0)
 for n, E in [(1, 3), (32, 3), (33, 3), (64, 3), (65, 3), (128, 3), (200, 3), (5000, 4), (70001, 3)]:

@@ -1,10 +1,10 @@
-"""print the float64 errors of the three edge-forward maths for a few sizes (diagnostic; run through gpurun)"""
+"""print the float64 errors of both edge-forward maths for a few sizes (diagnostic; run through gpurun)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
-from test_gpu_edge_x3 import ref_edge, run_gpu, H
+from test_gpu_edge_h2 import ref_edge, run_gpu, H
 
 dev = torch.device("cuda:0")
 for n, E in [(255, 3), (257, 1), (4096, 3), (70001, 3)]:
@@ -16,7 +16,7 @@ for n, E in [(255, 3), (257, 1), (4096, 3), (70001, 3)]:
     bs = [rng.standard_normal(H) * 0.1 for _ in range(3)] + [rng.standard_normal(E) * 0.1]
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     e_ref, z_ref = ref_edge(f32(d_src), f32(d_eff), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws], [f32(b) for b in bs])
-    for math in ("f16x2", "bf16x3", "fp32"):
+    for math in ("f16x2", "fp32"):
         os.environ["NG_EDGE_MATH"] = math
         from nmrgnn_amd import _lib
         _lib.get_context(0).lib.ng_reload_env()
