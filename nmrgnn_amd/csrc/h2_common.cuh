@@ -1,6 +1,7 @@
 // Shared pieces of the two-piece fp16 split-operand kernels (edge_fwd_h2.hip, edge_bwd_h2.hip, gemm_h2 paths).
 // An fp32 value x is written as x = h + l + r with h = rne_f16(x), l = rne_f16(x - h) (the subtraction is exact in
-// fp32), |r| <= 2^-22 |x| (typically 2^-24: two 11-bit significands with a signed residual cover 22-23 bits), and a
+// fp32), |r| <= 2^-22 |x| (rms 2^-23 |x|: two 11-bit significands with a signed residual cover 22-23 bits; host
+// restatement in tests/test_host.py), and a
 // product a*b is taken as  al*bh + ah*bl + ah*bh  (smallest first), every piece product exact in the fp32 accumulator
 // of v_mfma_f32_32x32x16_f16 (11 x 11 significand bits).  Dropped: al*bl <= 2^-22 |a||b| and the residuals — the size
 // of an fp32 rounding of the product.  Three matrix instructions per fp32 multiply; the exact three-piece bf16 split

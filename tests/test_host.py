@@ -95,19 +95,30 @@ def test_shard_range_partitions_everything():
     assert shard_range(4096, 3, 8) == (1536, 2048)
 
 
-def test_three_piece_split_is_exact():
-    """host restatement of the split used on the device: x == h + m + l exactly, every piece has <= 8 significant bits"""
+def test_two_piece_fp16_split_bounds():
+    """host restatement of the split used on the device (csrc/h2_common.cuh): h = rne_f16(x), l = rne_f16(x - h) with
+    the subtraction exact in fp32; x - h - l is at most max(2^-22 |x|, 2^-25) (l may be an fp16 subnormal, which the
+    matrix pipe honours), and a product taken as lh + hl + hh misses a*b by no more than the two representation errors
+    plus the dropped l*l <= 2^-22 |a b|"""
     rng = np.random.default_rng(0)
-    x = np.concatenate([rng.standard_normal(4096), rng.standard_normal(4096) * 1e-20, rng.standard_normal(4096) * 1e20]
+    x = np.concatenate([rng.standard_normal(8192), rng.standard_normal(4096) * 1e-3, rng.uniform(-6e4, 6e4, 4096)]
                        ).astype(np.float32)
-
-    def rne_bf16(v):
-        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
-        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-        return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
-    h = rne_bf16(x)
-    r1 = x - h
-    m = rne_bf16(r1)
-    r2 = r1 - m
-    l = rne_bf16(r2)
-    assert np.all(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64) == x.astype(np.float64))
+    h = x.astype(np.float16)
+    r = x - h.astype(np.float32)
+    assert np.all(r.astype(np.float64) == x.astype(np.float64) - h.astype(np.float64))      # exact in fp32
+    l = r.astype(np.float16)
+    rest = x.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64)
+    assert np.all(np.abs(rest) <= np.maximum(2.0 ** -22 * np.abs(x.astype(np.float64)), 2.0 ** -25))
+    # typical (rms) representation error: ~2^-23 |x|, twice the unit of fp32's own rounding
+    big = np.abs(x) > 1e-2
+    assert np.sqrt(np.mean((rest[big] / x[big]) ** 2)) < 2.0 ** -22.5
+    # three piece products against the exact product
+    y = rng.standard_normal(x.size).astype(np.float32)
+    hy = y.astype(np.float16)
+    ly = (y - hy.astype(np.float32)).astype(np.float16)
+    f = lambda a: a.astype(np.float64)
+    prod3 = f(l) * f(hy) + f(h) * f(ly) + f(h) * f(hy)
+    exact = f(x) * f(y)
+    ax, ay = np.abs(f(x)), np.abs(f(y))
+    bound = ax * np.maximum(2.0 ** -22 * ay, 2.0 ** -25) + ay * np.maximum(2.0 ** -22 * ax, 2.0 ** -25) + 2.0 ** -21.9 * ax * ay
+    assert np.all(np.abs(prod3 - exact) <= bound)
