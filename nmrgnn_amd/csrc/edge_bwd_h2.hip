@@ -19,7 +19,9 @@
 //
 // Mapping.  512 threads = 8 waves (2 per SIMD), one persistent workgroup per CU, 64-edge tiles.
 // Every GEMM operand that comes from activations lives in LDS as an fp16-piece IMAGE [2 pieces][64 edges][136]:
-// three images (Z-type, G ping, G pong) = 101 KB.  Elementwise work is done ONCE per element in the accumulator
+// four images (Z-type x 2, G ping, G pong) = 134 KB; with the second Z-type image a tile needs FOUR barriers
+// (after the staging writes, after phase A, after phase B, after phase C) instead of the seven of the
+// three-image schedule.  Elementwise work is done ONCE per element in the accumulator
 // layout of the dZ GEMM (lane = edge row, 16 columns of the wave's 32-column slab): the lane that loads Z_l from
 // HBM in that layout splits it into the image AND keeps the fp32 values for s'(Z_l) in its own epilogue.
 //   dZ GEMM (wave: k-slab zk = w&3, edge half zrt = w>>2): A = W^T pieces streamed from a fragment-ordered image
@@ -55,12 +57,12 @@ constexpr int HX_IMG_G = 2 * HX_PIECE_G;     // 34,816 B
 constexpr int HX_IMG_Z = 2 * HX_PIECE_Z;     // 33,792 B
 constexpr int HX_STG = 132;                  // fp32 staging row stride (floats)
 constexpr int HX_MISC_FLOATS = FH * 4 + FTM * 4 + FH;   // sWo4 | sdE | sCen
-constexpr int HX_IMGS = HX_IMG_Z + 2 * HX_IMG_G;
+constexpr int HX_IMGS = 2 * HX_IMG_Z + 2 * HX_IMG_G;     // two Z-type images (the fp16 pieces freed the room)
 #ifdef HX_STAMP
 constexpr int HX_LDS_BYTES = HX_IMGS + HX_MISC_FLOATS * 4 + 1024;
 #else
 constexpr int HX_LDS_BYTES = HX_IMGS + HX_MISC_FLOATS * 4;
-#endif             // 106,752 of 163,840
+#endif             // 140,544 of 163,840
 constexpr int HX_WS = 8;                     // log2 of the W^T scale
 constexpr float HX_WSCALE = (float)(1 << HX_WS), HX_WINV = 1.0f / (float)(1 << HX_WS);
 
@@ -263,9 +265,10 @@ __device__ __forceinline__ void hx_sprime2(float& x0, float& x1, float z0, float
 
 __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_hx[];
-  char* IZ = smem_hx;                           // Z2 -> Z1 -> R
-  char* GA = smem_hx + HX_IMG_Z;                // G3 -> G1
-  char* GB = smem_hx + HX_IMG_Z + HX_IMG_G;     // fp32 Z3 staging -> G2
+  char* IZ = smem_hx;                           // Z2 -> R
+  char* IZb = smem_hx + HX_IMG_Z;               // Z1 (second Z-type image: its writes need no barrier of their own)
+  char* GA = smem_hx + 2 * HX_IMG_Z;            // G3 -> G1
+  char* GB = smem_hx + 2 * HX_IMG_Z + HX_IMG_G; // fp32 Z3 staging -> G2
   float* stg = reinterpret_cast<float*>(GB);
   float* sWo4 = reinterpret_cast<float*>(smem_hx + HX_IMGS);      // [128][4]
   float* sdE = sWo4 + FH * 4;         // [64][4]
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
     HX_T(4);
     // ------------------------------------------------------------------ phase B (layer 3)
     // the two waves of a SIMD (zrt = 0 / 1) take the two independent GEMMs of the phase in opposite order, so that
-    // one wave's epilogue (VALU: s', bias sums, split) runs beside the other's MFMAs
+    // one wave's epilogue (VALU: s', split) runs beside the other's MFMAs
     if (zrt == 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
     HX_T(5);
     {
@@ -418,19 +421,20 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       HX_T(6);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z2r[r], z2r[r + 1]);
-      hx_img_write<HX_ROWG>(GB, prg, col0, g);       // G2
+      hx_img_write<HX_ROWG>(GB, prg, col0, g);       // G2  (the Z3 staging in GB was last read before the previous barrier)
     }
+    // Z1 pieces into the SECOND Z-type image: nobody reads IZb between the end of the previous tile's phase C and the
+    // next barrier, so this write needs no barrier pair of its own (with one Z image it waited for phase B's readers)
+    hx_img_write<HX_ROWZ>(IZb, prz, col0, z1r);
+    hx_wload(w0, wrs, lane * 16, ((0 * 4 + zk) * 8) * 2 * 1024, 0);
     HX_T(7);
     if (zrt != 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
     HX_T(8);
-    NG_LDS_BARRIER();
+    NG_LDS_BARRIER();      // G2, Z1 images complete; every reader of G3 (GA) and Z2 (IZ) is done
     HX_T(9);
-    hx_img_write<HX_ROWZ>(IZ, prz, col0, z1r);       // Z1 pieces
-    hx_wload(w0, wrs, lane * 16, ((0 * 4 + zk) * 8) * 2 * 1024, 0);
-    NG_LDS_BARRIER();
     HX_T(10);
     // ------------------------------------------------------------------ phase C (layer 2)
-    if (zrt == 0) hx_dw_gemm(accW[1], accB, 2, IZ, GB, kslab, nsl0, lane);
+    if (zrt == 0) hx_dw_gemm(accW[1], accB, 2, IZb, GB, kslab, nsl0, lane);
     {
       float g[16];
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
@@ -443,11 +447,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z1r[r], z1r[r + 1]);
       hx_img_write<HX_ROWG>(GA, prg, col0, g);       // G1
     }
-    HX_T(11);
-    if (zrt != 0) hx_dw_gemm(accW[1], accB, 2, IZ, GB, kslab, nsl0, lane);
-    NG_LDS_BARRIER();
-    HX_T(12);
-    {   // R = m * rbf(d_eff)  ->  IZ   (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
+    {   // R = m * rbf(d_eff)  ->  IZ, free since the barrier above  (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
       float rr[16];
       const float dm = on ? dn : 1.0e19f;
 #pragma unroll
@@ -461,13 +461,17 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       }
       hx_img_write<HX_ROWZ>(IZ, prz, col0, rr);
     }
-    NG_LDS_BARRIER();
+    HX_T(11);
+    if (zrt != 0) hx_dw_gemm(accW[1], accB, 2, IZb, GB, kslab, nsl0, lane);
+    NG_LDS_BARRIER();      // G1, R images complete; every reader of G2 (GB) and Z1 (IZb) is done
+    HX_T(12);
     HX_T(13);
     // ------------------------------------------------------------------ phase D (layer 1)
     prefetch_z2(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
     hx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
     HX_T(14);
-    NG_LDS_BARRIER();
+    // no barrier here: the next tile's first writes go to the Z3 staging (GB) and sdE, which phase D does not touch; its
+    // first barrier stands between phase D's reads of GA / IZ and the next G3 / Z2 image writes
     HX_T(15);
   }
 
@@ -476,6 +480,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   if (blockIdx.x == 3 && tid < 128) a.stamps[tid] = sStamp[tid];
   __syncthreads();
 #endif
+  __syncthreads();     // the last tile's phase D still reads GA / IZ, which the epilogue below reuses
   // ---------------------------------------------------------------------- write this workgroup's partial
   float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
   {
