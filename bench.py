@@ -47,6 +47,8 @@ PEAK_MFMA_F16_TFLOPS = 2516.6   # dense fp16 (= bf16): 256 CU x 4 SIMD x 1024 fl
 # share of the kernel time) is LOWER for a FASTER kernel: the remainder is VALU issue time (softplus, splits, RBF),
 # which adds to matrix time on a gfx950 SIMD.
 H2_KERNELS = {"edge_fwd_h2", "edge_bwd_h2"}
+# window kernels whose matrix phase runs on the fp16 pipe unless NG_GEMM_MATH=fp32 (mp_win.hip)
+H2_WINDOW_KERNELS = {"mp_win_fwd"}
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 achievable
 
 ARCH = dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
@@ -256,7 +258,8 @@ def roofline_rows(prof, psteps, work, x3_gemm):
         row = {"kernel": name, "launches_per_step": cnt / psteps, "avg_ms": avg_ms, "ms_per_step": tot_ms / psteps}
         if name in work and avg_ms > 0:
             _, fl, by = work[name]
-            on_h2 = name in H2_KERNELS or (x3_gemm and name in X3_GEMM_TAGS)
+            on_h2 = name in H2_KERNELS or (x3_gemm and name in X3_GEMM_TAGS) or (
+                name in H2_WINDOW_KERNELS and os.environ.get("NG_GEMM_MATH", "") != "fp32")
             peak_tf = PEAK_MFMA_F16_TFLOPS / 3.0 if on_h2 else PEAK_MFMA_F32_TFLOPS
             # both rooflines, the binding one is reported: floor = max(flops at the matrix peak, bytes at the HBM peak)
             t_mfma = fl / (peak_tf * 1e12) * 1e3 if fl > 0 else 0.0

@@ -33,6 +33,7 @@
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
 #include "edge_fused.h"   // NG_LDS_BARRIER
+#include "h2_common.cuh"
 
 namespace ng {
 
@@ -77,6 +78,26 @@ __global__ void mpw_pack_kernel(int E, int mode0, const float* __restrict__ w, f
     }
     out[idx] = v;
   }
+}
+
+// ---- weight fragments for v_mfma_f32_16x16x32_f16 with two-piece operands (forward, h2_common.cuh) ----
+// out[(((ct*NT2 + T)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of 2^8 Wsrc(k = 32T + 8(lane>>4) + t,
+// o = 16ct + (lane&15)),  Wsrc(k = n*64 + l, o = m) = w[l][m][n]  (mode 0 above)
+__global__ void mpw_pack_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ out) {
+  const int KF = E * WF, NT2 = KF / 32;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (ct, T, lane)
+  if (idx >= 4 * NT2 * 64) return;
+  const int lane = idx & 63, T = (idx >> 6) % NT2, ct = (idx >> 6) / NT2;
+  const int o = 16 * ct + (lane & 15);
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k0 = 32 * T + 8 * (lane >> 4) + 2 * j, k1 = k0 + 1;
+    split2_pair(256.0f * w[((k0 % WF) * WF + o) * E + k0 / WF], 256.0f * w[((k1 % WF) * WF + o) * E + k1 / WF], h[j], l[j]);
+  }
+  unsigned* d = out + ((size_t)((ct * NT2 + T) * 2) * 64 + lane) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
 }
 
 int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
@@ -219,6 +240,38 @@ __device__ __forceinline__ void win_stage(float4* __restrict__ win4, const float
 }
 static_assert(WROWS * WC4 == 9 * WTHREADS, "window staging assumes 9 float4 per thread");
 
+// ---- aggregate tile in LDS -------------------------------------------------------------------------------
+// H2 = false: fp32 rows [32][E*64 + 4].  H2 = true: two fp16 piece planes [2][32][E*64 + 8] (h2_common.cuh): the gather
+// splits its sums where they are formed and the matrix phase runs on v_mfma_f32_16x16x32_f16 (18 instead of 48 MFMAs
+// per wave and tile at E = 3); aggregates are O(1-10) activations and are split unscaled.
+template <int E>
+struct WinTile {
+  static constexpr int KF = E * WF;
+  static constexpr int LD = KF + 4;                    // fp32 row stride (floats)
+  static constexpr int ROWB = (KF + 8) * 2;            // fp16 plane row stride (bytes): 16 rows on disjoint 4-bank groups
+  static constexpr int PLANE = WTA * ROWB;
+  static constexpr int BYTES_F32 = WTA * LD * 4, BYTES_H2 = 2 * PLANE;
+};
+
+template <int E, bool H2>
+__device__ __forceinline__ void tile_put(float* __restrict__ tb, int al, int c, const f32x2 (&lo)[E], const f32x2 (&hi)[E]) {
+  if (H2) {
+    char* p = reinterpret_cast<char*>(tb) + al * WinTile<E>::ROWB + 8 * c;
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+      unsigned h0, l0, h1, l1;
+      split2_pair(lo[n][0], lo[n][1], h0, l0);
+      split2_pair(hi[n][0], hi[n][1], h1, l1);
+      *reinterpret_cast<u32x2*>(p + n * (WF * 2)) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(p + n * (WF * 2) + WinTile<E>::PLANE) = u32x2{l0, l1};
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < E; ++n)
+      *reinterpret_cast<float4*>(tb + al * WinTile<E>::LD + n * WF + 4 * c) = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
+  }
+}
+
 // ---- rotation gather (K <= 16, window mode) ------------------------------------------------------------
 // Lane c of an atom's 16-lane row owns neighbour slot c: ONE index and E weights per lane instead of
 // every lane reading the whole list (which cost as much LDS bandwidth as the row gather itself).  In
@@ -257,10 +310,10 @@ __device__ __forceinline__ void rot_fma4(const float4 (&h)[4], const float (&w)[
   for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ror_f<S0 + 3>(w[n]), h[3]);
 }
 
-template <int E>
+template <int E, bool H2>
 __device__ __forceinline__ void win_gather_rot(int K, int wave, int lane, int wlo,
                                                const int32_t* __restrict__ nl, const float* __restrict__ ee,
-                                               float* __restrict__ tb, int ld, const float4* __restrict__ win4) {
+                                               float* __restrict__ tb, const float4* __restrict__ win4) {
   const int c = lane & 15;
   const int al = wave * 4 + (lane >> 4);
   const int slot = al * K + (c < K ? c : 0);
@@ -286,19 +339,17 @@ __device__ __forceinline__ void win_gather_rot(int K, int wave, int lane, int wl
   __builtin_amdgcn_sched_barrier(0);
   rot_fma4<E, 8>(ha, w, lo, hi);
   rot_fma4<E, 12>(hb, w, lo, hi);
-#pragma unroll
-  for (int n = 0; n < E; ++n)
-    *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
+  tile_put<E, H2>(tb, al, c, lo, hi);
 }
 
 // gather + edge-weighted sum of one 32-atom tile: 16 lanes per atom, 4 atoms per wave, 8 waves.
 // MODE 0 reads rows from the LDS window, MODE 1 from global memory; a compile-time constant because
 // the window instance must not contain global loads (the compiler's vmcnt(0) in front of their use
 // would also wait for the list prefetch that is deliberately left in flight).
-template <int E, bool K4, int MODE>
+template <int E, bool K4, int MODE, bool H2>
 __device__ __forceinline__ void win_gather(int K, int wave, int lane, int wlo,
                                            const int32_t* __restrict__ nl, const float* __restrict__ ee,
-                                           float* __restrict__ tb, int ld, const float4* __restrict__ win4,
+                                           float* __restrict__ tb, const float4* __restrict__ win4,
                                            const float4* __restrict__ src4) {
   const int c = lane & 15;
   const int al = wave * 4 + (lane >> 4);
@@ -366,20 +417,16 @@ __device__ __forceinline__ void win_gather(int K, int wave, int lane, int wlo,
       for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ee[(al * K + j) * E + n], hv);
     }
   }
-#pragma unroll
-  for (int n = 0; n < E; ++n) {
-    const float4 v = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
-    *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = v;
-  }
+  tile_put<E, H2>(tb, al, c, lo, hi);
 }
 
 // The global-memory variant is kept out of line: inlined next to the window variant it makes the
 // compiler put vmcnt waits (for registers its loads may target) into the window gather, which then
 // stalls on the list prefetch in flight.
-template <int E, bool K4>
+template <int E, bool K4, bool H2>
 __device__ __noinline__ void win_gather_global(int K, int wave, int lane, const int32_t* nl, const float* ee,
-                                               float* tb, int ld, const float4* src4) {
-  win_gather<E, K4, 1>(K, wave, lane, 0, nl, ee, tb, ld, nullptr, src4);
+                                               float* tb, const float4* src4) {
+  win_gather<E, K4, 1, H2>(K, wave, lane, 0, nl, ee, tb, nullptr, src4);
 }
 
 // ---- forward ------------------------------------------------------------------------------------------
@@ -400,15 +447,16 @@ struct MpWinFwdArgs {
   float* dummy;            // 64 floats: where the lanes of rows >= N store
 };
 
-template <int E, bool K4>
+template <int E, bool K4, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a) {
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
-  constexpr int NT = KF / 16;
+  constexpr int NT = KF / 16, NT2 = KF / 32;
+  constexpr int TILE_FLOATS = (H2 ? WinTile<E>::BYTES_H2 : WinTile<E>::BYTES_F32) / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* win = smem;                                                   // [WROWS][64]
-  float* tile = win + WROWS * WF;                                      // [32][LD]
-  int32_t* s_nl = reinterpret_cast<int32_t*>(tile + WTA * LD);         // [2][32*K]
+  float* tile = win + WROWS * WF;                                      // [32][LD] fp32, or two fp16 piece planes (WinTile)
+  int32_t* s_nl = reinterpret_cast<int32_t*>(tile + TILE_FLOATS);      // [2][32*K]
   float* s_e = reinterpret_cast<float*>(s_nl + 2 * WTA * a.K);         // [2][32*K*E]
   int* ctl = reinterpret_cast<int*>(s_e + 2 * WTA * a.K * E);          // [2][16]
 
@@ -428,8 +476,17 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
 
   // this wave's weight slab (output columns 16ct..) resident in registers for the whole launch
   const int ct = wave & 3, hh = wave >> 2;
-  float wf[KF / 4];
-  {
+  float wf[H2 ? 1 : KF / 4];
+  u32x4 wh[H2 ? NT2 : 1], wl[H2 ? NT2 : 1];        // fp16 pieces of 2^8 W: A operands of v_mfma_f32_16x16x32_f16
+  if (H2) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(a.Wfrag) + (size_t)(ct * NT2) * 2 * 64 + lane;
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) { wh[T] = p[(2 * T) * 64]; wl[T] = p[(2 * T + 1) * 64]; }
+#pragma unroll
+    for (int T = 0; T < NT2; ++T)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(wh[T][j])); asm volatile("" : "+v"(wl[T][j])); }
+  } else {
     const float4* p = reinterpret_cast<const float4*>(a.Wfrag) + (ct * NT) * 64 + lane;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -472,32 +529,58 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
     {
       const int32_t* nl = s_nl + (t & 1) * per_tile;
       const float* ee = s_e + (t & 1) * per_tile * E;
-      if (mode == 0 && K <= 16) win_gather_rot<E>(K, wave, lane, wlo, nl, ee, tile, LD, win4);
-      else if (mode == 0) win_gather<E, K4, 0>(K, wave, lane, wlo, nl, ee, tile, LD, win4, src4);
-      else win_gather_global<E, K4>(K, wave, lane, nl, ee, tile, LD, src4);
+      if (mode == 0 && K <= 16) win_gather_rot<E, H2>(K, wave, lane, wlo, nl, ee, tile, win4);
+      else if (mode == 0) win_gather<E, K4, 0, H2>(K, wave, lane, wlo, nl, ee, tile, win4, src4);
+      else win_gather_global<E, K4, H2>(K, wave, lane, nl, ee, tile, src4);
     }
     NG_LDS_BARRIER();
     // ---- phase 2: tile x weights on the matrix cores, epilogue
     {
-      const float* xrow = tile + (16 * hh + a16) * LD + 4 * g;
-      // operand reads run two k-steps ahead of the MFMAs that consume them (pinned: left alone the
-      // scheduler hoists all of them to the top and the matrix pipe idles behind the LDS)
-      float4 x[NT];
-      x[0] = *reinterpret_cast<const float4*>(xrow);
-      x[1] = *reinterpret_cast<const float4*>(xrow + 16);
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float rsx = rs;
+      if (H2) {
+        // B operand: lane (atom a16, k-slots 8g..8g+7 of the 32-wide step) = 16 B of each piece plane; reads run two
+        // steps ahead.  acc0 collects the small products (l h, h l), acc1 the leading ones; the pieces carry 2^8.
+        const char* xrow = reinterpret_cast<const char*>(tile) + (16 * hh + a16) * WinTile<E>::ROWB + 16 * g;
+        u32x4 xh[NT2], xl[NT2];
 #pragma unroll
-      for (int T = 0; T < NT; ++T) {
-        if (T + 2 < NT) x[T + 2] = *reinterpret_cast<const float4*>(xrow + 16 * (T + 2));
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int T = 0; T < 2 && T < NT2; ++T) {
+          xh[T] = *reinterpret_cast<const u32x4*>(xrow + 64 * T);
+          xl[T] = *reinterpret_cast<const u32x4*>(xrow + 64 * T + WinTile<E>::PLANE);
+        }
+#pragma unroll
+        for (int T = 0; T < NT2; ++T) {
+          if (T + 2 < NT2) {
+            xh[T + 2] = *reinterpret_cast<const u32x4*>(xrow + 64 * (T + 2));
+            xl[T + 2] = *reinterpret_cast<const u32x4*>(xrow + 64 * (T + 2) + WinTile<E>::PLANE);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[T]), __builtin_bit_cast(f16x8, xh[T]), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[T]), __builtin_bit_cast(f16x8, xh[T]), acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[T]), __builtin_bit_cast(f16x8, xl[T]), acc0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        rsx = rs * (1.0f / 256.0f);
+      } else {
+        const float* xrow = tile + (16 * hh + a16) * LD + 4 * g;
+        // operand reads run two k-steps ahead of the MFMAs that consume them (pinned: left alone the
+        // scheduler hoists all of them to the top and the matrix pipe idles behind the LDS)
+        float4 x[NT];
+        x[0] = *reinterpret_cast<const float4*>(xrow);
+        x[1] = *reinterpret_cast<const float4*>(xrow + 16);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          if (T + 2 < NT) x[T + 2] = *reinterpret_cast<const float4*>(xrow + 16 * (T + 2));
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      float4 v = make_float4((acc0[0] + acc1[0]) * rs, (acc0[1] + acc1[1]) * rs, (acc0[2] + acc1[2]) * rs,
-                             (acc0[3] + acc1[3]) * rs);
+      float4 v = make_float4((acc0[0] + acc1[0]) * rsx, (acc0[1] + acc1[1]) * rsx, (acc0[2] + acc1[2]) * rsx,
+                             (acc0[3] + acc1[3]) * rsx);
       if (a.act == NG_ACT_SOFTPLUS) {
         v.x = softplus_f(v.x); v.y = softplus_f(v.y); v.z = softplus_f(v.z); v.w = softplus_f(v.w);
       } else if (a.act != NG_ACT_NONE) {
@@ -524,9 +607,13 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
 }
 
 size_t mp_win_lds_bytes(int K, int E) {
-  const int LD = E * WF + 4;
-  return (size_t)(WROWS * WF + WTA * LD + 2 * WTA * K * (1 + E) + 32) * 4;
+  // the larger of the two tile forms (fp32 rows, fp16 piece planes): the budget check is the same for both
+  const int tile_bytes = std::max(WTA * (E * WF + 4) * 4, 2 * WTA * (E * WF + 8) * 2);
+  return (size_t)(WROWS * WF + 2 * WTA * K * (1 + E) + 32) * 4 + tile_bytes;
 }
+
+// matrix phase of the forward window kernel on the fp16 pipe with two-piece operands unless NG_GEMM_MATH=fp32
+static bool mp_win_h2() { return !sw().gemm_math_fp32; }
 
 bool mp_win_supported(int F, int E, int K) {
   return F == WF && E >= 1 && E <= 3 && K >= 1 && K <= 32 && mp_win_lds_bytes(K, E) <= 160 * 1024;
@@ -542,10 +629,18 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   if (N == 0) return NG_OK;
   const int KF = E * WF;
   bool have = false;
-  float* Wfrag = (float*)cached_image(ctx, w, 4, (size_t)(KF * WF + 64) * 4, &have);
+  const bool h2 = mp_win_h2();
+  // both images take KF*64*4 bytes (fp32 fragments / two fp16 pieces); different cache kinds
+  float* Wfrag = (float*)cached_image(ctx, w, h2 ? 7 : 4, (size_t)(KF * WF + 64) * 4, &have);
   if (!Wfrag) Wfrag = (float*)workspace(ctx, (size_t)(KF * WF + 64) * 4);
   if (!Wfrag) return NG_ERR_NOMEM;
-  int rc = have ? NG_OK : mpw_pack(ctx, st, E, 0, w, Wfrag);
+  int rc = NG_OK;
+  if (!have && h2) {
+    hipLaunchKernelGGL(mpw_pack_h2_kernel, dim3((unsigned)cdiv(4 * (KF / 32) * 64, 256)), dim3(256), 0, st, E, w, (unsigned*)Wfrag);
+    NG_HIP(ctx, hipGetLastError());
+  } else if (!have) {
+    rc = mpw_pack(ctx, st, E, 0, w, Wfrag);
+  }
   if (rc) return rc;
   MpWinFwdArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
@@ -560,10 +655,14 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   const size_t lds = mp_win_lds_bytes(K, E);
   ProfScope ps(ctx, st, "mp_win_fwd");
 #define CALL(EE)                                                                                          \
-  if (K % 4 == 0)                                                                                         \
-    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true>), dim3(grid), dim3(WTHREADS), lds, st, a);            \
+  if (K % 4 == 0 && h2)                                                                                   \
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true, true>), dim3(grid), dim3(WTHREADS), lds, st, a);      \
+  else if (K % 4 == 0)                                                                                    \
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true, false>), dim3(grid), dim3(WTHREADS), lds, st, a);     \
+  else if (h2)                                                                                            \
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false, true>), dim3(grid), dim3(WTHREADS), lds, st, a);     \
   else                                                                                                    \
-    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false>), dim3(grid), dim3(WTHREADS), lds, st, a);
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false, false>), dim3(grid), dim3(WTHREADS), lds, st, a);
   switch (E) {
     case 1: { CALL(1) } break;
     case 2: { CALL(2) } break;
