@@ -106,6 +106,46 @@ int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float
   return NG_OK;
 }
 
+// backward images in ONE launch: blockIdx.y = 0 -> the dA = dP Wp^T image as fp16 piece fragments for
+// v_mfma_f32_16x16x32_f16 (mp_win_bwd_edge_kernel<E, true>):
+//   outT[(((ctile*2 + Ts)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of
+//   2^8 Wsrc2(k = 32 Ts + 8 (lane>>4) + t, o = 16 ctile + (lane&15)),  Wsrc2(k = m, o = n*64 + l) = w[l][m][n];
+// blockIdx.y = 1 -> the fp32 fragments of mode 1 (dh = B Wn)
+__global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ outT, float* __restrict__ outN) {
+  const int KF = E * WF;
+  if (blockIdx.y == 0) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (KF / 16) * 2 * 64; idx += gridDim.x * blockDim.x) {
+      const int lane = idx & 63, Ts = (idx >> 6) & 1, ctile = idx >> 7;
+      const int o = 16 * ctile + (lane & 15);
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = 32 * Ts + 8 * (lane >> 4) + 2 * j;
+        split2_pair(256.0f * w[((o % WF) * WF + k0) * E + o / WF], 256.0f * w[((o % WF) * WF + k0 + 1) * E + o / WF], h[j], l[j]);
+      }
+      unsigned* d = outT + ((size_t)((ctile * 2 + Ts) * 2) * 64 + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
+    }
+  } else {
+    const int NT = KF / 16;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < KF * WF; idx += gridDim.x * blockDim.x) {
+      int r = idx;
+      const int u = r & 3; r >>= 2;
+      const int lane = r & 63; r >>= 6;
+      const int T = r % NT, ct = r / NT;
+      const int k = 16 * T + 4 * (lane >> 4) + u, o = 16 * ct + (lane & 15);
+      outN[idx] = w[(o * WF + (k % WF)) * E + k / WF];
+    }
+  }
+}
+
+int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN) {
+  hipLaunchKernelGGL(mpw_pack_bwd_h2_kernel, dim3(24, 2), dim3(256), 0, st, E, w, (unsigned*)outT, outN);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 int mpw_pack2(ng_ctx* ctx, hipStream_t st, int E, const float* w, int mode_a, float* out_a, int mode_b, float* out_b) {
   hipLaunchKernelGGL(mpw_pack_kernel, dim3(24, 2), dim3(256), 0, st, E, mode_a, w, out_a, mode_b, out_b);
   NG_HIP(ctx, hipGetLastError());

@@ -23,6 +23,7 @@
 #include "ng_internal.h"
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "reduce.cuh"
+#include "h2_common.cuh"
 
 namespace ng {
 
@@ -167,7 +168,12 @@ __device__ __noinline__ void edge_dot_global(int K, int wave, int lane, const in
   for (int n = 0; n < E; ++n) out3[n] = out[n];
 }
 
-template <int E>
+// H2: the dA product on the fp16 pipe with two-piece operands (h2_common.cuh).  dP is a gradient of arbitrary
+// magnitude, and dA = dP Wp^T is independent per atom row: every row gets its OWN power-of-two scale, taken from the
+// row's max |dP| where the row is formed (commit: 16 lanes of a DPP row hold it) and kept beside the row in LDS
+// (columns 64 / 65 of the padded dP tile: S and 1/S); the lane that multiplies a row splits S * dP in registers and
+// multiplies its outputs by 2^-8 / S.  Scaling dH by 2^k moves every S by 2^-k: bit-identical scaled results.
+template <int E, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeArgs a) {
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
@@ -193,17 +199,31 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
 
   // weight fragments: this wave's NCT column tiles of dA (o = 16*ct + ...), contraction over m (4 k-steps)
   const int hh = wave >> 2, ct0 = (wave & 3) * NCT;
-  float wf[NCT][16];
+  float wf[H2 ? 1 : NCT][16];
+  u32x4 wh[H2 ? NCT : 1][2], wl[H2 ? NCT : 1][2];      // fp16 pieces of 2^8 Wp^T, two 32-wide k-steps per column tile
+  if (H2) {
 #pragma unroll
-  for (int u = 0; u < NCT; ++u) {
-    const float4* p = reinterpret_cast<const float4*>(a.WfragT) + ((ct0 + u) * 4) * 64 + lane;
+    for (int u = 0; u < NCT; ++u) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(a.WfragT) + (size_t)((ct0 + u) * 2) * 2 * 64 + lane;
 #pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      const float4 v = p[T * 64];
-      wf[u][4 * T + 0] = v.x; wf[u][4 * T + 1] = v.y; wf[u][4 * T + 2] = v.z; wf[u][4 * T + 3] = v.w;
+      for (int Ts = 0; Ts < 2; ++Ts) { wh[u][Ts] = p[(2 * Ts) * 64]; wl[u][Ts] = p[(2 * Ts + 1) * 64]; }
+#pragma unroll
+      for (int Ts = 0; Ts < 2; ++Ts)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(wh[u][Ts][j])); asm volatile("" : "+v"(wl[u][Ts][j])); }
     }
+  } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wf[u][i]));
+    for (int u = 0; u < NCT; ++u) {
+      const float4* p = reinterpret_cast<const float4*>(a.WfragT) + ((ct0 + u) * 4) * 64 + lane;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        const float4 v = p[T * 64];
+        wf[u][4 * T + 0] = v.x; wf[u][4 * T + 1] = v.y; wf[u][4 * T + 2] = v.z; wf[u][4 * T + 3] = v.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wf[u][i]));
+    }
   }
 
   // per-tile inputs in flight: neighbour indices (threads < 8K), this thread's float4 of dH and S
@@ -248,6 +268,18 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
     }
     g.x *= p_rs; g.y *= p_rs; g.z *= p_rs; g.w *= p_rs;
     *reinterpret_cast<float4*>(dp + prow * SDP_LD + 4 * pc) = g;
+    if (H2) {
+      // row max over the 16 lanes of this DPP row -> S = 2^(14 - e), 2^e > max (biased exponent arithmetic; an all-zero
+      // or non-finite row keeps S = 1)
+      float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+      m = fmaxf(m, ror_f<8>(m)); m = fmaxf(m, ror_f<4>(m)); m = fmaxf(m, ror_f<2>(m)); m = fmaxf(m, ror_f<1>(m));
+      const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
+      const int sb = (ef == 0 || ef == 255) ? 127 : min(267 - ef, 253);
+      if (pc == 0) {
+        dp[prow * SDP_LD + 64] = __builtin_bit_cast(float, sb << 23);
+        dp[prow * SDP_LD + 65] = __builtin_bit_cast(float, (254 - sb) << 23);
+      }
+    }
     const int64_t row = t * WTA + prow;
     *reinterpret_cast<float4*>(row < a.N ? a.dP + row * WF + 4 * pc : a.dummy + 4 * pc) = g;
     lo = wave_min_i32(lo);
@@ -268,13 +300,42 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
     if (win_decide(ctl + (t & 1) * 16, wlo, mode)) win_stage(win4, src4, wlo, a.N, tid);
     // ---- matrix interval: dA tile = dP tile x Wp^T
     {
+      f32x4 acc[NCT];
+#pragma unroll
+      for (int u = 0; u < NCT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float oscale = 1.0f;
+      if (H2) {
+        // B operand of step Ts: this lane's row (atom a16), k-slots 32 Ts + 8 g4 + (0..7), scaled and split here
+        const float* xr = sdp + (t & 1) * WTA * SDP_LD + (16 * hh + a16) * SDP_LD;
+        const float S = xr[64];
+        oscale = xr[65] * (1.0f / 256.0f);
+        u32x4 xh[2], xl[2];
+#pragma unroll
+        for (int Ts = 0; Ts < 2; ++Ts) {
+          const float4 v0 = *reinterpret_cast<const float4*>(xr + 32 * Ts + 8 * g4);
+          const float4 v1 = *reinterpret_cast<const float4*>(xr + 32 * Ts + 8 * g4 + 4);
+          unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+          split2_pair(S * v0.x, S * v0.y, h0, l0); split2_pair(S * v0.z, S * v0.w, h1, l1);
+          split2_pair(S * v1.x, S * v1.y, h2, l2); split2_pair(S * v1.z, S * v1.w, h3, l3);
+          xh[Ts] = u32x4{h0, h1, h2, h3}; xl[Ts] = u32x4{l0, l1, l2, l3};
+        }
+#pragma unroll
+        for (int Ts = 0; Ts < 2; ++Ts) {
+#pragma unroll
+          for (int u = 0; u < NCT; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[u][Ts]), __builtin_bit_cast(f16x8, xh[Ts]), acc[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NCT; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[u][Ts]), __builtin_bit_cast(f16x8, xl[Ts]), acc[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NCT; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[u][Ts]), __builtin_bit_cast(f16x8, xh[Ts]), acc[u], 0, 0, 0);
+        }
+      } else {
       const float* xrow = sdp + (t & 1) * WTA * SDP_LD + (16 * hh + a16) * SDP_LD + 4 * g4;
       float4 x[4];
 #pragma unroll
       for (int T = 0; T < 4; ++T) x[T] = *reinterpret_cast<const float4*>(xrow + 16 * T);
-      f32x4 acc[NCT];
-#pragma unroll
-      for (int u = 0; u < NCT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int T = 0; T < 4; ++T) {
 #pragma unroll
@@ -286,11 +347,12 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
 #pragma unroll
         for (int u = 0; u < NCT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][4 * T + 3], x[T].w, acc[u], 0, 0, 0);
       }
+      }
       // lane holds dA[atom 16hh + a16][o = 16(ct0+u) + 4*g4 + (0..3)]
 #pragma unroll
       for (int u = 0; u < NCT; ++u)
         *reinterpret_cast<float4*>(tile + (16 * hh + a16) * LD + 16 * (ct0 + u) + 4 * g4) =
-            make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+            make_float4(acc[u][0] * oscale, acc[u][1] * oscale, acc[u][2] * oscale, acc[u][3] * oscale);
     }
     NG_LDS_BARRIER();
     // ---- vector interval: de of tile t, then dP / lists of tile t+1 into LDS, requests for t+2
@@ -651,6 +713,9 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
   return NG_OK;
 }
 
+// the dA product of the edge kernel on the fp16 pipe with two-piece operands unless NG_GEMM_MATH=fp32
+static bool mp_win_bwd_h2() { return !sw().gemm_math_fp32; }
+
 bool mp_win_bwd_supported(int F, int E, int K) {
   return F == WF && E >= 1 && E <= 3 && K % 4 == 0 && K >= 4 && K <= 16;
 }
@@ -669,10 +734,18 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
   const int grid = (int)cdiv(a.ntiles, per);
   const size_t lds = edge_lds_bytes(K, E);
   ProfScope ps(ctx, st, "mp_win_bwd_edge");
-  switch (E) {
-    case 1: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<1>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-    case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+  if (mp_win_bwd_h2()) {
+    switch (E) {
+      case 1: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<1, true>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2, true>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3, true>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    }
+  } else {
+    switch (E) {
+      case 1: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<1, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    }
   }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
@@ -699,7 +772,8 @@ int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, co
   float* rec = dP + N * WF;
   float* scr = rec + rec_floats;
   float* dummy = scr + dw_scr;
-  int rc = mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // both weight images in one launch
+  int rc = mp_win_bwd_h2() ? mpw_pack_bwd_h2(ctx, st, E, w, WfragT, WfragN)
+                           : mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // both weight images in one launch
   if (rc) return rc;
   rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum, dummy);
   if (rc) return rc;

@@ -90,3 +90,49 @@ def test_mp_layer_bwd_vs_numpy(gpu_device, monkeypatch, path, kind, N, K, E, act
                                       ptr(tw), None, ptr(tS), ptr(csc_ptr), ptr(csc_edge), ptr(tdH), ptr(tdh2),
                                       ptr(tde2), 0, ptr(tdw2)), "bwd2")
     assert torch.equal(tdh2, tdh) and torch.equal(tdw2, tdw)
+
+
+@pytest.mark.parametrize("shift", [-50, -20, 12, 35])
+def test_mp_layer_bwd_scales_exactly_with_the_upstream_gradient(gpu_device, shift):
+    """The window edge kernel forms dA = dP Wp^T on the fp16 pipe with two-piece operands and a power-of-two scale PER ATOM
+    ROW taken from the row's max |dP| (mp_win_bwd.hip), so tiny gradients keep their bits.  Property: dH * 2^shift gives
+    de, dh and dw times 2^shift bit for bit (fp32 arithmetic is homogeneous under powers of two away from under/overflow)."""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    from nmrgnn_amd.graph import GraphBatch
+    N, K, E, F, act = 1000, 16, 3, 64, 1
+    rng = np.random.default_rng(3)
+    nl, e = make_case("local", N, K, E, rng)
+    h = rng.standard_normal((N, F)) * 0.5
+    inv = rng.random(N)
+    w = rng.standard_normal((F, F, E)) * 0.1
+    dH = rng.standard_normal((N, F)).astype(np.float32)
+    dH[5] = 0.0                                             # an all-zero row keeps S = 1
+    S, _, _, _ = ref_bwd(h, nl, e, inv, w, dH.astype(np.float64), act)
+    dev = gpu_device
+    t = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    edges = (np.abs(e).sum(-1) > 0).astype(np.float32)
+    gb = GraphBatch(np.eye(10, dtype=np.float32)[rng.integers(0, 10, N)], nl, edges, inv, device=dev)
+    csc_ptr, csc_edge = gb.csc()
+    th, te, tinv, tw, tS = t(h), t(e), t(inv), t(w), t(S)
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(dh_up):
+        tdH = t(dh_up)
+        tdh = torch.empty(N, F, device=dev); tdw = torch.empty(F, F, E, device=dev); tde = torch.zeros(N, K, E, device=dev)
+        ctx.check(ctx.lib.ng_mp_layer_bwd(ctx.handle, st, N, K, F, E, act, ptr(th), ptr(gb.nlist_c), ptr(te), ptr(tinv),
+                                          ptr(tw), None, ptr(tS), ptr(csc_ptr), ptr(csc_edge), ptr(tdH), ptr(tdh),
+                                          ptr(tde), 0, ptr(tdw)), "bwd")
+        torch.cuda.synchronize()
+        return [x.cpu().numpy().astype(np.float64) for x in (tdh, tdw, tde)]
+
+    base = run(dH)
+    moved = run((dH.astype(np.float64) * 2.0 ** shift).astype(np.float32))
+    live = np.abs(e).sum(-1) > 0
+    for k, (a, b) in enumerate(zip(moved, base)):
+        if k == 2:
+            a, b = a[live], b[live]
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b * 2.0 ** shift), k
