@@ -646,6 +646,209 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
   }
 }
 
+// ---- window-resident neighbour aggregation for the reference's default width (F % 128 == 0, e.g. 256) -------------
+//   A[i][n][:] = sum_j e[i][j][n] * h[nlist[i][j]][:]          (nmrgnn/layers.py:39-40, first contraction)
+// At F = 256 the generic kernel (node_ops.hip: aggregate_kernel) pulls every gathered row out of L2 once per
+// referencing edge — 2.1 GB per launch at the bench batch, ~14 TB/s of L2 traffic, 190 us.  Here a persistent
+// 512-thread workgroup walks its run of 32-atom tiles once per 128-column SLAB of h with a 272-row window of that slab
+// in LDS (136 KB), so a row leaves L2 once per run and slab; the gathers hit LDS.  Same skeleton as the F = 64 kernels
+// (lists one tile ahead through registers, restage when a tile's range leaves the window, global-memory gather when
+// the range is wider than the window).  Neighbours are summed in ENTRY order with fused multiply-adds, exactly like
+// the generic and the CSR kernels: the three agree bit for bit (tests/test_gpu_csr.py).
+constexpr int AW_ROWS = 272;          // window rows
+constexpr int AW_SLAB = 128;          // floats per slab row
+constexpr int AW_C4 = AW_SLAB / 4;    // 32 float4 per slab row: lane c of an atom's 16 lanes owns chunks c and c + 16
+
+struct AggWinArgs {
+  int64_t N;
+  int K, F;
+  int64_t ntiles;
+  int tiles_per_wg;
+  const float* h;          // [N][F]
+  const int32_t* nlist;    // [N][K]
+  const float* e;          // [N*K][E]
+  float* A;                // [N][E][F]
+};
+
+__device__ __forceinline__ bool aw_decide(const int* __restrict__ ctl, int& wlo, int& mode) {
+  int lo = ctl[0], hi = ctl[8];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) { lo = min(lo, ctl[i]); hi = max(hi, ctl[8 + i]); }
+  mode = 0;
+  if (hi < lo) return false;                                  // empty tile
+  if (lo >= wlo && hi < wlo + AW_ROWS) return false;          // window hit
+  if (hi - lo + 1 > AW_ROWS) { mode = 1; return false; }      // too wide: gather from global memory
+  wlo = max(0, lo - (AW_ROWS - (hi - lo + 1)) / 2);
+  return true;
+}
+
+__device__ __forceinline__ void aw_stage(float4* __restrict__ win4, const float4* __restrict__ src4, int f4n, int slab,
+                                         int wlo, int64_t N, int tid) {
+  float4 v[17];
+#pragma unroll
+  for (int u = 0; u < 17; ++u) {
+    const int idx = tid + WTHREADS * u;
+    const int64_t row = (int64_t)wlo + (idx >> 5);
+    v[u] = row < N ? src4[row * f4n + AW_C4 * slab + (idx & 31)] : f4zero();
+  }
+#pragma unroll
+  for (int u = 0; u < 17; ++u) win4[tid + WTHREADS * u] = v[u];
+}
+static_assert(AW_ROWS * AW_C4 == 17 * WTHREADS, "slab window staging assumes 17 float4 per thread");
+
+// one 32-atom tile: 16 lanes per atom, each lane two float4 chunks (c, c + 16) of the slab; eight neighbours per round
+template <int E, int MODE>
+__device__ __forceinline__ void aw_gather(int K, int wave, int lane, int wlo, const int32_t* __restrict__ nl,
+                                          const float* __restrict__ ee, const float4* __restrict__ win4,
+                                          const float4* __restrict__ src4, int f4n, int slab, float* __restrict__ Arow) {
+  const int c = lane & 15;
+  const int al = wave * 4 + (lane >> 4);
+  f32x2 lo[2][E], hi[2][E];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int n = 0; n < E; ++n) { lo[k][n] = f32x2{0.f, 0.f}; hi[k][n] = f32x2{0.f, 0.f}; }
+  const int4* nl4 = reinterpret_cast<const int4*>(nl + al * K);
+  const float4* e4 = reinterpret_cast<const float4*>(ee + al * K * E);
+  const int ng = K / 4;
+#pragma unroll 1
+  for (int g0 = 0; g0 < ng; g0 += 2) {
+    int4 r4[2];
+    float4 ev4[2][E];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gq = g0 + q < ng ? g0 + q : ng - 1;
+      r4[q] = nl4[gq];
+#pragma unroll
+      for (int n = 0; n < E; ++n) ev4[q][n] = e4[gq * E + n];
+    }
+    float4 hv[8][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int rr[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE == 0) {
+          const int r = min(max(rr[u] - wlo, 0), AW_ROWS - 1);     // padded slots stay inside the window (weight 0)
+          hv[4 * q + u][0] = win4[r * AW_C4 + c];
+          hv[4 * q + u][1] = win4[r * AW_C4 + c + 16];
+        } else {
+          hv[4 * q + u][0] = src4[(int64_t)rr[u] * f4n + AW_C4 * slab + c];
+          hv[4 * q + u][1] = src4[(int64_t)rr[u] * f4n + AW_C4 * slab + c + 16];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (g0 + q < ng) {
+        float ev[4 * E];
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+          ev[4 * n + 0] = ev4[q][n].x; ev[4 * n + 1] = ev4[q][n].y;
+          ev[4 * n + 2] = ev4[q][n].z; ev[4 * n + 3] = ev4[q][n].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int n = 0; n < E; ++n) {
+            pk_axpy(lo[0][n], hi[0][n], ev[u * E + n], hv[4 * q + u][0]);
+            pk_axpy(lo[1][n], hi[1][n], ev[u * E + n], hv[4 * q + u][1]);
+          }
+      }
+    }
+  }
+  // Arow: this atom's A[i][0][slab columns] (nullptr for rows past the end); written once, read by a later kernel
+  if (Arow) {
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+      nt4* d = reinterpret_cast<nt4*>(Arow) + n * f4n + c;
+      __builtin_nontemporal_store(nt4{lo[0][n][0], lo[0][n][1], hi[0][n][0], hi[0][n][1]}, d);
+      __builtin_nontemporal_store(nt4{lo[1][n][0], lo[1][n][1], hi[1][n][0], hi[1][n][1]}, d + 16);
+    }
+  }
+}
+
+template <int E>
+__device__ __noinline__ void aw_gather_global(int K, int wave, int lane, const int32_t* nl, const float* ee,
+                                              const float4* src4, int f4n, int slab, float* Arow) {
+  aw_gather<E, 1>(K, wave, lane, 0, nl, ee, nullptr, src4, f4n, slab, Arow);
+}
+
+template <int E>
+__global__ __launch_bounds__(WTHREADS, 1) void agg_win_kernel(AggWinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* win = smem;                                                        // [AW_ROWS][AW_SLAB]
+  int32_t* s_nl = reinterpret_cast<int32_t*>(win + AW_ROWS * AW_SLAB);      // [2][32*K]
+  float* s_e = reinterpret_cast<float*>(s_nl + 2 * WTA * a.K);              // [2][32*K*E]
+  int* ctl = reinterpret_cast<int*>(s_e + 2 * WTA * a.K * E);               // [2][16]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K, per_tile = WTA * K, f4n = a.F / 4;
+  const int64_t T0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+  const int64_t T1 = std::min<int64_t>(T0 + a.tiles_per_wg, a.ntiles);
+  if (T0 >= T1) return;
+  const float4* src4 = reinterpret_cast<const float4*>(a.h);
+  float4* win4 = reinterpret_cast<float4*>(win);
+  const int al = wave * 4 + (lane >> 4);
+
+#pragma unroll 1
+  for (int slab = 0; slab < a.F / AW_SLAB; ++slab) {
+    for (int t = tid; t < AW_ROWS * AW_C4; t += WTHREADS) win4[t] = f4zero();   // clamped reads must hit finite values
+    WinLists<E, true> lists;
+    int wlo = -(1 << 30), mode = 0;
+    lists.issue(a.nlist, a.e, T0, K, a.N, tid);
+    lists.commit(s_nl + (T0 & 1) * per_tile, s_e + (T0 & 1) * per_tile * E, ctl + (T0 & 1) * 16, K, tid, wave, lane);
+    lists.issue(a.nlist, a.e, T0 + 1 < T1 ? T0 + 1 : T0, K, a.N, tid);
+    NG_LDS_BARRIER();
+    if (aw_decide(ctl + (T0 & 1) * 16, wlo, mode)) aw_stage(win4, src4, f4n, slab, wlo, a.N, tid);
+    NG_LDS_BARRIER();
+#pragma unroll 1
+    for (int64_t t = T0; t < T1; ++t) {
+      if (t + 1 < T1)
+        lists.commit(s_nl + ((t + 1) & 1) * per_tile, s_e + ((t + 1) & 1) * per_tile * E, ctl + ((t + 1) & 1) * 16, K, tid,
+                     wave, lane);
+      lists.issue(a.nlist, a.e, t + 2 < T1 ? t + 2 : t, K, a.N, tid);
+      const int32_t* nl = s_nl + (t & 1) * per_tile;
+      const float* ee = s_e + (t & 1) * per_tile * E;
+      const int64_t row = t * WTA + al;
+      float* Arow = row < a.N ? a.A + (row * E) * a.F + AW_SLAB * slab : nullptr;
+      if (mode == 0) aw_gather<E, 0>(K, wave, lane, wlo, nl, ee, win4, src4, f4n, slab, Arow);
+      else aw_gather_global<E>(K, wave, lane, nl, ee, src4, f4n, slab, Arow);
+      NG_LDS_BARRIER();      // lists of t+1 (and their range) are in LDS; every gather of tile t is done
+      if (t + 1 < T1 && aw_decide(ctl + ((t + 1) & 1) * 16, wlo, mode)) {      // uniform over the workgroup
+        aw_stage(win4, src4, f4n, slab, wlo, a.N, tid);
+        NG_LDS_BARRIER();
+      }
+    }
+    NG_LDS_BARRIER();        // the next slab zeroes and restages the window
+  }
+}
+
+bool agg_win_supported(int F, int E, int K) {
+  return F % AW_SLAB == 0 && F <= 1024 && E >= 1 && E <= 3 && K % 4 == 0 && K >= 4 && K <= 16 && !sw().mp_layered;
+}
+
+int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
+            const float* e, float* A) {
+  AggWinArgs a{};
+  a.N = N; a.K = K; a.F = F; a.ntiles = cdiv(N, WTA);
+  int64_t per = cdiv(a.ntiles, ctx->num_cu);
+  per = cdiv(per, 8) * 8;      // runs start on molecule boundaries for the common 256-atom padding
+  a.tiles_per_wg = (int)per;
+  a.h = h; a.nlist = nlist; a.e = e; a.A = A;
+  const int grid = (int)cdiv(a.ntiles, per);
+  const size_t lds = (size_t)(AW_ROWS * AW_SLAB + 2 * WTA * K * (1 + E) + 32) * 4;
+  switch (E) {
+    case 1: hipLaunchKernelGGL((agg_win_kernel<1>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((agg_win_kernel<2>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((agg_win_kernel<3>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+  }
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 size_t mp_win_lds_bytes(int K, int E) {
   // the larger of the two tile forms (fp32 rows, fp16 piece planes): the budget check is the same for both
   const int tile_bytes = std::max(WTA * (E * WF + 4) * 4, 2 * WTA * (E * WF + 8) * 2);

@@ -154,6 +154,8 @@ static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
   if (N == 0) return NG_OK;
   if (E > MAX_E) return csr_aggregate(ctx, st, N, K, F, E, h, nullptr, nlist, e, A);
   ProfScope ps(ctx, st, "mp_aggregate");
+  // the reference's default width: slab windows in LDS instead of one L2 gather per edge (mp_win.hip)
+  if (agg_win_supported(F, E, K) && N >= 4096) return agg_win(ctx, st, N, K, F, E, h, nlist, e, A);
   const int apb = 256 / (F / 4);
   const size_t lds = (size_t)apb * K * (1 + E) * 4;
   const dim3 grid((unsigned)cdiv(N, apb));
