@@ -48,13 +48,19 @@ const char* ng_last_error(ng_ctx* ctx);
  * the environment once per process; ng_reload_env() parses them again (tests / A-B tools that flip one in-process). */
 int ng_reload_env(void);
 /* Inference with constant weights: between ng_weights_frozen(ctx, owner != 0) and ng_weights_frozen(ctx, 0) the library
- * keeps its packed weight images (MFMA fragment orders, bf16-piece images) across calls instead of re-packing them on
+ * keeps its packed weight images (MFMA fragment orders, fp16-piece images) across calls instead of re-packing them on
  * every call.  The images are keyed by the weight tensors' addresses, so `owner` names the model they belong to: a
  * call with a different non-zero owner discards what the cache holds (another model's freed weights may have had the
  * same addresses).  A change of a weight tensor of the current owner must be announced with ng_weights_changed(ctx)
  * (ng_adam_step does so itself).  Off (owner 0) is the default; calls made while it is off never touch the cache. */
 int ng_weights_frozen(ng_ctx* ctx, int owner);
 int ng_weights_changed(ng_ctx* ctx);
+/* Hint about the batch the following calls work on: the largest number of atoms of one member graph (the reference
+ * concatenates molecules with offset neighbour indices, nmrgnn/library.py:106-117, so a neighbour index lies within its
+ * own graph).  0 = unknown (default).  With 0 < span <= 272 the default-width neighbour aggregation (F % 128 == 0) keeps
+ * slab windows of the gathered rows in LDS; larger or unknown spans (whole proteins) take the L2-gather kernel.  Results
+ * do not depend on the hint. */
+int ng_ctx_set_graph_span(ng_ctx* ctx, int64_t max_graph_atoms);
 /* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
 int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
 

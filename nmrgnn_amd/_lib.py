@@ -34,6 +34,7 @@ SIGNATURES = {
     "ng_reload_env": (_int, []),
     "ng_weights_frozen": (_int, [_vp, _int]),
     "ng_weights_changed": (_int, [_vp]),
+    "ng_ctx_set_graph_span": (_int, [_vp, _i64]),
     "ng_prof_enable": (_int, [_vp, _int]),
     "ng_prof_reset": (_int, [_vp]),
     "ng_prof_read": (_int, [_vp, _int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),

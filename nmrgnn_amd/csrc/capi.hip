@@ -139,6 +139,12 @@ extern "C" int ng_weights_frozen(ng_ctx* ctx, int owner) {
   return NG_OK;
 }
 
+extern "C" int ng_ctx_set_graph_span(ng_ctx* ctx, int64_t max_graph_atoms) {
+  if (!ctx) return NG_ERR_INVALID;
+  ctx->graph_span = max_graph_atoms > 0 ? max_graph_atoms : 0;
+  return NG_OK;
+}
+
 extern "C" int ng_weights_changed(ng_ctx* ctx) {
   if (!ctx) return NG_ERR_INVALID;
   ctx->wver++;

@@ -826,6 +826,8 @@ __global__ __launch_bounds__(WTHREADS, 1) void agg_win_kernel(AggWinArgs a) {
   }
 }
 
+int agg_win_rows() { return AW_ROWS; }
+
 bool agg_win_supported(int F, int E, int K) {
   return F % AW_SLAB == 0 && F <= 1024 && E >= 1 && E <= 3 && K % 4 == 0 && K >= 4 && K <= 16 && !sw().mp_layered;
 }

@@ -33,6 +33,8 @@ struct ng_ctx {
   std::vector<hipEvent_t> pool;
   // cached device properties
   int num_cu = 256;
+  // largest member graph of the current batch (ng_ctx_set_graph_span), 0 = unknown
+  int64_t graph_span = 0;
   // packed weight images kept across calls while the caller declares the weights frozen (ng_weights_frozen):
   // inference repacks nothing.  key = (source pointer, image kind); an entry is valid while its version equals wver,
   // which ng_weights_changed / ng_adam_step / (un)freezing bump.

@@ -155,7 +155,10 @@ static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
   if (E > MAX_E) return csr_aggregate(ctx, st, N, K, F, E, h, nullptr, nlist, e, A);
   ProfScope ps(ctx, st, "mp_aggregate");
   // the reference's default width: slab windows in LDS instead of one L2 gather per edge (mp_win.hip)
-  if (agg_win_supported(F, E, K) && N >= 4096) return agg_win(ctx, st, N, K, F, E, h, nlist, e, A);
+  // (only for batches of small graphs, ng_ctx_set_graph_span: the lists of a whole protein leave any window, and the
+  // window kernel's global-memory fall-back is slower than the kernel below)
+  if (agg_win_supported(F, E, K) && N >= 4096 && ctx->graph_span > 0 && ctx->graph_span <= agg_win_rows())
+    return agg_win(ctx, st, N, K, F, E, h, nlist, e, A);
   const int apb = 256 / (F / 4);
   const size_t lds = (size_t)apb * K * (1 + E) * 4;
   const dim3 grid((unsigned)cdiv(N, apb));

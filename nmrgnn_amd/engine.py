@@ -137,6 +137,8 @@ class Engine:
         if batch.C != self.C:
             raise ValueError(f"atoms has {batch.C} element columns, model was built for {self.C}")
         ne = batch.n_edges
+        # locality hint for the default-width aggregation (results do not depend on it)
+        self._ck(lib.ng_ctx_set_graph_span(h, batch.max_graph_atoms), "ng_ctx_set_graph_span")
         d_src = batch.edges.reshape(-1)
         d_eff = d_src
         if training and self.sigma > 0:
@@ -220,6 +222,7 @@ class Engine:
         N, K, F, E, H = b.N, b.K, self.F, self.E, self.H
         Fh = F // 2
         ne = b.n_edges
+        self._ck(lib.ng_ctx_set_graph_span(h, b.max_graph_atoms), "ng_ctx_set_graph_span")
         dpeaks = dpeaks.contiguous()
         dg = self._new(N, Fh)
         self._ck(lib.ng_head_bwd(h, st, N, Fh, self.C, ptr(tp.g), ptr(tp.drop_mask),

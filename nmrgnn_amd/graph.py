@@ -137,6 +137,12 @@ class GraphBatch:
                                    self.inv_degree, graph_ptr=self.graph_ptr_host, device=self.device, validate=False)
 
     @property
+    def max_graph_atoms(self):
+        """atoms of the largest member graph (a hint for the engine: ng_ctx_set_graph_span)"""
+        gp = self.graph_ptr_host
+        return int(np.max(np.diff(gp))) if len(gp) > 1 else int(self.N)
+
+    @property
     def n_edges(self):
         return self.nnz if self.is_csr else self.N * self.K
 

@@ -165,3 +165,40 @@ def test_mplayer_kernel_regularizer_adds_a_loss(gpu_device):
     assert float(custom.losses[0]) == pytest.approx(3.0 * np.abs(custom.w.cpu().numpy()).max(), rel=1e-6)
     with pytest.raises(ValueError):
         nmrgnn_amd.MPLayer(kernel_regularizer='no-such-regularizer')
+
+
+@pytest.mark.parametrize("F,E,K,graph", [(256, 3, 16, 256), (128, 2, 8, 200), (256, 1, 16, 300)])
+def test_slab_window_aggregation_equals_the_gather_kernel(gpu_device, F, E, K, graph):
+    """At F % 128 == 0 and a batch of small graphs (ng_ctx_set_graph_span <= 272) ng_mp_aggregate keeps 128-column slab
+    windows of h in LDS (mp_win.hip: agg_win_kernel); it sums a row's neighbours in entry order with fused multiply-adds
+    like the L2-gather kernel, so the two agree BIT FOR BIT — also for graphs that straddle tiles (200, 300 atoms: tiles
+    whose range leaves the window restage it or gather from global memory) and for a ragged last tile."""
+    import ctypes as C
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    rng = np.random.default_rng(F + K)
+    G = 24
+    N = G * graph - 7                                   # ragged end
+    base = (np.arange(N) // graph) * graph
+    nl = np.minimum(base[:, None] + rng.integers(0, graph, (N, K)), N - 1).astype(np.int32)
+    e = rng.standard_normal((N, K, E)).astype(np.float32)
+    e[rng.random((N, K)) < 0.1] = 0.0
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    th, tn, te = (torch.from_numpy(a).to(gpu_device) for a in (h, nl, e))
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    out = {}
+    for span in (0, graph):
+        ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, span), "span")
+        A = torch.full((N, E, F), 7.0, device=gpu_device)
+        ctx.check(ctx.lib.ng_mp_aggregate(ctx.handle, st, N, K, F, E, ptr(th), ptr(tn), ptr(te), ptr(A)), "agg")
+        torch.cuda.synchronize()
+        out[span] = A
+    ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, 0), "span")
+    ref = np.einsum("ijn,ijl->inl", e.astype(np.float64), h.astype(np.float64)[nl])
+    assert np.abs(out[0].cpu().numpy() - ref).max() < 1e-4
+    if graph <= 272:
+        assert torch.equal(out[0], out[graph])
+    else:
+        assert torch.equal(out[0], out[graph])          # span above the window: the hint selects the gather kernel

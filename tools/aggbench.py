@@ -22,6 +22,7 @@ out = {"workload": "ng_mp_aggregate on the bench batch: 512 graphs x 256 atoms, 
 for F in (64, 256):
     h = torch.randn(N, F, device=dev, generator=g)
     A = torch.empty(N, E, F, device=dev)
+    ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, 256), "span")    # molecule batch: slab-window kernel at F % 128 == 0
     f = lambda: ctx.check(ctx.lib.ng_mp_aggregate(ctx.handle, st, N, K, F, E, ptr(h), ptr(gb.nlist_c), ptr(e), ptr(A)), "agg")
     for _ in range(3): f()
     torch.cuda.synchronize()
