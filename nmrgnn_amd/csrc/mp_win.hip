@@ -110,7 +110,7 @@ int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float
 // v_mfma_f32_16x16x32_f16 (mp_win_bwd_edge_kernel<E, true>):
 //   outT[(((ctile*2 + Ts)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of
 //   2^8 Wsrc2(k = 32 Ts + 8 (lane>>4) + t, o = 16 ctile + (lane&15)),  Wsrc2(k = m, o = n*64 + l) = w[l][m][n];
-// blockIdx.y = 1 -> the fp32 fragments of mode 1 (dh = B Wn)
+// blockIdx.y = 1 -> the dh = B Wn image in the same fp16 piece form (mp_win_bwd_node_kernel<E, true>)
 __global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ outT, float* __restrict__ outN) {
   const int KF = E * WF;
   if (blockIdx.y == 0) {
@@ -128,14 +128,21 @@ __global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsig
       for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
     }
   } else {
-    const int NT = KF / 16;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < KF * WF; idx += gridDim.x * blockDim.x) {
-      int r = idx;
-      const int u = r & 3; r >>= 2;
-      const int lane = r & 63; r >>= 6;
-      const int T = r % NT, ct = r / NT;
-      const int k = 16 * T + 4 * (lane >> 4) + u, o = 16 * ct + (lane & 15);
-      outN[idx] = w[(o * WF + (k % WF)) * E + k / WF];
+    // dh = B Wn image, same fragment form: Wsrc1(k = n*64 + m, o = l) = w[l][m][n], contraction over k (KF/32 steps)
+    const int NT2 = KF / 32;
+    unsigned* outNu = reinterpret_cast<unsigned*>(outN);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 4 * NT2 * 64; idx += gridDim.x * blockDim.x) {
+      const int lane = idx & 63, T = (idx >> 6) % NT2, ct = (idx >> 6) / NT2;
+      const int o = 16 * ct + (lane & 15);
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = 32 * T + 8 * (lane >> 4) + 2 * j, k1 = k0 + 1;
+        split2_pair(256.0f * w[(o * WF + (k0 % WF)) * E + k0 / WF], 256.0f * w[(o * WF + (k1 % WF)) * E + k1 / WF], h[j], l[j]);
+      }
+      unsigned* d = outNu + ((size_t)((ct * NT2 + T) * 2) * 64 + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
     }
   }
 }

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
 // ---- node kernel ---------------------------------------------------------------------------------------
 // Incoming-edge records in CSC order, 16 bytes each: { source atom (int bits), e[p][0..2] } — built once
 // per backward pass (the edge features are the same for every layer).
-constexpr int NREC_CAP = 1024;          // records staged per 32-atom tile (mean 16 * 32 = 512)
+constexpr int NREC_CAP = 768;           // records staged per 32-atom tile (mean 16 * 32 = 512); 1024 until the fp16 piece planes of B needed the room
 
 struct MpWinNodeArgs {
   int64_t N;
@@ -428,11 +428,14 @@ __device__ __forceinline__ void node_steps4(const char* __restrict__ wbytes, con
 
 // B[t][(n,m)] for the tile's 32 target atoms: 16 lanes per atom, the atom's incoming records taken 16 at a
 // time (lane c owns record 16*round + c), rotation walk as in the forward gather
+// pl (H2 form of the dh product): besides the fp32 tile (the dw product contracts over atoms and needs one scale for
+// all rows) the row goes into two fp16 piece planes [2][32][E*64 + 8], scaled by a power of two taken from the row's
+// own max |B| (the 16 lanes of a DPP row hold the whole row); rs[atom] receives 2^-8 / S for the epilogue.
 template <int E, int MODE>
 __device__ __forceinline__ void node_gather(int wave, int lane, int wlo, const int* __restrict__ s_ptr,
                                             const float4* __restrict__ recs, int rec_base,
                                             float* __restrict__ tb, int ld, const float4* __restrict__ win4,
-                                            const float4* __restrict__ src4) {
+                                            const float4* __restrict__ src4, char* __restrict__ pl, float* __restrict__ rs) {
   const int c = lane & 15;
   const int al = wave * 4 + (lane >> 4);
   const int p0 = s_ptr[al], cnt = s_ptr[al + 1] - p0;
@@ -464,19 +467,40 @@ __device__ __forceinline__ void node_gather(int wave, int lane, int wlo, const i
 #pragma unroll
   for (int n = 0; n < E; ++n)
     *reinterpret_cast<float4*>(tb + al * ld + n * WF + 4 * c) = make_float4(lo[n][0], lo[n][1], hi[n][0], hi[n][1]);
+  if (pl) {
+    float m = 0.f;
+#pragma unroll
+    for (int n = 0; n < E; ++n) m = fmaxf(fmaxf(m, fmaxf(fabsf(lo[n][0]), fabsf(lo[n][1]))), fmaxf(fabsf(hi[n][0]), fabsf(hi[n][1])));
+    m = fmaxf(m, ror_f<8>(m)); m = fmaxf(m, ror_f<4>(m)); m = fmaxf(m, ror_f<2>(m)); m = fmaxf(m, ror_f<1>(m));
+    const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
+    const int sb = (ef == 0 || ef == 255) ? 127 : min(267 - ef, 253);      // S = 2^(14 - e), 2^e > max; zero / non-finite rows: 1
+    const float S = __builtin_bit_cast(float, sb << 23);
+    if (c == 0) rs[al] = __builtin_bit_cast(float, (254 - sb) << 23) * (1.0f / 256.0f);
+    constexpr int ROWB = (E * WF + 8) * 2, PLANE = WTA * ROWB;
+    char* p = pl + al * ROWB + 8 * c;
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+      unsigned h0, l0, h1, l1;
+      split2_pair(S * lo[n][0], S * lo[n][1], h0, l0);
+      split2_pair(S * hi[n][0], S * hi[n][1], h1, l1);
+      *reinterpret_cast<u32x2*>(p + n * (WF * 2)) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(p + n * (WF * 2) + PLANE) = u32x2{l0, l1};
+    }
+  }
 }
 
 template <int E>
 __device__ __noinline__ void node_gather_global(int wave, int lane, const int* s_ptr, const float4* recs,
-                                                int rec_base, float* tb, int ld, const float4* src4) {
-  node_gather<E, 1>(wave, lane, 0, s_ptr, recs, rec_base, tb, ld, nullptr, src4);
+                                                int rec_base, float* tb, int ld, const float4* src4, char* pl, float* rs) {
+  node_gather<E, 1>(wave, lane, 0, s_ptr, recs, rec_base, tb, ld, nullptr, src4, pl, rs);
 }
 
-template <int E>
+template <int E, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeArgs a) {
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
-  constexpr int NT = KF / 16;
+  constexpr int NT = KF / 16, NT2 = KF / 32;
+  constexpr int ROWB = (KF + 8) * 2, PLANE = WTA * ROWB;     // fp16 piece planes of B (H2)
   constexpr int NCT = NT / 2;              // dw column tiles per wave: (lt = w & 3) x (NT/2 tiles of half w >> 2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* win = smem;                                                   // [WROWS][64]   dP rows
@@ -485,20 +509,32 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
   float4* s_rec = reinterpret_cast<float4*>(htile + WTA * SDP_LD);     // [2][NREC_CAP]
   int* s_ptr = reinterpret_cast<int*>(s_rec + 2 * NREC_CAP);           // [2][36]
   int* ctl = s_ptr + 2 * 36;                                           // [2][16]
+  float* s_rs = reinterpret_cast<float*>(ctl + 32);                    // [32]  2^-8 / S per atom row (H2)
+  char* planes = reinterpret_cast<char*>(s_rs + 32);                   // [2][32][ROWB] (H2)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t T0 = (int64_t)blockIdx.x * a.tiles_per_wg;
   const int64_t T1 = std::min<int64_t>(T0 + a.tiles_per_wg, a.ntiles);
   float* part = a.partial + (int64_t)blockIdx.x * (KF * WF);
+  char* const pl = H2 ? planes : nullptr;
 
   const float4* src4 = reinterpret_cast<const float4*>(a.dP);
   float4* win4 = reinterpret_cast<float4*>(win);
   for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
 
   const int ct = wave & 3, hh = wave >> 2;      // dh: column tile, atom half;  dw: l-tile ct, column half hh
-  float wf[KF / 4];
-  {
+  float wf[H2 ? 1 : KF / 4];
+  u32x4 wh[H2 ? NT2 : 1], wl[H2 ? NT2 : 1];      // fp16 pieces of 2^8 Wn: A operands of v_mfma_f32_16x16x32_f16
+  if (H2) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(a.WfragN) + (size_t)(ct * NT2) * 2 * 64 + lane;
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) { wh[T] = p[(2 * T) * 64]; wl[T] = p[(2 * T + 1) * 64]; }
+#pragma unroll
+    for (int T = 0; T < NT2; ++T)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(wh[T][j])); asm volatile("" : "+v"(wl[T][j])); }
+  } else {
     const float4* p = reinterpret_cast<const float4*>(a.WfragN) + (ct * NT) * 64 + lane;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -538,7 +574,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
       float4* rc = s_rec + (t & 1) * NREC_CAP;
       int* pp = s_ptr + (t & 1) * 36;
       rc[tid] = p_rec0;
-      rc[tid + WTHREADS] = p_rec1;
+      if (tid + WTHREADS < NREC_CAP) rc[tid + WTHREADS] = p_rec1;
       if (tid <= WTA) pp[tid] = p_ptr;
       // row range over the tile's OWN records only (the staging area also holds the head of later tiles)
       int lo = 0x7fffffff, hi = -1;
@@ -581,9 +617,9 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
         const bool fits = pp[WTA] - rec_base <= NREC_CAP;
         // a tile with more records than the staging area reads them from global memory instead (separate
         // call sites: the fast path must see an LDS pointer, not a generic one)
-        if (mode == 0 && fits) node_gather<E, 0>(wave, lane, wlo, pp, rc, rec_base, tile, LD, win4, src4);
-        else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4);
-        else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4);
+        if (mode == 0 && fits) node_gather<E, 0>(wave, lane, wlo, pp, rc, rec_base, tile, LD, win4, src4, pl, s_rs);
+        else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4, pl, s_rs);
+        else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4, pl, s_rs);
       }
       issue(t + 2 < T1 ? t + 2 : t);
       issue_rows(t + 1 < T1 ? t + 1 : t);
@@ -592,24 +628,50 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
       {
         // operand reads run two k-steps ahead of their MFMAs (pinned): holding all NT of them kept 48 VGPRs
         // live and pushed freshly requested prefetch registers into scratch — behind a vmcnt wait
-        const float* xrow = tile + (16 * hh + a16) * LD + 4 * g4;
-        float4 x[NT];
-        x[0] = *reinterpret_cast<const float4*>(xrow);
-        x[1] = *reinterpret_cast<const float4*>(xrow + 16);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float osc = 1.0f;
+        if (H2) {
+          // B operand: lane (atom a16, k-slots 8 g4 .. +7 of the 32-wide step) = 16 B of each piece plane, two steps
+          // ahead; acc0 collects the small products, acc1 the leading ones
+          const char* xrow = planes + (16 * hh + a16) * ROWB + 16 * g4;
+          osc = s_rs[16 * hh + a16];
+          u32x4 xh[NT2], xl[NT2];
 #pragma unroll
-        for (int T = 0; T < NT; ++T) {
-          if (T + 2 < NT) x[T + 2] = *reinterpret_cast<const float4*>(xrow + 16 * (T + 2));
-          __builtin_amdgcn_sched_barrier(0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int T = 0; T < 2 && T < NT2; ++T) {
+            xh[T] = *reinterpret_cast<const u32x4*>(xrow + 64 * T);
+            xl[T] = *reinterpret_cast<const u32x4*>(xrow + 64 * T + PLANE);
+          }
+#pragma unroll
+          for (int T = 0; T < NT2; ++T) {
+            if (T + 2 < NT2) {
+              xh[T + 2] = *reinterpret_cast<const u32x4*>(xrow + 64 * (T + 2));
+              xl[T + 2] = *reinterpret_cast<const u32x4*>(xrow + 64 * (T + 2) + PLANE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[T]), __builtin_bit_cast(f16x8, xh[T]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[T]), __builtin_bit_cast(f16x8, xh[T]), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[T]), __builtin_bit_cast(f16x8, xl[T]), acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          const float* xrow = tile + (16 * hh + a16) * LD + 4 * g4;
+          float4 x[NT];
+          x[0] = *reinterpret_cast<const float4*>(xrow);
+          x[1] = *reinterpret_cast<const float4*>(xrow + 16);
+#pragma unroll
+          for (int T = 0; T < NT; ++T) {
+            if (T + 2 < NT) x[T + 2] = *reinterpret_cast<const float4*>(xrow + 16 * (T + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], x[T].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 1], x[T].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 2], x[T].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 3], x[T].w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         const int64_t row = t * WTA + 16 * hh + a16;
-        const float4 v = make_float4(acc0[0] + acc1[0] + dHc.x, acc0[1] + acc1[1] + dHc.y,
-                                     acc0[2] + acc1[2] + dHc.z, acc0[3] + acc1[3] + dHc.w);
+        const float4 v = make_float4(fmaf(acc0[0] + acc1[0], osc, dHc.x), fmaf(acc0[1] + acc1[1], osc, dHc.y),
+                                     fmaf(acc0[2] + acc1[2], osc, dHc.z), fmaf(acc0[3] + acc1[3], osc, dHc.w));
         *reinterpret_cast<float4*>(row < a.N ? a.dh + row * WF + col : a.dummy + col) = v;
       }
       {
@@ -661,8 +723,9 @@ __global__ void mp_records_kernel(int64_t N, int K, int E, const int32_t* __rest
   }
 }
 
-size_t node_lds_bytes(int E) {
-  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + WTA * SDP_LD) * 4 + (size_t)2 * NREC_CAP * 16 + (2 * 36 + 32) * 4;
+size_t node_lds_bytes(int E, bool h2) {
+  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + WTA * SDP_LD) * 4 + (size_t)2 * NREC_CAP * 16 + (2 * 36 + 32 + 32) * 4 +
+         (h2 ? (size_t)2 * WTA * (E * WF + 8) * 2 : 0);
 }
 
 size_t edge_lds_bytes(int K, int E) {
@@ -670,6 +733,10 @@ size_t edge_lds_bytes(int K, int E) {
 }
 
 }  // namespace
+
+// the dA product of the edge kernel and the dh product of the node kernel on the fp16 pipe with two-piece operands
+// unless NG_GEMM_MATH=fp32
+static bool mp_win_bwd_h2() { return !sw().gemm_math_fp32; }
 
 int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
                    const int32_t* csc_edge, const float* e, float* rec) {
@@ -696,13 +763,17 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
   a.dP = dP; a.dH = dh_out; a.h = h; a.csc_ptr = csc_ptr; a.rec = reinterpret_cast<const float4*>(rec);
   a.WfragN = WfragN; a.dh = dh_in; a.partial = scratch; a.dummy = dummy;
   const int grid = (int)cdiv(a.ntiles, per);
-  const size_t lds = node_lds_bytes(E);
+  const bool h2 = mp_win_bwd_h2();
+  const size_t lds = node_lds_bytes(E, h2);
   {
     ProfScope ps(ctx, st, "mp_win_bwd_node");
     switch (E) {
-      case 1: hipLaunchKernelGGL((mp_win_bwd_node_kernel<1>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 2: hipLaunchKernelGGL((mp_win_bwd_node_kernel<2>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 3: hipLaunchKernelGGL((mp_win_bwd_node_kernel<3>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 1: if (h2) hipLaunchKernelGGL((mp_win_bwd_node_kernel<1, true>), dim3(grid), dim3(WTHREADS), lds, st, a);
+              else hipLaunchKernelGGL((mp_win_bwd_node_kernel<1, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 2: if (h2) hipLaunchKernelGGL((mp_win_bwd_node_kernel<2, true>), dim3(grid), dim3(WTHREADS), lds, st, a);
+              else hipLaunchKernelGGL((mp_win_bwd_node_kernel<2, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+      case 3: if (h2) hipLaunchKernelGGL((mp_win_bwd_node_kernel<3, true>), dim3(grid), dim3(WTHREADS), lds, st, a);
+              else hipLaunchKernelGGL((mp_win_bwd_node_kernel<3, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
     }
     NG_HIP(ctx, hipGetLastError());
   }
@@ -712,9 +783,6 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
-
-// the dA product of the edge kernel on the fp16 pipe with two-piece operands unless NG_GEMM_MATH=fp32
-static bool mp_win_bwd_h2() { return !sw().gemm_math_fp32; }
 
 bool mp_win_bwd_supported(int F, int E, int K) {
   return F == WF && E >= 1 && E <= 3 && K % 4 == 0 && K >= 4 && K <= 16;
