@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dw_kernel(GtArgs a) {
 // workgroups (the aggregate A [N, 768] of the MPLayer weight gradient once instead of twice, dP 3 x instead of 6 x).
 constexpr int GT8_ROWB = 528;                    // image row stride (bytes): 256 fp16 + 16, 132 dwords = 4 mod 64 banks
 constexpr int GT8_PLANE = 32 * GT8_ROWB;         // 16,896
-constexpr int GT8_LDS = 2 * 2 * GT8_PLANE;       // 67,584
+constexpr int GT8_LDS = 2 * 2 * 2 * GT8_PLANE;   // 135,168: two (X image, dP image) pairs
 
 __device__ __forceinline__ u32x4 gt8_tr_frag(const char* p) {
   const gx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gx_s16x4*)p);
@@ -815,8 +815,11 @@ __device__ __forceinline__ void gt8_store16(char* img, int prow, int col0, const
 
 __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_gt8[];
-  char* sXi = smem_gt8;                    // X image  [2][32][528 B]
-  char* sPi = smem_gt8 + 2 * GT8_PLANE;    // dP image
+  // two image pairs (the fp16 pieces freed the room): step s multiplies pair s & 1 while the rows of step s + 1 are split
+  // into the other pair — ONE barrier per 32-row step — and two register sets keep the rows of steps s + 1 and s + 2 in
+  // flight (a step is 48 MFMAs = 0.75 us since the move to two pieces, less than an HBM round trip under load)
+  char* const img0 = smem_gt8;             // X image [2][32][528 B] | dP image
+  char* const img1 = smem_gt8 + 4 * GT8_PLANE;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nh = wave & 1, kh = wave >> 1;           // n-blocks 4 nh .. 4 nh + 3, k-blocks 2 kh, 2 kh + 1
@@ -829,8 +832,8 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   const int lr = tid >> 4, lc = 16 * (tid & 15);
   const int e16 = lr & 15;
   const int prow = 16 * (lr >> 4) + 4 * (e16 & 3) + (e16 >> 2);   // see hx_prow_g in edge_bwd_h2.hip
-  float xv[16], pv[16];
-  auto load = [&](int64_t row) {
+  float xa[16], pa_[16], xb_[16], pb_[16];
+  auto load = [&](float (&xv)[16], float (&pv)[16], int64_t row) {
     const bool ok = row < r1;
     const int64_t rc = ok ? row : a.M - 1;
     const float* xp = a.X + rc * a.K + k0 + lc;
@@ -861,14 +864,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   const int g = lane >> 4, li = lane & 15;
   const int lane_off = (4 * (li >> 2) + 2 * (g >> 1)) * GT8_ROWB + (16 * (g & 1) + 4 * (li & 3)) * 2;
 
-  load(r0 + lr);
-#pragma unroll 1
-  for (int64_t rb = r0; rb < r1; rb += 32) {
-    NG_LDS_BARRIER();
-    gt8_store16(sXi, prow, lc, xv);
-    gt8_store16(sPi, prow, lc, pv);
-    NG_LDS_BARRIER();
-    load(rb + 32 + lr);                   // next step (rows past r1 load row M-1 and are zeroed)
+  auto multiply = [&](const char* sXi, const char* sPi) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 pa[4][2];
@@ -887,6 +883,27 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
         mma3_2a(pa[2], pa[3], xb, acc[2][i], acc[3][i]);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load(xa, pa_, r0 + lr);
+  load(xb_, pb_, r0 + 32 + lr);
+  gt8_store16(img0, prow, lc, xa);
+  gt8_store16(img0 + 2 * GT8_PLANE, prow, lc, pa_);
+  load(xa, pa_, r0 + 64 + lr);          // rows past r1 load row M-1 and are zeroed
+  NG_LDS_BARRIER();
+#pragma unroll 1
+  for (int64_t rb = r0; rb < r1; rb += 64) {
+    gt8_store16(img1, prow, lc, xb_);                       // rows rb + 32 (img1 was last read before the previous barrier)
+    gt8_store16(img1 + 2 * GT8_PLANE, prow, lc, pb_);
+    load(xb_, pb_, rb + 96 + lr);
+    multiply(img0, img0 + 2 * GT8_PLANE);                   // rows rb
+    NG_LDS_BARRIER();
+    if (rb + 32 < r1) {                                     // uniform over the workgroup
+      gt8_store16(img0, prow, lc, xa);                      // rows rb + 64
+      gt8_store16(img0 + 2 * GT8_PLANE, prow, lc, pa_);
+      load(xa, pa_, rb + 128 + lr);
+      multiply(img1, img1 + 2 * GT8_PLANE);                 // rows rb + 32
+      NG_LDS_BARRIER();
     }
   }
   // D rows = n (from dP), D cols = k (from X): lane holds k = k0 + 32 (2 kh + i) + l31, n = n0 + 32 (4 nh + j) + 8q + 4 half + (0..3)
