@@ -195,7 +195,7 @@ def cpu_baseline(hp_dict, sample_graphs, seed, budget_s=20.0):
 
 
 # kernels whose generic GEMM runs on the fp16 pipe with two-piece split operands when the shape allows (gemm_h2.hip)
-X3_GEMM_TAGS = {"mp_update_fwd", "mp_dw", "mp_dA", "dense_fwd", "dense_dx", "dense_dw", "edge_dense_fwd",
+H2_GEMM_TAGS = {"mp_update_fwd", "mp_dw", "mp_dA", "dense_fwd", "dense_dx", "dense_dw", "edge_dense_fwd",
                 "edge_dense_dx", "edge_dense_dw"}
 # kernel tag -> the source files whose content decides whether a committed PMC number still describes it
 KERNEL_SOURCES = {
@@ -251,14 +251,14 @@ def pmc_lookup(kernel):
     return traffic, busy, "; ".join(notes) or None
 
 
-def roofline_rows(prof, psteps, work, x3_gemm):
+def roofline_rows(prof, psteps, work, h2_gemm):
     rows = []
     for name, (tot_ms, cnt) in prof.items():
         avg_ms = tot_ms / max(cnt, 1)
         row = {"kernel": name, "launches_per_step": cnt / psteps, "avg_ms": avg_ms, "ms_per_step": tot_ms / psteps}
         if name in work and avg_ms > 0:
             _, fl, by = work[name]
-            on_h2 = name in H2_KERNELS or (x3_gemm and name in X3_GEMM_TAGS) or (
+            on_h2 = name in H2_KERNELS or (h2_gemm and name in H2_GEMM_TAGS) or (
                 name in H2_WINDOW_KERNELS and os.environ.get("NG_GEMM_MATH", "") != "fp32")
             peak_tf = PEAK_MFMA_F16_TFLOPS / 3.0 if on_h2 else PEAK_MFMA_F32_TFLOPS
             # both rooflines, the binding one is reported: floor = max(flops at the matrix peak, bytes at the HBM peak)
@@ -467,7 +467,7 @@ def main():
             prof = None
         if rank == 0:
             work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM)
-            rows = roofline_rows(prof, psteps, work, x3_gemm=False)
+            rows = roofline_rows(prof, psteps, work, h2_gemm=False)
             out["roofline_all"] = rows
             dom = next((r for r in rows if "bound" in r), None)
             if dom is not None:
@@ -523,7 +523,7 @@ def main():
             if not args.no_profile:
                 prof2 = profiled_steps(eng2, step2, 3)
                 rows2 = roofline_rows(prof2, 3, kernel_work(gb.N, K_NEIGH, 256, 3, 128, 4, 4, 4, NUM_ELEM),
-                                      x3_gemm=os.environ.get("NG_GEMM_MATH", "") != "fp32")
+                                      h2_gemm=os.environ.get("NG_GEMM_MATH", "") != "fp32")
                 blk["roofline_all"] = rows2
                 dom2 = next((r for r in rows2 if "bound" in r), None)
                 if dom2 is not None:

@@ -338,7 +338,7 @@ extern "C" int ng_rbf_expand(ng_ctx* ctx, void* stream, int64_t n, int H, const 
   return NG_OK;
 }
 
-// the fused kernels (edge_fused*.hip, edge_*_x3.hip) hard-wire softplus hidden layers and edge_feature_size <= 8;
+// the fused kernels (edge_fused*.hip, edge_*_h2.hip) hard-wire softplus hidden layers and edge_feature_size <= 8;
 // fc_activation = relu (model.py:35-36) and edge_feature_size = 64 (model.py:23) run the layered path
 static bool use_fused(int H, int E, int Le, int act) {
   return act == NG_ACT_SOFTPLUS && edge_fused_supported(H, E, Le) && !force_layered();

@@ -1,7 +1,7 @@
 """Run-to-run determinism: the engine uses no floating-point atomics and fixed-order reductions, so the same inputs
 must give bit-identical outputs and gradients every time.  (Round 2 found the training variant of the split-operand
 edge forward returning slightly different e from run to run: inline-asm bf16 conversions that the scheduler had moved
-into an MFMA chain without the hazard wait states — csrc/x3_common.cuh.  This test keeps that class of bug out.)"""
+into an MFMA chain without the hazard wait states — csrc/h2_common.cuh.  This test keeps that class of bug out.)"""
 import numpy as np
 import pytest
 

@@ -22,7 +22,7 @@ step = lambda: tr.step(gb, y, w)
 for _ in range(3): step()
 ms = bench.event_timed(step, 10)
 prof = bench.profiled_steps(eng, step, 3)
-rows = bench.roofline_rows(prof, 3, bench.kernel_work(gb.N, 16, F, 3, 128, 4, 4, 4, 10), x3_gemm=os.environ.get("NG_GEMM_MATH") != "fp32")
+rows = bench.roofline_rows(prof, 3, bench.kernel_work(gb.N, 16, F, 3, 128, 4, 4, 4, 10), h2_gemm=os.environ.get("NG_GEMM_MATH") != "fp32")
 print(f"F={F} step median {np.median(ms):.3f} ms  ({gb.N/np.median(ms)/1e3:.2f} M atoms/s)  env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("NG_")))
 for r in rows[:16]:
     print("  %-18s x%-3g %7.3f ms/step  %s %s" % (r["kernel"], r["launches_per_step"], r["ms_per_step"], r.get("bound", ""), ("%.3f" % r["frac"]) if "frac" in r else ""))
