@@ -38,6 +38,7 @@ constexpr int SDP_LD = 68;      // dP / h tile row stride (== 4 mod 16: conflict
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short gs16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int wave_min_i32(int v) {
   const int big = 0x7fffffff;
@@ -435,7 +436,8 @@ template <int E, int MODE>
 __device__ __forceinline__ void node_gather(int wave, int lane, int wlo, const int* __restrict__ s_ptr,
                                             const float4* __restrict__ recs, int rec_base,
                                             float* __restrict__ tb, int ld, const float4* __restrict__ win4,
-                                            const float4* __restrict__ src4, char* __restrict__ pl, float* __restrict__ rs) {
+                                            const float4* __restrict__ src4, char* __restrict__ pl, float* __restrict__ rs,
+                                            int* __restrict__ sbv, int* __restrict__ wmin) {
   const int c = lane & 15;
   const int al = wave * 4 + (lane >> 4);
   const int p0 = s_ptr[al], cnt = s_ptr[al + 1] - p0;
@@ -475,7 +477,11 @@ __device__ __forceinline__ void node_gather(int wave, int lane, int wlo, const i
     const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
     const int sb = (ef == 0 || ef == 255) ? 127 : min(267 - ef, 253);      // S = 2^(14 - e), 2^e > max; zero / non-finite rows: 1
     const float S = __builtin_bit_cast(float, sb << 23);
-    if (c == 0) rs[al] = __builtin_bit_cast(float, (254 - sb) << 23) * (1.0f / 256.0f);
+    if (c == 0) { rs[al] = __builtin_bit_cast(float, (254 - sb) << 23) * (1.0f / 256.0f); sbv[al] = sb; }
+    // the tile's reference scale for the dw product: the smallest S (= the largest row) among rows that are not all
+    // zero; this wave's four atoms here, the eight waves' minima meet after the barrier
+    const int wm = wave_min_i32(ef == 0 ? 253 : sb);
+    if (lane == 63) wmin[wave] = wm;
     constexpr int ROWB = (E * WF + 8) * 2, PLANE = WTA * ROWB;
     char* p = pl + al * ROWB + 8 * c;
 #pragma unroll
@@ -491,8 +497,9 @@ __device__ __forceinline__ void node_gather(int wave, int lane, int wlo, const i
 
 template <int E>
 __device__ __noinline__ void node_gather_global(int wave, int lane, const int* s_ptr, const float4* recs,
-                                                int rec_base, float* tb, int ld, const float4* src4, char* pl, float* rs) {
-  node_gather<E, 1>(wave, lane, 0, s_ptr, recs, rec_base, tb, ld, nullptr, src4, pl, rs);
+                                                int rec_base, float* tb, int ld, const float4* src4, char* pl, float* rs,
+                                                int* sbv, int* wmin) {
+  node_gather<E, 1>(wave, lane, 0, s_ptr, recs, rec_base, tb, ld, nullptr, src4, pl, rs, sbv, wmin);
 }
 
 template <int E, bool H2>
@@ -510,7 +517,9 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
   int* s_ptr = reinterpret_cast<int*>(s_rec + 2 * NREC_CAP);           // [2][36]
   int* ctl = s_ptr + 2 * 36;                                           // [2][16]
   float* s_rs = reinterpret_cast<float*>(ctl + 32);                    // [32]  2^-8 / S per atom row (H2)
-  char* planes = reinterpret_cast<char*>(s_rs + 32);                   // [2][32][ROWB] (H2)
+  int* s_sb = reinterpret_cast<int*>(s_rs + 32);                       // [32]  biased exponent of S per atom row (H2)
+  int* s_wmin = s_sb + 32;                                             // [8]   per-wave minimum of it over non-zero rows
+  char* planes = reinterpret_cast<char*>(s_wmin + 8);                  // [2][32][ROWB] (H2)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -617,9 +626,9 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
         const bool fits = pp[WTA] - rec_base <= NREC_CAP;
         // a tile with more records than the staging area reads them from global memory instead (separate
         // call sites: the fast path must see an LDS pointer, not a generic one)
-        if (mode == 0 && fits) node_gather<E, 0>(wave, lane, wlo, pp, rc, rec_base, tile, LD, win4, src4, pl, s_rs);
-        else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4, pl, s_rs);
-        else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4, pl, s_rs);
+        if (mode == 0 && fits) node_gather<E, 0>(wave, lane, wlo, pp, rc, rec_base, tile, LD, win4, src4, pl, s_rs, s_sb, s_wmin);
+        else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4, pl, s_rs, s_sb, s_wmin);
+        else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4, pl, s_rs, s_sb, s_wmin);
       }
       issue(t + 2 < T1 ? t + 2 : t);
       issue_rows(t + 1 < T1 ? t + 1 : t);
@@ -674,7 +683,48 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
                                      fmaf(acc0[2] + acc1[2], osc, dHc.z), fmaf(acc0[3] + acc1[3], osc, dHc.w));
         *reinterpret_cast<float4*>(row < a.N ? a.dh + row * WF + col : a.dummy + col) = v;
       }
-      {
+      if (H2) {
+        // dw on the fp16 pipe.  The contraction runs over the tile's 32 atoms (ONE 32-deep MFMA step), whose B rows carry
+        // different power-of-two scales S_a in the piece planes: the h operand takes the inverse, h'[a] = h[a] * S_ref / S_a
+        // with S_ref the smallest S of the tile (its largest row; ratio <= 1, a small row's h' may underflow — its
+        // term is below the fp32 rounding of the large rows' terms), so that h'[a] (S_a B[a]) = S_ref h[a] B[a]; the tile's
+        // product goes into a fresh accumulator and is added to the running sums times 1 / S_ref.
+        int sbref = s_wmin[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) sbref = min(sbref, s_wmin[i]);
+        const float inv_ref = __builtin_bit_cast(float, (254 - sbref) << 23);
+        float hv[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const int at = 8 * g4 + tt;
+          const int sba = s_sb[at];
+          // all-zero rows keep S = 1 (sba may lie below the reference): their B pieces are exact zeros, any finite h' does
+          const float ratio = sba < sbref ? 1.0f : __builtin_bit_cast(float, max(sbref - sba + 127, 0) << 23);
+          hv[tt] = htile[at * SDP_LD + 16 * ct + a16] * ratio;
+        }
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        split2_pair(hv[0], hv[1], h0, l0); split2_pair(hv[2], hv[3], h1, l1);
+        split2_pair(hv[4], hv[5], h2, l2); split2_pair(hv[6], hv[7], h3, l3);
+        const u32x4 ah = {h0, h1, h2, h3}, al = {l0, l1, l2, l3};
+        // B operand: this lane's column of the piece planes for atoms 8 g4 .. 8 g4 + 7: two transposing reads of four atoms
+        const char* bp = planes + (8 * g4 + (a16 >> 2)) * ROWB + (16 * (NCT * hh) + 4 * (a16 & 3)) * 2;
+#pragma unroll
+        for (int u = 0; u < NCT; ++u) {
+          const char* q0 = bp + 32 * u;
+          const gs16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)q0);
+          const gs16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(q0 + 4 * ROWB));
+          const gs16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(q0 + PLANE));
+          const gs16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(q0 + PLANE + 4 * ROWB));
+          const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
+          const u32x2 c0 = __builtin_bit_cast(u32x2, w0), c1 = __builtin_bit_cast(u32x2, w1);
+          const u32x4 bh = {a0[0], a0[1], a1[0], a1[1]}, bl = {c0[0], c0[1], c1[0], c1[1]};
+          f32x4 at = {0.f, 0.f, 0.f, 0.f};
+          at = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), at, 0, 0, 0);
+          at = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), at, 0, 0, 0);
+          at = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), at, 0, 0, 0);
+          accW[u] += at * inv_ref;
+        }
+      } else {
         // D[i = l][j = (n,m)] += sum_atoms h[atom][l] B[atom][(n,m)]: l-tile ct, column tiles NCT*hh + u
         const float* ha = htile + 16 * ct + a16;
         const float* bb = tile + 16 * (NCT * hh) + a16;
@@ -724,7 +774,7 @@ __global__ void mp_records_kernel(int64_t N, int K, int E, const int32_t* __rest
 }
 
 size_t node_lds_bytes(int E, bool h2) {
-  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + WTA * SDP_LD) * 4 + (size_t)2 * NREC_CAP * 16 + (2 * 36 + 32 + 32) * 4 +
+  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + WTA * SDP_LD) * 4 + (size_t)2 * NREC_CAP * 16 + (2 * 36 + 32 + 32 + 32 + 8) * 4 +
          (h2 ? (size_t)2 * WTA * (E * WF + 8) * 2 : 0);
 }
 
