@@ -14,7 +14,10 @@ def softplus(x):
 
 
 @pytest.mark.parametrize("M,K,N,act,residual", [(4096, 128, 128, 1, 0), (5000, 256, 256, 1, 1), (138500, 768, 256, 0, 0),
-                                                (4097, 64, 128, 0, 0), (300000, 128, 128, 1, 0)])
+                                                (4097, 64, 128, 0, 0), (300000, 128, 128, 1, 0),
+                                                # one molecule per call: the 32-row short-operand kernel
+                                                (2770, 768, 256, 1, 0), (300, 256, 256, 1, 1), (2771, 128, 256, 0, 0),
+                                                (2770, 384, 512, 1, 0)])
 def test_dense_fwd_split_vs_float64(gpu_device, monkeypatch, M, K, N, act, residual):
     import torch
     from nmrgnn_amd import _lib
