@@ -272,3 +272,60 @@ def test_edge_backward_beyond_one_launch_segment(gpu_device):
             scale = max(float(a.abs().max() + b.abs().max()), 1e-6)
             # fp32 accumulation over 8.5 M edges in a different partition (512 instead of 2 x 256 partial sums)
             assert float((whole - ref).abs().max()) / scale < 2e-5, l
+
+
+@pytest.mark.parametrize("wscale", [0.003, 1.0, 8.0])
+def test_edge_forward_split_across_weight_magnitudes(gpu_device, monkeypatch, wscale):
+    """The fp16 pieces are taken from 2^8 W and from unscaled activations: weights 300 times smaller than Glorot's (their
+    l pieces become fp16 subnormals, which the matrix pipe honours) and 8 times larger (a gain of ~14 per layer, activations
+    in the thousands, still below 65504) must keep the float64 agreement of the default case, relative to the size of
+    the summed terms."""
+    n, E = 4096, 3
+    rng = np.random.default_rng(17)
+    d_src = rng.uniform(0.05, 1.2, n)
+    d_src[rng.random(n) < 0.1] = 0.0
+    centers = np.linspace(0.0, 1.2, H)
+    gap = centers[1] - centers[0]
+    Ws = [rng.standard_normal((H, H)) * 0.15 * wscale for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2 * wscale]
+    bs = [rng.standard_normal(H) * 0.1 * wscale for _ in range(3)] + [rng.standard_normal(E) * 0.1]
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    e_ref, z_ref = ref_edge(f32(d_src), f32(d_src), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws],
+                            [f32(b) for b in bs])
+    out = {}
+    for math in ("f16x2", "fp32"):
+        monkeypatch.setenv("NG_EDGE_MATH", math)
+        out[math] = run_gpu(gpu_device, d_src, d_src, centers, gap, Ws, bs, E, True)
+    assert np.isfinite(out["f16x2"][0]).all()
+    mag = (np.abs(z_ref[2]) @ np.abs(f32(Ws[3])) + np.abs(f32(bs[3]))).max()
+    err = {k: np.abs(v[0] - e_ref).max() for k, v in out.items()}
+    # the error of a deep chain grows with the weights' gain (each layer amplifies the previous layer's rounding); the
+    # split path has to stay within twice the f32-input MFMA path's error, whatever that gain is
+    assert err["f16x2"] < 2.0 * err["fp32"] + 1e-6 * mag, (wscale, err, mag)
+    for l in range(3):
+        zmag = max(np.abs(z_ref[l]).max(), 1.0)
+        dz = {k: np.abs(v[1][l] - z_ref[l]).max() / zmag for k, v in out.items()}
+        assert dz["f16x2"] < 2.0 * dz["fp32"] + 5e-7, (wscale, l, dz)
+
+
+def test_edge_forward_split_overflow_is_loud(gpu_device, monkeypatch):
+    """The documented range limit of the two-piece fp16 operands: an ACTIVATION at or above 65504 (here: weights 40 times
+    Glorot's, a gain of ~68 per layer, third-layer activations ~1e5) overflows the h piece.  The result must then be
+    non-finite — never a finite wrong number — while NG_EDGE_MATH=fp32 still evaluates the same inputs."""
+    n, E = 1024, 3
+    rng = np.random.default_rng(18)
+    d_src = rng.uniform(0.05, 1.2, n)
+    centers = np.linspace(0.0, 1.2, H)
+    gap = centers[1] - centers[0]
+    Ws = [rng.standard_normal((H, H)) * 6.0 for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2]
+    bs = [rng.standard_normal(H) * 0.1 for _ in range(3)] + [rng.standard_normal(E) * 0.1]
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    e_ref, z_ref = ref_edge(f32(d_src), f32(d_src), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws], [f32(b) for b in bs])
+    assert np.abs(z_ref[2]).max() > 65504                         # the case really leaves the fp16 range
+    monkeypatch.setenv("NG_EDGE_MATH", "f16x2")
+    e_h2, _ = run_gpu(gpu_device, d_src, d_src, centers, gap, Ws, bs, E, False)
+    over = np.abs(z_ref[2]).max(axis=1) > 70000                   # edges with an overflowing activation
+    assert over.any() and not np.isfinite(e_h2[over]).any()
+    monkeypatch.setenv("NG_EDGE_MATH", "fp32")
+    e_32, _ = run_gpu(gpu_device, d_src, d_src, centers, gap, Ws, bs, E, False)
+    assert np.isfinite(e_32).all()
+    assert np.abs(e_32 - e_ref).max() < 1e-4 * np.abs(e_ref).max()
