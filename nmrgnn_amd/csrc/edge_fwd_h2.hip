@@ -22,7 +22,8 @@
 // summed with.  Softplus outputs >= 65504 would overflow the h piece (inf -> NaN output, loud).
 //
 // Weights reach LDS by LDS-DMA in 32-KB chunks (half a layer: 2 output blocks x 4 input blocks x 2 k-steps x
-// 2 pieces x 1 KB fragments), 7 chunks per tile, ring of two slots, one barrier per chunk.
+// 2 pieces x 1 KB fragments); the ring has two slots of a WHOLE layer (two chunks, 128 KB in all): four barriers per
+// tile.  (The row-major-tape form, which also needs the transposition tile, keeps half-layer slots: seven.)
 #include <algorithm>
 #include <string>
 
@@ -187,9 +188,14 @@ __device__ __forceinline__ void h2_epilogue(const f32x16& acc, u32x4 (&bfo)[2][2
 template <int SAVE>
 __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_h2[];
+  // WL (every form but the row-major tape, which needs the transposition tile): ring slots hold a WHOLE layer (64 KB = two
+  // consecutive half-layer chunks of the image): four barriers and DMA waits per tile instead of seven, and a layer's
+  // weights have the whole previous layer to arrive
+  constexpr bool WL = SAVE != 1;
+  constexpr int SLOT = WL ? 2 * H2_CHUNK : H2_CHUNK;
   char* ring = smem_h2;
-  float* sT = reinterpret_cast<float*>(smem_h2 + H2_RING);     // [8 waves][32][36] store transposition (SAVE == 1)
-  float* sCen = reinterpret_cast<float*>(smem_h2 + H2_RING + (SAVE == 1 ? H2_TBYTES : 0));   // [128]
+  float* sT = reinterpret_cast<float*>(smem_h2 + 2 * SLOT);    // [8 waves][32][36] store transposition (SAVE == 1)
+  float* sCen = reinterpret_cast<float*>(smem_h2 + 2 * SLOT + (SAVE == 1 ? H2_TBYTES : 0));   // [128]
   float* sBias = sCen + FH;                                     // [3][128], scaled
   float* sBo = sBias + 3 * FH;                                  // [32]
 
@@ -213,14 +219,17 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, H2_NCHUNK * H2_CHUNK, 0x00020000);
   // ring state: chunk id (0..6) and slot of the NEXT chunk to request / to consume
   int req_c = 0, req_s = 0, use_s = 0;
-  h2_dma_chunk(rsrc, req_c, ring + req_s * H2_CHUNK, wave, lane);
-  req_c = 1; req_s = 1;
-  H2_WAIT_DMA();   // chunk 0 landed (this wave's share)
+  h2_dma_chunk(rsrc, req_c, ring + req_s * SLOT, wave, lane);
+  if (WL) h2_dma_chunk(rsrc, 1, ring + req_s * SLOT + H2_CHUNK, wave, lane);
+  req_c = WL ? 2 : 1; req_s = 1;
+  H2_WAIT_DMA();   // chunk 0 (WL: layer 0) landed (this wave's share)
 
+  // WL: req_c counts half-layer chunks in steps of two (0, 2, 4 = layers, 6 = output layer, one half-chunk)
 #define H2_STEP_BEGIN()                                              \
   NG_LDS_BARRIER();                                                  \
-  h2_dma_chunk(rsrc, req_c, ring + req_s * H2_CHUNK, wave, lane);   \
-  req_c = req_c == H2_NCHUNK - 1 ? 0 : req_c + 1;                    \
+  h2_dma_chunk(rsrc, req_c, ring + req_s * SLOT, wave, lane);       \
+  if (WL && req_c < H2_NCHUNK - 1) h2_dma_chunk(rsrc, req_c + 1, ring + req_s * SLOT + H2_CHUNK, wave, lane); \
+  req_c = WL ? (req_c >= H2_NCHUNK - 1 ? 0 : req_c + 2) : (req_c == H2_NCHUNK - 1 ? 0 : req_c + 1); \
   req_s ^= 1;
 #define H2_STEP_END()                                                \
   H2_WAIT_DMA();                                                     \
@@ -263,10 +272,12 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     for (int layer = 0; layer < 3; ++layer) {
       f32x16 acc[4];
       H2_STEP_BEGIN();
-      h2_hidden_chunk<false>(ring + use_s * H2_CHUNK, bf, acc[0], acc[1], sBias + layer * FH, 0, lane, acc[2], acc[3]);
-      H2_STEP_END();
-      H2_STEP_BEGIN();
-      h2_hidden_chunk<true>(ring + use_s * H2_CHUNK, bf, acc[2], acc[3], sBias + layer * FH, 2, lane, acc[0], acc[1]);
+      h2_hidden_chunk<false>(ring + use_s * SLOT, bf, acc[0], acc[1], sBias + layer * FH, 0, lane, acc[2], acc[3]);
+      if (!WL) {
+        H2_STEP_END();
+        H2_STEP_BEGIN();
+      }
+      h2_hidden_chunk<true>(ring + use_s * SLOT + (WL ? H2_CHUNK : 0), bf, acc[2], acc[3], sBias + layer * FH, 2, lane, acc[0], acc[1]);
       H2_STEP_END();
       // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
       const int64_t wrow0 = tile * H2_TM + 32 * wave;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
       H2_STEP_BEGIN();
-      const u32x4* fr = reinterpret_cast<const u32x4*>(ring + use_s * H2_CHUNK) + lane;
+      const u32x4* fr = reinterpret_cast<const u32x4*>(ring + use_s * SLOT) + lane;
 #pragma unroll
       for (int bi = 0; bi < 4; ++bi) {
         u32x4 a0[2], a1[2];
@@ -356,11 +367,11 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   const size_t misc = (size_t)(FH + 3 * FH + 32) * 4;
   ProfScope ps(ctx, st, "edge_fwd_h2");
   if (z_save && edge_tape_blocked(E, n_edges))
-    hipLaunchKernelGGL(edge_fwd_h2_kernel<2>, dim3(grid), dim3(512), H2_RING + misc, st, a);
+    hipLaunchKernelGGL(edge_fwd_h2_kernel<2>, dim3(grid), dim3(512), 2 * H2_RING + misc, st, a);
   else if (z_save)
     hipLaunchKernelGGL(edge_fwd_h2_kernel<1>, dim3(grid), dim3(512), H2_RING + H2_TBYTES + misc, st, a);
   else
-    hipLaunchKernelGGL(edge_fwd_h2_kernel<0>, dim3(grid), dim3(512), H2_RING + misc, st, a);
+    hipLaunchKernelGGL(edge_fwd_h2_kernel<0>, dim3(grid), dim3(512), 2 * H2_RING + misc, st, a);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
