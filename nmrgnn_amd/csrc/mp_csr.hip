@@ -336,6 +336,9 @@ int csr_edge_grad(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, c
                   const int32_t* col, const float* dA, float* de, int accumulate) {
   if (N == 0) return NG_OK;
   ProfScope ps(ctx, st, "mp_edge_grad");
+  // padded lists of a batch of small graphs at the default width: slab windows of h in LDS (mp_win.hip)
+  if (!row_ptr && agg_win_supported(F, E, K) && N >= 4096 && ctx->graph_span > 0 && ctx->graph_span <= agg_win_rows())
+    return egrad_win(ctx, st, N, K, F, E, h, col, dA, de, accumulate);
   const RowRange rr{row_ptr, K};
   if ((F == 128 || F == 256) && E <= 4) {          // wide-lane form: DPP reductions over F/16 lanes
     const int lpa = F / 16;

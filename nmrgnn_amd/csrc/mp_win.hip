@@ -833,6 +833,194 @@ __global__ __launch_bounds__(WTHREADS, 1) void agg_win_kernel(AggWinArgs a) {
   }
 }
 
+// ---- window-resident edge gradient for the default width ---------------------------------------------------------------
+//   de[i][j][n] (+)= sum_l dA[i][n][l] * h[nlist[i][j]][l]          (generic form: csr_edge_grad_wide_kernel)
+// Same slab windows of h as the aggregation above (two passes at F = 256); per atom the 16 lanes hold the slab's part of
+// their OWN dA row in registers (one contiguous read per pass), walk the neighbours with the rotation scheme of the F = 64
+// kernels — lane c owns slot c, in step s it multiplies ITS two chunks with the row of slot (c + s) and sends the partial
+// back to the owner over DPP — and the owner adds the pass's sum to de (slab 0: += the caller's de when accumulating).
+struct EGradWinArgs {
+  int64_t N;
+  int K, F;
+  int64_t ntiles;
+  int tiles_per_wg;
+  const float* h;          // [N][F]
+  const int32_t* nlist;    // [N][K]
+  const float* dA;         // [N][E][F]
+  float* de;               // [N][K][E]
+  int accumulate;
+};
+
+template <int E, int S, int MODE>
+__device__ __forceinline__ void eg_step(const char* __restrict__ wb, const float4* __restrict__ src4, int f4n, int slab, int c,
+                                        int roff, int gidx, const float4 (&da)[2][E], float (&out)[E]) {
+  float4 h0, h1;
+  if (MODE == 0) {
+    const char* p = wb + ror_i<S>(roff);
+    h0 = *reinterpret_cast<const float4*>(p);
+    h1 = *reinterpret_cast<const float4*>(p + 256);
+  } else {
+    const int64_t r = ror_i<S>(gidx);
+    h0 = src4[r * f4n + AW_C4 * slab + c];
+    h1 = src4[r * f4n + AW_C4 * slab + c + 16];
+  }
+#pragma unroll
+  for (int n = 0; n < E; ++n) {
+    float p = da[0][n].x * h0.x;
+    p = fmaf(da[0][n].y, h0.y, p); p = fmaf(da[0][n].z, h0.z, p); p = fmaf(da[0][n].w, h0.w, p);
+    p = fmaf(da[1][n].x, h1.x, p); p = fmaf(da[1][n].y, h1.y, p); p = fmaf(da[1][n].z, h1.z, p); p = fmaf(da[1][n].w, h1.w, p);
+    out[n] += ror_f<(16 - S) & 15>(p);      // slot (c + S) was processed here: back to its owner lane
+  }
+}
+
+template <int E, int MODE>
+__device__ __forceinline__ void eg_tile(int K, int wave, int lane, int wlo, const int32_t* __restrict__ nl,
+                                        const float4* __restrict__ win4, const float4* __restrict__ src4, int f4n, int slab,
+                                        const float4 (&da)[2][E], float (&out)[E]) {
+  const int c = lane & 15;
+  const int al = wave * 4 + (lane >> 4);
+  const int idx = nl[al * K + (c < K ? c : 0)];
+  const int roff = min(max(idx - wlo, 0), AW_ROWS - 1) * (AW_SLAB * 4);
+  const char* wb = reinterpret_cast<const char*>(win4) + 16 * c;
+#pragma unroll
+  for (int n = 0; n < E; ++n) out[n] = 0.f;
+  eg_step<E, 0, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 1, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 2, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 3, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 4, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 5, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 6, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 7, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 8, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 9, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 10, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 11, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 12, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 13, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 14, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+  eg_step<E, 15, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
+}
+
+template <int E>
+__device__ __noinline__ void eg_tile_global(int K, int wave, int lane, const int32_t* nl, const float4* src4, int f4n, int slab,
+                                            const float4* da_flat, float* out_flat) {
+  float4 da[2][E];
+  float out[E];
+#pragma unroll
+  for (int n = 0; n < E; ++n) { da[0][n] = da_flat[n]; da[1][n] = da_flat[E + n]; }
+  eg_tile<E, 1>(K, wave, lane, 0, nl, nullptr, src4, f4n, slab, da, out);
+#pragma unroll
+  for (int n = 0; n < E; ++n) out_flat[n] = out[n];
+}
+
+template <int E>
+__global__ __launch_bounds__(WTHREADS, 1) void egrad_win_kernel(EGradWinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* win = smem;                                                        // [AW_ROWS][AW_SLAB]
+  int32_t* s_nl = reinterpret_cast<int32_t*>(win + AW_ROWS * AW_SLAB);      // [2][32*K]
+  int* ctl = reinterpret_cast<int*>(s_nl + 2 * WTA * a.K);                  // [2][16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K, per_tile = WTA * K, f4n = a.F / 4;
+  const int64_t T0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+  const int64_t T1 = std::min<int64_t>(T0 + a.tiles_per_wg, a.ntiles);
+  if (T0 >= T1) return;
+  const float4* src4 = reinterpret_cast<const float4*>(a.h);
+  const float4* dA4 = reinterpret_cast<const float4*>(a.dA);
+  float4* win4 = reinterpret_cast<float4*>(win);
+  const int c = lane & 15, al = wave * 4 + (lane >> 4);
+
+  // lists of one tile in flight: indices only (threads < 8 K int4)
+  int4 p_nl;
+  auto issue = [&](int64_t t) {
+    const int64_t nb = t * per_tile / 4, nlim = a.N * K / 4;
+    const int64_t qn = nb + tid;
+    const int4 v = reinterpret_cast<const int4*>(a.nlist)[qn < nlim ? qn : nlim - 1];
+    p_nl = (qn < nlim && tid < per_tile / 4) ? v : make_int4(0, 0, 0, 0);
+  };
+  auto commit = [&](int64_t t) {
+    int lo = 0x7fffffff, hi = -1;
+    if (tid < per_tile / 4) {
+      reinterpret_cast<int4*>(s_nl + (t & 1) * per_tile)[tid] = p_nl;
+      lo = min(min(p_nl.x, p_nl.y), min(p_nl.z, p_nl.w));
+      hi = max(max(p_nl.x, p_nl.y), max(p_nl.z, p_nl.w));
+    }
+    lo = wave_min_i32(lo);
+    hi = -wave_min_i32(-hi);
+    if (lane == 63) { ctl[(t & 1) * 16 + wave] = lo; ctl[(t & 1) * 16 + 8 + wave] = hi; }
+  };
+
+#pragma unroll 1
+  for (int slab = 0; slab < a.F / AW_SLAB; ++slab) {
+    for (int t = tid; t < AW_ROWS * AW_C4; t += WTHREADS) win4[t] = f4zero();
+    int wlo = -(1 << 30), mode = 0;
+    issue(T0);
+    commit(T0);
+    issue(T0 + 1 < T1 ? T0 + 1 : T0);
+    NG_LDS_BARRIER();
+    if (aw_decide(ctl + (T0 & 1) * 16, wlo, mode)) aw_stage(win4, src4, f4n, slab, wlo, a.N, tid);
+    NG_LDS_BARRIER();
+#pragma unroll 1
+    for (int64_t t = T0; t < T1; ++t) {
+      const int64_t row = t * WTA + al;
+      const int64_t rc = row < a.N ? row : a.N - 1;
+      // this lane's two chunks of its own dA row (slab part), and the old value of its (atom, slot) gradient
+      float4 da[2][E];
+#pragma unroll
+      for (int n = 0; n < E; ++n) {
+        da[0][n] = dA4[(rc * E + n) * f4n + AW_C4 * slab + c];
+        da[1][n] = dA4[(rc * E + n) * f4n + AW_C4 * slab + c + 16];
+      }
+      const bool owner = row < a.N && c < K;
+      float old[E];
+#pragma unroll
+      for (int n = 0; n < E; ++n) old[n] = (owner && (slab > 0 || a.accumulate)) ? a.de[(row * K + c) * E + n] : 0.f;
+      if (t + 1 < T1) commit(t + 1);
+      issue(t + 2 < T1 ? t + 2 : t);
+      float out[E];
+      const int32_t* nl = s_nl + (t & 1) * per_tile;
+      if (mode == 0) {
+        eg_tile<E, 0>(K, wave, lane, wlo, nl, win4, src4, f4n, slab, da, out);
+      } else {
+        float4 daf[2 * E];
+#pragma unroll
+        for (int n = 0; n < E; ++n) { daf[n] = da[0][n]; daf[E + n] = da[1][n]; }
+        eg_tile_global<E>(K, wave, lane, nl, src4, f4n, slab, daf, out);
+      }
+      if (owner) {
+#pragma unroll
+        for (int n = 0; n < E; ++n) a.de[(row * K + c) * E + n] = old[n] + out[n];
+      }
+      NG_LDS_BARRIER();
+      if (t + 1 < T1 && aw_decide(ctl + ((t + 1) & 1) * 16, wlo, mode)) {
+        aw_stage(win4, src4, f4n, slab, wlo, a.N, tid);
+        NG_LDS_BARRIER();
+      }
+    }
+    NG_LDS_BARRIER();
+  }
+}
+
+int egrad_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
+              const float* dA, float* de, int accumulate) {
+  EGradWinArgs a{};
+  a.N = N; a.K = K; a.F = F; a.ntiles = cdiv(N, WTA);
+  int64_t per = cdiv(a.ntiles, ctx->num_cu);
+  per = cdiv(per, 8) * 8;
+  a.tiles_per_wg = (int)per;
+  a.h = h; a.nlist = nlist; a.dA = dA; a.de = de; a.accumulate = accumulate;
+  const int grid = (int)cdiv(a.ntiles, per);
+  const size_t lds = (size_t)(AW_ROWS * AW_SLAB + 2 * WTA * K + 32) * 4;
+  switch (E) {
+    case 1: hipLaunchKernelGGL((egrad_win_kernel<1>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((egrad_win_kernel<2>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((egrad_win_kernel<3>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
+  }
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 int agg_win_rows() { return AW_ROWS; }
 
 bool agg_win_supported(int F, int E, int K) {

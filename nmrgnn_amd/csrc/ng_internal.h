@@ -106,6 +106,9 @@ int mpw_pack2(ng_ctx* ctx, hipStream_t st, int E, const float* w, int mode_a, fl
 // window-resident neighbour aggregation for F % 128 == 0 (mp_win.hip); padded lists with K % 4 == 0, K <= 16, E <= 3
 bool agg_win_supported(int F, int E, int K);
 int agg_win_rows();
+// the edge gradient de (+)= <dA, h[nlist]> with the same slab windows (same conditions as agg_win)
+int egrad_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
+              const float* dA, float* de, int accumulate);
 int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
             const float* e, float* A);
 // backward images, the dA image as fp16 piece fragments (mp_win.hip)

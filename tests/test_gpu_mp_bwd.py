@@ -136,3 +136,54 @@ def test_mp_layer_bwd_scales_exactly_with_the_upstream_gradient(gpu_device, shif
             a, b = a[live], b[live]
         assert np.isfinite(a).all()
         assert np.array_equal(a, b * 2.0 ** shift), k
+
+
+@pytest.mark.parametrize("graph,K,E", [(256, 16, 3), (200, 8, 2)])
+def test_default_width_backward_with_slab_windows(gpu_device, graph, K, E):
+    """F = 256 (the reference's default): with the locality hint (ng_ctx_set_graph_span) the neighbour aggregation and the
+    edge gradient de = <dA, h[nlist]> keep slab windows of h in LDS (mp_win.hip: agg_win_kernel, egrad_win_kernel).  Both
+    forms of ng_mp_layer_bwd against the float64 statement of SURVEY App. B and against each other; graphs of 200 atoms
+    straddle the 32-atom tiles (window restaging / global fall-back), the last tile is ragged."""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    from nmrgnn_amd.graph import GraphBatch
+    F, act = 256, 1
+    G = 4200 // graph + 1
+    N = G * graph - 5
+    rng = np.random.default_rng(graph + K)
+    base = (np.arange(N) // graph) * graph
+    nl = np.minimum(base[:, None] + rng.integers(0, graph, (N, K)), N - 1).astype(np.int32)
+    e = rng.standard_normal((N, K, E))
+    e[rng.random((N, K)) < 0.1] = 0.0
+    h = rng.standard_normal((N, F)) * 0.5
+    inv = rng.random(N)
+    w = rng.standard_normal((F, F, E)) * 0.05
+    dH = rng.standard_normal((N, F))
+    S, de, dh, dw = ref_bwd(h, nl, e, inv, w, dH, act)
+    dev = gpu_device
+    t = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    edges = (np.abs(e).sum(-1) > 0).astype(np.float32)
+    gb = GraphBatch(np.eye(10, dtype=np.float32)[rng.integers(0, 10, N)], nl, edges, inv, device=dev)
+    csc_ptr, csc_edge = gb.csc()
+    th, te, tinv, tw, tdH, tS = t(h), t(e), t(inv), t(w), t(dH), t(S)
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    live = np.abs(e).sum(-1) > 0
+    got = {}
+    for span in (0, graph):
+        ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, span), "span")
+        tdh = torch.empty(N, F, device=dev); tdw = torch.empty(F, F, E, device=dev); tde = torch.full((N, K, E), 0.5, device=dev)
+        ctx.check(ctx.lib.ng_mp_layer_bwd(ctx.handle, st, N, K, F, E, act, ptr(th), ptr(gb.nlist_c), ptr(te), ptr(tinv),
+                                          ptr(tw), None, ptr(tS), ptr(csc_ptr), ptr(csc_edge), ptr(tdH), ptr(tdh),
+                                          ptr(tde), 1, ptr(tdw)), "bwd")
+        torch.cuda.synchronize()
+        got[span] = (tdh.cpu().numpy(), tdw.cpu().numpy(), tde.cpu().numpy() - 0.5)
+    ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, 0), "span")
+    scale = lambda a: max(1.0, np.abs(a).max())
+    for span, (gdh, gdw, gde) in got.items():
+        assert np.abs(gdh - dh).max() < 2e-4 * scale(dh), span
+        assert np.abs(gdw - dw).max() < 2e-4 * scale(dw), span
+        assert np.abs((gde - de)[live]).max() < 2e-4 * scale(de), span
+    # the two forms differ only by the summation order of the window kernels
+    assert np.abs((got[0][2] - got[graph][2])[live]).max() < 1e-5 * scale(de)
