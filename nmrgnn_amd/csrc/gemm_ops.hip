@@ -178,7 +178,9 @@ static DwPlan dw_plan(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
   const int BMo = t256 ? 256 : 128, BNo = t256 ? 256 : (p.big_n ? 128 : 64);
   const int64_t tiles = cdiv(Kin, BMo) * cdiv(Nout, BNo);
   // split the contraction (rows) so that ~2 workgroups per CU (one for the 256-tiles) are in flight
-  int64_t nz = cdiv((int64_t)(t256 ? 1 : 2) * ctx->num_cu, tiles);
+  // (256-tiles: ONE 8-wave workgroup fits a CU, so the grid must not exceed the CU count — rounding 256 / 3 tiles UP gave
+  // 258 workgroups, two of which ran alone in a second round and doubled the kernel's time)
+  int64_t nz = t256 ? std::max<int64_t>(ctx->num_cu / tiles, 1) : cdiv((int64_t)2 * ctx->num_cu, tiles);
   const int64_t max_z = std::max<int64_t>(cdiv(M, 32), 1);
   nz = std::max<int64_t>(std::min(nz, max_z), 1);
   p.k_chunk = std::max<int64_t>(cdiv(cdiv(M, nz), 32) * 32, 32);
