@@ -1006,8 +1006,7 @@ int egrad_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const
               const float* dA, float* de, int accumulate) {
   EGradWinArgs a{};
   a.N = N; a.K = K; a.F = F; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, ctx->num_cu);
-  per = cdiv(per, 8) * 8;
+  const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.h = h; a.nlist = nlist; a.dA = dA; a.de = de; a.accumulate = accumulate;
   const int grid = (int)cdiv(a.ntiles, per);
@@ -1031,8 +1030,7 @@ int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const f
             const float* e, float* A) {
   AggWinArgs a{};
   a.N = N; a.K = K; a.F = F; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, ctx->num_cu);
-  per = cdiv(per, 8) * 8;      // runs start on molecule boundaries for the common 256-atom padding
+  const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.h = h; a.nlist = nlist; a.e = e; a.A = A;
   const int grid = (int)cdiv(a.ntiles, per);
@@ -1086,8 +1084,7 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
   // contiguous runs of tiles per workgroup, a multiple of 8 tiles (256 atoms) so that runs start on
   // molecule boundaries for the common 256-atom padding
-  int64_t per = cdiv(a.ntiles, ctx->num_cu);
-  per = cdiv(per, 8) * 8;
+  const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.h = h; a.nlist = nlist; a.e = e; a.Wfrag = Wfrag; a.rowscale = inv_degree; a.residual = residual;
   a.out = h_out; a.S_save = s_save; a.act = act; a.dummy = Wfrag + KF * WF;

@@ -807,8 +807,7 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
                     float* dh_in, float* dw, float* scratch, float* dummy) {
   MpWinNodeArgs a{};
   a.N = N; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, ctx->num_cu);
-  per = cdiv(per, 8) * 8;
+  const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.dP = dP; a.dH = dh_out; a.h = h; a.csc_ptr = csc_ptr; a.rec = reinterpret_cast<const float4*>(rec);
   a.WfragN = WfragN; a.dh = dh_in; a.partial = scratch; a.dummy = dummy;
@@ -843,8 +842,7 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
                     const float* dh_out, float* dP, float* de, int de_accum, float* dummy) {
   MpWinEdgeArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, ctx->num_cu);
-  per = cdiv(per, 8) * 8;
+  const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.dH = dh_out; a.S = act == NG_ACT_NONE ? nullptr : s_save; a.rowscale = inv_degree; a.h = h;
   a.nlist = nlist; a.WfragT = WfragT; a.dP = dP; a.de = de; a.dummy = dummy; a.act = act;

@@ -1,5 +1,7 @@
 // Internal C++ entry points shared between the .hip translation units.
 #pragma once
+#include <algorithm>
+
 #include "ng_common.h"
 
 namespace ng {
@@ -103,6 +105,19 @@ bool mp_win_supported(int F, int E, int K);
 bool mp_win_enabled(int F, int E, int K);
 int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out);
 int mpw_pack2(ng_ctx* ctx, hipStream_t st, int E, const float* w, int mode_a, float* out_a, int mode_b, float* out_b);
+// Contiguous runs of 32-atom tiles per persistent workgroup of the window kernels: a multiple of 8 tiles (256 atoms) so
+// that runs start on molecule boundaries for the common 256-atom padding — unless that leaves more than a tenth of the
+// CUs without a run (N not a multiple of 256 * num_cu), then the coarsest of 4 / 2 / 1 that does not.
+inline int64_t win_tiles_per_wg(int64_t ntiles, int num_cu) {
+  const int64_t base = std::max<int64_t>(cdiv(ntiles, num_cu), 1);
+  const int64_t want = std::min<int64_t>(num_cu, ntiles);
+  for (int align = 8; align > 1; align >>= 1) {
+    const int64_t per = cdiv(base, align) * align;
+    if (cdiv(ntiles, per) * 10 >= want * 9) return per;
+  }
+  return base;
+}
+
 // window-resident neighbour aggregation for F % 128 == 0 (mp_win.hip); padded lists with K % 4 == 0, K <= 16, E <= 3
 bool agg_win_supported(int F, int E, int K);
 int agg_win_rows();
