@@ -823,8 +823,21 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nh = wave & 1, kh = wave >> 1;           // n-blocks 4 nh .. 4 nh + 3, k-blocks 2 kh, 2 kh + 1
-  const int k0 = blockIdx.x * 256, n0 = blockIdx.y * 256;
-  const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_z;
+  // Workgroup -> (tile, row chunk z).  The tiles of one row chunk read the SAME rows of dY (and, across n-tiles, of X);
+  // workgroups are dealt to the 8 XCDs round-robin by their linear id, so with the plain (x, y, z) order the three k-tiles
+  // of a chunk sit on three different L2s and dY comes out of HBM three times.  When the chunk count is a multiple of 8
+  // (dw_plan arranges that) ids r, r + 8, r + 16, ... — one XCD — take the tiles of chunk 8 q + r.
+  int tx = blockIdx.x, ty = blockIdx.y, zc = blockIdx.z;
+  if ((gridDim.z & 7) == 0) {
+    const int tiles = gridDim.x * gridDim.y;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int r = L & 7, q = L >> 3;
+    const int t = q % tiles;
+    zc = (q / tiles) * 8 + r;
+    tx = t % gridDim.x; ty = t / gridDim.x;
+  }
+  const int k0 = tx * 256, n0 = ty * 256;
+  const int64_t r0 = (int64_t)zc * a.rows_per_z;
   const int64_t r1 = std::min<int64_t>(r0 + a.rows_per_z, a.M);
 
   const float gS = a.gscale[0], gI = a.gscale[1];       // dP is split as S * dP, the partial is written as acc / S
@@ -907,7 +920,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
     }
   }
   // D rows = n (from dP), D cols = k (from X): lane holds k = k0 + 32 (2 kh + i) + l31, n = n0 + 32 (4 nh + j) + 8q + 4 half + (0..3)
-  float* part = a.partial + (int64_t)blockIdx.z * a.K * a.N;
+  float* part = a.partial + (int64_t)zc * a.K * a.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int k = k0 + 32 * (2 * kh + i) + l31;

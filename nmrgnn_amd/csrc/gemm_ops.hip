@@ -181,10 +181,14 @@ static DwPlan dw_plan(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool has_db) {
   // (256-tiles: ONE 8-wave workgroup fits a CU, so the grid must not exceed the CU count — rounding 256 / 3 tiles UP gave
   // 258 workgroups, two of which ran alone in a second round and doubled the kernel's time)
   int64_t nz = t256 ? std::max<int64_t>(ctx->num_cu / tiles, 1) : cdiv((int64_t)2 * ctx->num_cu, tiles);
+  // several 256-tiles per row chunk: a multiple of 8 chunks lets the kernel put the tiles of a chunk on one XCD (gemm_h2.hip)
+  if (t256 && tiles > 1 && nz >= 16) nz = nz / 8 * 8;
   const int64_t max_z = std::max<int64_t>(cdiv(M, 32), 1);
   nz = std::max<int64_t>(std::min(nz, max_z), 1);
   p.k_chunk = std::max<int64_t>(cdiv(cdiv(M, nz), 32) * 32, 32);
   p.nz = std::max<int64_t>(cdiv(M, p.k_chunk), 1);
+  // keep the multiple of 8 (a trailing chunk may then be empty: it writes a zero partial)
+  if (t256 && tiles > 1 && nz % 8 == 0 && p.nz <= nz) p.nz = nz;
   p.cs_blocks = has_db ? std::min<int64_t>(std::max<int64_t>(cdiv(M, 512), 1), 2048) : 0;
   p.cs_rows = has_db ? cdiv(M, p.cs_blocks) : 0;
   return p;
