@@ -238,8 +238,16 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_fwd_kernel(GxArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nh = wave & 1, mh = wave >> 1;
-  const int64_t m0 = (int64_t)blockIdx.x * GX_BM;
-  const int ct = blockIdx.y;
+  // column tiles of a row tile on one XCD, consecutive in time (see gemm_h2_fwdr_kernel)
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int r = L & 7, q = L >> 3;
+    by = q % gridDim.y;
+    bx = (q / gridDim.y) * 8 + r;
+  }
+  const int64_t m0 = (int64_t)bx * GX_BM;
+  const int ct = by;
   const int KT = a.K / GX_BK;
 
   // this thread's slice of the X tile: row tid >> 1, 16 floats at column 16 (tid & 1) of the k-step
@@ -364,8 +372,18 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_fwdr_kernel(GxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_g4[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int nq = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t m0 = (int64_t)blockIdx.x * GX_BM;
-  const int ct = blockIdx.y;
+  // Workgroup -> (row tile, column tile).  The column tiles of a row tile read the same X rows; dealt to the XCDs by linear
+  // id, the plain (x, y) order puts them rounds apart and on different L2s.  With a multiple of 8 row tiles, ids r, r + 8,
+  // r + 16, ... (one XCD, consecutive in time) take the column tiles of row tile 8 q + r.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int r = L & 7, q = L >> 3;
+    by = q % gridDim.y;
+    bx = (q / gridDim.y) * 8 + r;
+  }
+  const int64_t m0 = (int64_t)bx * GX_BM;
+  const int ct = by;
   const int KT = a.K / GX_BK;
   constexpr int WCHUNK = gx_wchunk(4);
 
