@@ -32,6 +32,7 @@
 //   Bias gradients ride on the dW GEMM: G^T x ones in one extra accumulator (hx_dw_gemm).
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <cstdio>
 
 #include "edge_fused.h"
@@ -243,14 +244,12 @@ __device__ __forceinline__ float hx_sprime(float x, float z) {
   return fmaf(-x, __builtin_amdgcn_exp2f(-1.4426950408889634f * z), x);
 }
 
-// the same for two values at once: the scale and the final fma as packed fp32 instructions
-typedef float hx_f32x2 __attribute__((ext_vector_type(2)));
+// the same for two values.  NOT packed: tools/ubench/mfma_fill.hip (round 3) shows a v_pk_{add,mul,fma}_f32 that issues while
+// the SIMD's matrix pipe is busy — this wave's MFMAs or the partner wave's — costs ~20 cycles, a plain VALU op ~0.5 (up to
+// five of them hide in every 32-cycle MFMA slot).  The file is built with -fno-slp-vectorize for the same reason.
 __device__ __forceinline__ void hx_sprime2(float& x0, float& x1, float z0, float z1) {
-  const hx_f32x2 t = hx_f32x2{z0, z1} * hx_f32x2{-1.4426950408889634f, -1.4426950408889634f};
-  const hx_f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-  const hx_f32x2 x = {x0, x1};
-  const hx_f32x2 r = __builtin_elementwise_fma(-x, e, x);
-  x0 = r[0]; x1 = r[1];
+  x0 = hx_sprime(x0, z0);
+  x1 = hx_sprime(x1, z1);
 }
 
 #ifdef HX_STAMP
@@ -265,11 +264,7 @@ __device__ __forceinline__ void hx_sprime2(float& x0, float& x1, float z0, float
 
 __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_hx[];
-  char* IZ = smem_hx;                           // Z2 -> R
-  char* IZb = smem_hx + HX_IMG_Z;               // Z1 (second Z-type image: its writes need no barrier of their own)
-  char* GA = smem_hx + 2 * HX_IMG_Z;            // G3 -> G1
-  char* GB = smem_hx + 2 * HX_IMG_Z + HX_IMG_G; // fp32 Z3 staging -> G2
-  float* stg = reinterpret_cast<float*>(GB);
+  // images: Z-type x at smem + x * HX_IMG_Z, G-type x at smem + 2 * HX_IMG_Z + x * HX_IMG_G (roles alternate per tile)
   float* sWo4 = reinterpret_cast<float*>(smem_hx + HX_IMGS);      // [128][4]
   float* sdE = sWo4 + FH * 4;         // [64][4]
   float* sCen = sdE + FTM * 4;        // [128]
@@ -349,32 +344,33 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   };
   if ((int64_t)blockIdx.x < ntiles) { prefetch((int64_t)blockIdx.x * FTM); prefetch_z2((int64_t)blockIdx.x * FTM); }
 
-#pragma unroll 1
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#ifdef HX_STAMP
-    ++titer;
-#endif
-    HX_T(0);
-    const int64_t row0 = tile * FTM;
-    const int64_t grow = std::min<int64_t>(row0 + row, a.n_edges - 1);
-    const bool on = pf_ds > 0.f && row0 + row < a.n_edges;
-    const float dn = pf_dn;
-    float dEm[4];
+  // ---- the head of a tile ("phase A": mask, dE, fp32 Z3 staging, dWo / dbo on the VALU, G3, the Z2 image) in three
+  // steps separated by barriers.  For every tile but a workgroup's first it runs INSIDE phase D of the tile before
+  // (round 3): phase D is a bare dW GEMM — matrix pipe and LDS reads, hardly any VALU — and this head is VALU / LDS
+  // work without a single MFMA (4.8k of the 19.6k cycles of a tile when it stood alone).  Images alternate per tile:
+  // tile t keeps {G3, G1} in G[gp] and {Z2, R} in Z[zp], {G2} in G[gp^1], {Z1} in Z[zp^1]; during its phase D the
+  // buffers G[gp^1] / Z[zp^1] are dead and take the next tile's G3 and staging -> Z2.
+  float dEm[4];
+  // step 1: this lane's row of the tile whose inputs sit in pf_* / z3r; `live` = 0 on the pass past the last tile
+  auto head1 = [&](int64_t row0, bool live, char* Zn, bool& on_o, float& dn_o) {
+    on_o = live && pf_ds > 0.f && row0 + row < a.n_edges;
+    dn_o = pf_dn;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) dEm[n] = (on && n < E) ? gscale * pf_de[n] : 0.f;
+    for (int n = 0; n < 4; ++n) dEm[n] = (on_o && n < E) ? gscale * pf_de[n] : 0.f;
 #pragma unroll
     for (int n = 0; n < 4; ++n) accbo[n] += dEm[n];
-    float z1r[16];
-    hx_load_z(z1r, rsZ1, HX_ZOFF(row0, (int)grow), HX_ZQ(row0));        // used after phase B's GEMMs
-    // ------------------------------------------------------------------ phase A
+    float* stg = reinterpret_cast<float*>(Zn);        // fp32 [64][132]: exactly the footprint of a Z-type image
     if (zk == 0 && half == 0) *reinterpret_cast<float4*>(sdE + 4 * row) = make_float4(dEm[0], dEm[1], dEm[2], dEm[3]);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(stg + row * HX_STG + col0 + 8 * q) =
           make_float4(z3r[4 * q + 0], z3r[4 * q + 1], z3r[4 * q + 2], z3r[4 * q + 3]);
-    HX_T(1);
-    NG_LDS_BARRIER();
-    HX_T(2);
+  };
+  // step 2 (after a barrier): dWo from the staging in Zn, G3 pieces -> Gn.  (The Z2 pieces follow in step 3, once every
+  // reader of the staging is past the next barrier: z2r has to stay in registers for s'(Z2) anyway, G3 does not —
+  // with the staging in the G buffer the sixteen G3 values were live across the second wave's dW GEMM and got spilled.)
+  auto head2 = [&](char* Gn, const char* Zn) {
+    const float* stg = reinterpret_cast<const float*>(Zn);
     // dWo[k][n] += sum_rows Z3[row][k] dE[row][n]   (thread: k = cn, rows 16rq..16rq+15), fp32 on the VALU
 #pragma unroll 4
     for (int r = 16 * rq; r < 16 * rq + 16; ++r) {
@@ -382,35 +378,65 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       const float4 d = *reinterpret_cast<const float4*>(sdE + 4 * r);
       accWo[0] += z * d.x; accWo[1] += z * d.y; accWo[2] += z * d.z; accWo[3] += z * d.w;
     }
-    {   // G3 = (dE Wo^T) * s'(Z3)  ->  GA ;  db3
-      float g[16];
-      typedef float f32x2v __attribute__((ext_vector_type(2)));
+    // G3 = (dE Wo^T) * s'(Z3)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          const float4 w01 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));      // (x0 x1 y0 y1)
-          const float4 w23 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j) + 4);  // (z0 z1 w0 w1)
-          f32x2v pre = f32x2v{w01.x, w01.y} * dEm[0];
-          pre = __builtin_elementwise_fma(f32x2v{w01.z, w01.w}, f32x2v{dEm[1], dEm[1]}, pre);
-          pre = __builtin_elementwise_fma(f32x2v{w23.x, w23.y}, f32x2v{dEm[2], dEm[2]}, pre);
-          pre = __builtin_elementwise_fma(f32x2v{w23.z, w23.w}, f32x2v{dEm[3], dEm[3]}, pre);
-          g[4 * q + j] = pre[0]; g[4 * q + j + 1] = pre[1];
-          hx_sprime2(g[4 * q + j], g[4 * q + j + 1], z3r[4 * q + j], z3r[4 * q + j + 1]);
-        }
-      hx_img_write<HX_ROWG>(GA, prg, col0, g);
-    }
-    hx_img_write<HX_ROWZ>(IZ, prz, col0, z2r);       // Z2 pieces
-    u32x4 w0[2];
-    hx_wload(w0, wrs, lane * 16, ((1 * 4 + zk) * 8) * 2 * 1024, 0);
-    HX_T(3);
+      for (int j = 0; j < 4; j += 2) {
+        const float4 w01 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j));      // (x0 x1 y0 y1)
+        const float4 w23 = *reinterpret_cast<const float4*>(sWo4 + 4 * (col0 + 8 * q + j) + 4);  // (z0 z1 w0 w1)
+        float p0 = w01.x * dEm[0], p1 = w01.y * dEm[0];
+        p0 = fmaf(w01.z, dEm[1], p0); p1 = fmaf(w01.w, dEm[1], p1);
+        p0 = fmaf(w23.x, dEm[2], p0); p1 = fmaf(w23.y, dEm[2], p1);
+        p0 = fmaf(w23.z, dEm[3], p0); p1 = fmaf(w23.w, dEm[3], p1);
+        z3r[4 * q + j] = hx_sprime(p0, z3r[4 * q + j]);
+        z3r[4 * q + j + 1] = hx_sprime(p1, z3r[4 * q + j + 1]);
+      }
+    hx_img_write<HX_ROWG>(Gn, prg, col0, z3r);       // G3 pieces
+  };
+
+  bool on = false;
+  float dn = 0.f;
+  u32x4 w0[2];
+  // Z1 of a tile is requested during the phase D of the tile BEFORE it (its registers are the ones the Z3 values leave
+  // when the head has turned them into the G3 image): requested at the tile head, as until round 3, the HBM loads
+  // sat in front of the W^T fragment loads of phase B's dZ GEMM — memory returns in order, so the waves that start the
+  // phase with that GEMM waited an HBM round trip for L2 hits.
+  float z1r[16];
+  auto load_z1 = [&](int64_t row0) {
+    const int gi = (int)std::min<int64_t>(row0 + row, a.n_edges - 1);
+    hx_load_z(z1r, rsZ1, HX_ZOFF(row0, gi), HX_ZQ(row0));
+  };
+  if ((int64_t)blockIdx.x < ntiles) {      // the first tile's head stands alone
+    head1((int64_t)blockIdx.x * FTM, true, smem_hx, on, dn);
     NG_LDS_BARRIER();
-    HX_T(4);
+    head2(smem_hx + 2 * HX_IMG_Z, smem_hx);
+    load_z1((int64_t)blockIdx.x * FTM);
+    NG_LDS_BARRIER();
+    hx_img_write<HX_ROWZ>(smem_hx, prz, col0, z2r);  // Z2 pieces over the staging
+    hx_wload(w0, wrs, lane * 16, ((1 * 4 + zk) * 8) * 2 * 1024, 0);
+    NG_LDS_BARRIER();
+  }
+
+  // The image roles alternate per tile; the loop is unrolled by two with COMPILE-TIME roles (runtime image bases cost an
+  // address VGPR per access site: 21 spills in a kernel that has no register to spare).
+  auto tile_body = [&](int64_t tile, auto parity) {
+    constexpr int gp = decltype(parity)::value, zp = gp;
+#ifdef HX_STAMP
+    ++titer;
+#endif
+    HX_T(0);
+    const bool has_next = tile + gridDim.x < ntiles;
+    const int64_t row0n = std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM;
+    char* IZ = smem_hx + zp * HX_IMG_Z;                             // Z2 -> R
+    char* IZb = smem_hx + (zp ^ 1) * HX_IMG_Z;                      // Z1 ; next tile's Z2
+    char* GA = smem_hx + 2 * HX_IMG_Z + gp * HX_IMG_G;              // G3 -> G1
+    char* GB = smem_hx + 2 * HX_IMG_Z + (gp ^ 1) * HX_IMG_G;        // G2 ; next tile's Z3 staging -> G3
     // ------------------------------------------------------------------ phase B (layer 3)
     // the two waves of a SIMD (zrt = 0 / 1) take the two independent GEMMs of the phase in opposite order, so that
     // one wave's epilogue (VALU: s', split) runs beside the other's MFMAs
     if (zrt == 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
-    HX_T(5);
+    HX_T(1);
     {
       float g[16];
       // the wave whose epilogue comes NEXT gets the matrix pipe first (the arbiter otherwise favours the partner,
@@ -418,31 +444,30 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
       hx_dz_gemm(g, GA, prg, wrs, w0, 1, zk, lane);
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
-      HX_T(6);
+      HX_T(2);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z2r[r], z2r[r + 1]);
-      hx_img_write<HX_ROWG>(GB, prg, col0, g);       // G2  (the Z3 staging in GB was last read before the previous barrier)
+      hx_img_write<HX_ROWG>(GB, prg, col0, g);       // G2
     }
-    // Z1 pieces into the SECOND Z-type image: nobody reads IZb between the end of the previous tile's phase C and the
-    // next barrier, so this write needs no barrier pair of its own (with one Z image it waited for phase B's readers)
-    hx_img_write<HX_ROWZ>(IZb, prz, col0, z1r);
+    hx_img_write<HX_ROWZ>(IZb, prz, col0, z1r);      // Z1 pieces
     hx_wload(w0, wrs, lane * 16, ((0 * 4 + zk) * 8) * 2 * 1024, 0);
-    HX_T(7);
+    HX_T(3);
     if (zrt != 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
-    HX_T(8);
+    HX_T(4);
     NG_LDS_BARRIER();      // G2, Z1 images complete; every reader of G3 (GA) and Z2 (IZ) is done
-    HX_T(9);
-    HX_T(10);
+    HX_T(5);
     // ------------------------------------------------------------------ phase C (layer 2)
     if (zrt == 0) hx_dw_gemm(accW[1], accB, 2, IZb, GB, kslab, nsl0, lane);
+    HX_T(6);
     {
       float g[16];
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
       hx_dz_gemm(g, GB, prg, wrs, w0, 0, zk, lane);
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
-      // next tile's Z3 / d / dE (registers dead since phase A).  Issued BEHIND the last W^T fragment loads of the tile:
+      // next tile's Z3 / d / dE (registers dead since the head).  Issued BEHIND the last W^T fragment loads of the tile:
       // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
-      prefetch(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);
+      prefetch(row0n);
+      HX_T(7);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z1r[r], z1r[r + 1]);
       hx_img_write<HX_ROWG>(GA, prg, col0, g);       // G1
@@ -461,18 +486,34 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       }
       hx_img_write<HX_ROWZ>(IZ, prz, col0, rr);
     }
-    HX_T(11);
+    HX_T(8);
     if (zrt != 0) hx_dw_gemm(accW[1], accB, 2, IZb, GB, kslab, nsl0, lane);
+    HX_T(9);
     NG_LDS_BARRIER();      // G1, R images complete; every reader of G2 (GB) and Z1 (IZb) is done
+    HX_T(10);
+    // ------------------------------------------------------------------ phase D (layer 1) with the NEXT tile's head
+    prefetch_z2(row0n);    // unconditional (clamped): no branch around the loads
+    head1(row0n, has_next, IZb, on, dn);     // the loop-carried mask / distance now belong to the next tile (R is built)
+    HX_T(11);
+    NG_LDS_BARRIER();      // staging complete
     HX_T(12);
+    if (zrt == 0) hx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
+    head2(GB, IZb);
+    load_z1(row0n);
     HX_T(13);
-    // ------------------------------------------------------------------ phase D (layer 1)
-    prefetch_z2(std::min<int64_t>(tile + gridDim.x, ntiles - 1) * FTM);   // unconditional (clamped): no branch around the loads
-    hx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
+    if (zrt != 0) hx_dw_gemm(accW[0], accB, 0, IZ, GA, kslab, nsl0, lane);
     HX_T(14);
-    // no barrier here: the next tile's first writes go to the Z3 staging (GB) and sdE, which phase D does not touch; its
-    // first barrier stands between phase D's reads of GA / IZ and the next G3 / Z2 image writes
+    NG_LDS_BARRIER();      // every reader of the staging is done; every reader of G1 / R too
+    hx_img_write<HX_ROWZ>(IZb, prz, col0, z2r);      // next tile's Z2 pieces over the staging
+    hx_wload(w0, wrs, lane * 16, ((1 * 4 + zk) * 8) * 2 * 1024, 0);
+    NG_LDS_BARRIER();
     HX_T(15);
+  };
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += 2 * (int64_t)gridDim.x) {
+    tile_body(tile, std::integral_constant<int, 0>());
+    if (tile + gridDim.x >= ntiles) break;
+    tile_body(tile + gridDim.x, std::integral_constant<int, 1>());
   }
 
 #ifdef HX_STAMP
@@ -480,7 +521,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   if (blockIdx.x == 3 && tid < 128) a.stamps[tid] = sStamp[tid];
   __syncthreads();
 #endif
-  __syncthreads();     // the last tile's phase D still reads GA / IZ, which the epilogue below reuses
+  __syncthreads();
   // ---------------------------------------------------------------------- write this workgroup's partial
   float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
   {
@@ -498,8 +539,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
         }
   }
   // bias sums of the two edge halves, dWo / dbo of the four row quarters: summed through LDS (IZ is free now)
-  float* red = reinterpret_cast<float*>(IZ);
-  float* dbw = reinterpret_cast<float*>(GA);     // [4 k-slab waves][3 layers][128]
+  float* red = reinterpret_cast<float*>(smem_hx);
+  float* dbw = reinterpret_cast<float*>(smem_hx + 2 * HX_IMG_Z);     // [4 k-slab waves][3 layers][128]
   const int red_stride = 3 * FH + FH * E + E;
   {
     const int c = l31 / 5;     // this lane's column group; its first column carries the sums

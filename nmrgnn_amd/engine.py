@@ -118,19 +118,21 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch: GraphBatch, training=False, noise=None, dropout_mask=None, seed=0):
-        """peaks[N].  training=True keeps the tape for backward().
+    def forward(self, batch: GraphBatch, training=False, noise=None, dropout_mask=None, seed=0, keep_tape=None):
+        """peaks[N].  training=True keeps the tape for backward(); ``keep_tape=True`` keeps it for an inference-mode
+        forward too (no noise, no dropout — what autograd through ``model(g, training=False)`` differentiates).
         ``noise`` (xi[N,K], standard normal) / ``dropout_mask`` ([N,F/2], values 0 or 1/keep) may be
         supplied explicitly (parity tests); otherwise they are drawn on the GPU from ``seed``."""
         if not self._frozen:
-            return self._forward(batch, training, noise, dropout_mask, seed)
+            return self._forward(batch, training, noise, dropout_mask, seed, keep_tape)
         self._ck(self.lib.ng_weights_frozen(self.ctx.handle, self._id), "ng_weights_frozen")
         try:
-            return self._forward(batch, training, noise, dropout_mask, seed)
+            return self._forward(batch, training, noise, dropout_mask, seed, keep_tape)
         finally:
             self.lib.ng_weights_frozen(self.ctx.handle, 0)
 
-    def _forward(self, batch, training, noise, dropout_mask, seed):
+    def _forward(self, batch, training, noise, dropout_mask, seed, keep_tape=None):
+        tape = bool(training) if keep_tape is None else bool(keep_tape)
         lib, h, st = self.lib, self.ctx.handle, self._st()
         P = self.params
         N, K, F, E, H = batch.N, batch.K, self.F, self.E, self.H
@@ -148,10 +150,10 @@ class Engine:
             d_eff = self._new(ne)
             self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
                      "ng_add_scaled")
-        z_save = self._new(self.Le - 1, ne, H) if training else None
+        z_save = self._new(self.Le - 1, ne, H) if tape else None
         # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
         # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
-        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if training else 0
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if tape else 0
         e = self._new(ne, E)
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
@@ -164,15 +166,15 @@ class Engine:
         hs, As, Ss = [h0], [], []
         for l in range(self.L):
             hn = self._new(N, F)
-            S = self._new(N, F) if (training and self.mp_act != 0) else None
+            S = self._new(N, F) if (tape and self.mp_act != 0) else None
             if batch.is_csr:        # variable-degree lists: row_ptr / col instead of [N,K]
-                A = self._new(N, E, F) if training else None
+                A = self._new(N, E, F) if tape else None
                 self._ck(lib.ng_mp_layer_fwd_csr(h, st, N, ne, F, E, self.mp_act, 1, ptr(hs[-1]),
                                                  ptr(batch.row_ptr), ptr(batch.nlist), ptr(e),
                                                  ptr(batch.inv_degree), ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A),
                                                  ptr(S)), "ng_mp_layer_fwd_csr")
             else:
-                A = self._new(N, E, F) if (training and lib.ng_mp_layer_wants_aggregate(F, E, K)) else None
+                A = self._new(N, E, F) if (tape and lib.ng_mp_layer_wants_aggregate(F, E, K)) else None
                 self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
                                              ptr(batch.nlist_c), ptr(e), ptr(batch.inv_degree),
                                              ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A), ptr(S)),
@@ -200,7 +202,7 @@ class Engine:
         self._ck(lib.ng_head_fwd(h, st, N, Fh, self.C, ptr(g), ptr(mask), ptr(P["out/kernel"]),
                                  ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
                                  ptr(self.peak_avg), ptr(peaks)), "ng_head_fwd")
-        if training:
+        if tape:
             tp = Tape()
             tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e
             tp.z_layout = z_layout

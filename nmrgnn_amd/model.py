@@ -42,6 +42,7 @@ class GNNModel:
         self.engine = None
         self._pending_state = None
         self._train_calls = 0         # training-mode calls so far: every one draws fresh noise / dropout
+        self._flat_leaf = None        # torch.nn.Parameter over the flat weight buffer, created by parameters()
 
     # -- keras-like build: the number of elements comes from the first input (model.py:236-243)
     def build(self, num_elem):
@@ -60,12 +61,19 @@ class GNNModel:
         pend = getattr(self, "_pending_adam", None)
         if pend is None or self.engine is None:
             return
-        m, v, t = pend
-        if m.shape[0] == self.engine.adam_m.shape[0]:
-            self.engine.adam_m.copy_(torch.from_numpy(m))
-            self.engine.adam_v.copy_(torch.from_numpy(v))
-            self.engine.adam_t = t
         self._pending_adam = None
+        if pend == "reset":            # a checkpoint without optimiser state: moments of OTHER weights must not survive
+            self.engine.adam_m.zero_()
+            self.engine.adam_v.zero_()
+            self.engine.adam_t = 0
+            return
+        m, v, t = pend
+        if m.shape[0] != self.engine.adam_m.shape[0]:
+            raise ValueError(f"checkpoint Adam state has {m.shape[0]} entries, the model's flat parameter buffer "
+                             f"{self.engine.adam_m.shape[0]}: it belongs to a different architecture")
+        self.engine.adam_m.copy_(torch.from_numpy(m))
+        self.engine.adam_v.copy_(torch.from_numpy(v))
+        self.engine.adam_t = t
 
     def _as_batch(self, inputs):
         if isinstance(inputs, GraphBatch):
@@ -86,6 +94,12 @@ class GNNModel:
         if training and seed is None:
             seed = ((int(self._seed) * 0x9E3779B97F4A7C15) ^ (self._train_calls * 1000003 + 0x632BE5AB)) & ((1 << 63) - 1)
             self._train_calls += 1
+        leaf = self._flat_leaf
+        if leaf is not None and leaf.requires_grad and torch.is_grad_enabled():
+            # differentiable call (nmrgnn/main.py:74-80 trains by autodiff through model(x)): the result is a device
+            # tensor with a grad_fn whatever the input container was — a numpy array could not carry one
+            from .autograd import model_forward
+            return model_forward(self.engine, leaf, batch, training=training, seed=seed or 0)
         peaks = self.engine.forward(batch, training=training, seed=seed or 0)
         if on_device:
             return peaks
@@ -93,6 +107,32 @@ class GNNModel:
 
     call = __call__
     predict = __call__
+
+    # -- torch.autograd surface (the outer autograd shell)
+    def parameters(self):
+        """The trainable state as ONE leaf tensor: the engine's flat fp32 parameter buffer, shared, not copied.
+        After this call ``model(g)`` under ``torch.enable_grad()`` returns a tensor with a grad_fn, and
+        ``loss.backward()`` accumulates into ``parameters()[0].grad`` (autograd.GNNModelFunction).
+        ``torch.optim.Adam(model.parameters(), lr, eps=1e-7)`` is the reference's optimiser (model.py:44-45)."""
+        self._need_engine()
+        if self._flat_leaf is None:
+            self._flat_leaf = torch.nn.Parameter(self.engine.params.flat, requires_grad=True)
+        return [self._flat_leaf]
+
+    def named_parameter_views(self):
+        """{keras-style name: (weight view, gradient view or None)} into the flat leaf and its ``.grad``"""
+        leaf = self.parameters()[0]
+        P = self.engine.params
+        out = {}
+        for name, shape in P.shapes.items():
+            o, n = P.offsets[name], int(np.prod(shape))
+            g = None if leaf.grad is None else leaf.grad[o:o + n].view(*shape)
+            out[name] = (leaf.data[o:o + n].view(*shape), g)
+        return out
+
+    def requires_grad_(self, on=True):
+        self.parameters()[0].requires_grad_(bool(on))
+        return self
 
     def freeze(self, on=True):
         """declare the weights constant (inference): packed weight images are cached across calls"""
@@ -136,6 +176,7 @@ class GNNModel:
             arrays["__adam_m"] = self.engine.adam_m.cpu().numpy()
             arrays["__adam_v"] = self.engine.adam_v.cpu().numpy()
             arrays["__adam_t"] = np.asarray(self.engine.adam_t, np.int64)
+        arrays["__train_calls"] = np.asarray(self._train_calls, np.int64)   # seeds the next noise / dropout draw
         np.savez(os.path.join(path, "weights.npz"), **arrays)
         cfg = {"hypers": self.hypers.as_dict(), "num_elem": self.engine.C,
                "peak_standards": {str(k): list(v) for k, v in self.peak_standards.items()}}
@@ -155,13 +196,19 @@ class GNNModel:
                 raise ValueError(f"{path}: no weights.npz and no checkpoint bundle")
             from .tfbundle import load_gnn_bundle
             self.set_weights(load_gnn_bundle(prefix)[0])
+            self._pending_adam = "reset"       # our bundle reader takes the weight tensors only
+            self._restore_adam()
             return
         f = path if path.endswith(".npz") else os.path.join(path, "weights.npz")
         z = np.load(f)
-        self.set_weights({k.replace(".", "/"): z[k] for k in z.files if not k.startswith("__adam_")})
+        self.set_weights({k.replace(".", "/"): z[k] for k in z.files if not k.startswith("__")})
         if "__adam_t" in z.files:
             self._pending_adam = (z["__adam_m"], z["__adam_v"], int(z["__adam_t"]))
-            self._restore_adam()
+        else:
+            self._pending_adam = "reset"
+        if "__train_calls" in z.files:
+            self._train_calls = int(z["__train_calls"])
+        self._restore_adam()
 
 
 def build_GNNModel(hp=None, metrics=True, loss_balance=1.0, device=None):

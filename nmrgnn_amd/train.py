@@ -34,7 +34,9 @@ class Trainer:
         world, rank = self.buckets.world(), self.buckets.rank()
         if seed is None:
             # different noise / dropout draws on every rank and every step
-            seed = 0x9E3779B97F4A7C15 ^ (self.step_count * 1000003) ^ (rank * 0x5851F42D4C957F2D)
+            # keyed on the optimiser step, which checkpoints carry (Engine.adam_t): a resumed run continues the
+            # sequence of draws instead of replaying it
+            seed = 0x9E3779B97F4A7C15 ^ (eng.adam_t * 1000003) ^ (rank * 0x5851F42D4C957F2D)
         seed &= (1 << 63) - 1
         peaks = eng.forward(batch, training=True, seed=seed)
         if self.loss_balance == 1.0:
