@@ -48,7 +48,7 @@ PEAK_MFMA_F16_TFLOPS = 2516.6   # dense fp16 (= bf16): 256 CU x 4 SIMD x 1024 fl
 # which adds to matrix time on a gfx950 SIMD.
 H2_KERNELS = {"edge_fwd_h2", "edge_bwd_h2"}
 # window kernels whose matrix phase runs on the fp16 pipe unless NG_GEMM_MATH=fp32 (mp_win.hip)
-H2_WINDOW_KERNELS = {"mp_win_fwd"}
+H2_WINDOW_KERNELS = {"mp_win_fwd", "mp_win_bwd_edge", "mp_win_bwd_node"}
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 achievable
 
 ARCH = dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
@@ -380,10 +380,11 @@ def main():
     gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=dev)
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    gb.csc()
-    torch.cuda.synchronize()
-    t_csc = time.perf_counter() - t0
+    # steady state of the per-batch list construction (ng_build_incoming_lists; the first call above also paid the
+    # scratch allocation): device tuple in, lists out
+    raw = (gb.atoms, gb.nlist, gb.edges, gb.inv_degree)
+    ev = event_timed(lambda: GraphBatch(*raw, graph_ptr=b["graph_ptr"], device=dev, validate=False), 5)
+    t_csc = float(np.median(ev)) * 1e-3
     y = torch.from_numpy(b["y"]).to(dev)
     w = torch.from_numpy(b["w"]).to(dev)
     tr = Trainer(eng, lr=1e-4)
@@ -442,9 +443,10 @@ def main():
         "ms_per_step_hipevent_min": float(np.min(ev_ms)),
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
         "allreduce_exposed_ms": comm_ms,
-        "preprocess_ms": {"h2d_and_lists": t_h2d * 1e3, "incoming_edge_lists_csc": t_csc * 1e3,
-                          "note": "per-batch graph preprocessing outside the timed step (the batch is resident); "
-                                  "a real epoch pays it once per batch"},
+        "preprocess_ms": {"h2d_and_lists_first_call": t_h2d * 1e3, "lists_steady_state": t_csc * 1e3,
+                          "note": "host tuple -> device + lists on the first call (allocations included); steady-state "
+                                  "list construction from a device tuple (ng_build_incoming_lists); see "
+                                  "fresh_batch_every_step for the step that includes it"},
         "loss": final_loss,
         "matrix_math": ("f32-input MFMA everywhere" if os.environ.get("NG_EDGE_MATH", "") == "fp32" else
                         "edge MLP forward and backward: fp16 MFMA on fp32 operands split into 2 fp16 pieces (22-24 "
@@ -452,6 +454,21 @@ def main():
                         "below the f32-input MFMA kernels' (tests/test_gpu_edge_h2.py); all other contractions: "
                         "f32-input MFMA"),
     }
+
+    # ---- the reference sees a NEW graph tuple every step (nmrgnn/library.py:88-89): the same step with the batch
+    # object rebuilt from the raw device tuple inside the timed region (compute-side lists + incoming-edge lists by
+    # ng_build_incoming_lists), i.e. nothing of the preprocessing amortised
+    if world == 1:
+        def fresh_step():
+            g2 = GraphBatch(*raw, graph_ptr=b["graph_ptr"], device=dev, validate=False)
+            return tr.step(g2, y, w, total_graphs=total_graphs)
+        for _ in range(2):
+            fresh_step()
+        ms = event_timed(fresh_step, max(5, args.steps // 2))
+        out["fresh_batch_every_step"] = {"ms_per_step": float(np.median(ms)), "value": gb.N / (np.median(ms) * 1e-3),
+                                         "unit": "atoms/s", "list_build_ms": t_csc * 1e3,
+                                         "note": "raw (atoms, nlist, edges, inv_degree) resident in HBM; GraphBatch and "
+                                                 "its lists rebuilt every step"}
 
     # ---- per-kernel hipEvent pass (same step, events bracketed inside the C library).  EVERY rank runs the
     # steps — they contain the gradient all-reduce, a collective — only rank 0 reads the events.

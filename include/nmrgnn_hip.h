@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 2
+#define NG_ABI_VERSION 3
 
 enum {
   NG_OK = 0,
@@ -188,6 +188,20 @@ int ng_mp_layer_bwd_csr(ng_ctx*, void* stream, int64_t N, int64_t nnz, int F, in
                         const float* inv_degree, const float* w, const float* A_save, const float* s_save,
                         const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in,
                         float* de, int de_accum, float* dw);
+
+/* ---- per-batch graph preprocessing: the incoming-edge lists of the deterministic backward scatter --------------
+ * The reference hands the model a NEW graph tuple every step (nmrgnn/library.py:88-89, main.py:79); its backward is
+ * TensorFlow's unsorted scatter-add behind tf.gather (layers.py:33).  The engine's backward pulls over incoming edges
+ * instead, which needs, per batch, the transposed lists
+ *   csc_ptr [N+1], csc_edge [<= n_entries]: the entries (eid = i*K + j for padded lists with K > 0 and slots
+ *   edges[eid] == 0 dropped; eid = CSR entry index when K == 0, edges may be NULL = every entry live) whose neighbour
+ *   is atom t, for t = 0..N-1, ascending eid inside a target (= a stable sort by target), csc_ptr[N] = number of
+ *   live entries; and, for padded lists, nlist_c [N*K] (may be NULL): nlist with padded slots replaced by the atom's
+ *   own index (their weight is exactly 0), the list the MP kernels gather through.
+ * A deterministic counting sort in HIP; scratch comes from the context.  All pointers are device pointers. */
+int ng_build_incoming_lists(ng_ctx*, void* stream, int64_t N, int K, int64_t n_entries, const int32_t* nlist,
+                            const float* edges, int32_t* nlist_c, int32_t* csc_ptr, int32_t* csc_edge);
+size_t ng_incoming_lists_scratch_bytes(int64_t N, int64_t n_entries);
 
 /* Distance-cutoff graph builder (BASELINE configs[4], "variable degree"; the counterpart of ng_knn_graph for the CSR
  * form, in front of nmrgnn/library.py:106-117): every OTHER atom of the same frame closer than `cutoff` (Angstrom).

@@ -64,6 +64,8 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     "ng_mp_layer_bwd_csr": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "ng_build_incoming_lists": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ng_incoming_lists_scratch_bytes": (C.c_size_t, [_i64, _i64]),
     "ng_cutoff_count": (_int, [_vp, _vp, _int, _int, _f, _vp, _vp]),
     "ng_cutoff_fill": (_int, [_vp, _vp, _int, _int, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ng_dense_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
@@ -106,7 +108,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 2:
+        if lib.ng_abi_version() != 3:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -1,0 +1,163 @@
+// Per-batch graph preprocessing on the engine side (round 3): the incoming-edge (CSC) lists of the deterministic
+// backward scatter and the compute-side copy of the padded neighbour lists, built by the library instead of a chain of
+// torch sort / bincount / cumsum launches.  The reference feeds a NEW graph every step (nmrgnn/library.py:88-89), so
+// this work is per step, not per data set.
+//
+//   entry id  eid = i*K + j (padded lists, slots with edges == 0 dropped: they carry e == 0 exactly, model.py:261)
+//             or the CSR entry index (row_ptr form: every entry is live)
+//   csc_ptr[t] .. csc_ptr[t+1]: the entries whose neighbour is atom t, in ASCENDING entry id — the order a stable sort by
+//   target gives, which every bit-for-bit test of the backward relies on.
+//
+// A stable counting sort in five small launches: histogram by target (integer atomics: order-free), exclusive scan
+// (block-local + block sums + offsets), unordered fill through per-target cursors, and a per-target rank sort of each
+// short segment (in-degree ~ K) that restores ascending entry order.  Nothing floating-point is reduced here, so the
+// atomics cannot make the result depend on the schedule.
+#include <string>
+
+#include "ng_common.h"
+
+namespace ng {
+
+constexpr int GL_BLOCK = 256;
+constexpr int GL_SCAN_ITEMS = 4;                       // per thread
+constexpr int GL_SCAN_TILE = GL_BLOCK * GL_SCAN_ITEMS;  // 1024 counts per scan block
+
+// one thread per entry: histogram of live targets; the compute-side list (padded slots -> the atom itself)
+__global__ __launch_bounds__(GL_BLOCK) void gl_count_kernel(int64_t n_entries, int K, const int32_t* __restrict__ nlist,
+                                                            const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
+                                                            int32_t* __restrict__ count) {
+  const int64_t eid = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
+  if (eid >= n_entries) return;
+  const int32_t t = nlist[eid];
+  const bool live = edges == nullptr || edges[eid] > 0.f;
+  if (nlist_c) nlist_c[eid] = live ? t : (int32_t)(eid / K);
+  if (live) atomicAdd(&count[t], 1);
+}
+
+// exclusive scan, step 1: per block of GL_SCAN_TILE counts, local exclusive scan in place + the block total
+__global__ __launch_bounds__(GL_BLOCK) void gl_scan_local_kernel(int64_t n, int32_t* __restrict__ data, int32_t* __restrict__ block_sum) {
+  __shared__ int32_t s[GL_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * GL_SCAN_TILE + (int64_t)threadIdx.x * GL_SCAN_ITEMS;
+  int32_t v[GL_SCAN_ITEMS], sum = 0;
+#pragma unroll
+  for (int k = 0; k < GL_SCAN_ITEMS; ++k) { v[k] = base + k < n ? data[base + k] : 0; sum += v[k]; }
+  s[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < GL_BLOCK; off <<= 1) {
+    const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int32_t run = s[threadIdx.x] - sum;       // exclusive prefix of this thread inside the block
+#pragma unroll
+  for (int k = 0; k < GL_SCAN_ITEMS; ++k) {
+    if (base + k < n) data[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == GL_BLOCK - 1) block_sum[blockIdx.x] = s[GL_BLOCK - 1];
+}
+
+// step 2 (one block): exclusive scan of the block totals, any count of them
+__global__ __launch_bounds__(GL_BLOCK) void gl_scan_sums_kernel(int nblocks, int32_t* __restrict__ block_sum) {
+  __shared__ int32_t s[GL_BLOCK];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nblocks; b0 += GL_BLOCK) {
+    const int i = b0 + threadIdx.x;
+    const int32_t v = i < nblocks ? block_sum[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < GL_BLOCK; off <<= 1) {
+      const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nblocks) block_sum[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == GL_BLOCK - 1) carry += s[GL_BLOCK - 1];
+    __syncthreads();
+  }
+}
+
+// step 3: csc_ptr[i] = local prefix + block offset = cursor[i]   (csc_ptr[n], the total, is written by gl_sort_kernel:
+// after the fill the cursor of the last target stands at it)
+__global__ __launch_bounds__(GL_BLOCK) void gl_scan_apply_kernel(int64_t n, const int32_t* __restrict__ local, const int32_t* __restrict__ block_sum,
+                                                                 int32_t* __restrict__ csc_ptr, int32_t* __restrict__ cursor) {
+  const int64_t i = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
+  if (i < n) {
+    const int32_t p = local[i] + block_sum[i / GL_SCAN_TILE];
+    csc_ptr[i] = p;
+    cursor[i] = p;
+  }
+}
+
+// unordered fill: entry eid goes to the next free slot of its target
+__global__ __launch_bounds__(GL_BLOCK) void gl_fill_kernel(int64_t n_entries, const int32_t* __restrict__ nlist,
+                                                           const float* __restrict__ edges, int32_t* __restrict__ cursor,
+                                                           int32_t* __restrict__ tmp) {
+  const int64_t eid = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
+  if (eid >= n_entries) return;
+  if (edges != nullptr && !(edges[eid] > 0.f)) return;
+  const int pos = atomicAdd(&cursor[nlist[eid]], 1);
+  tmp[pos] = (int32_t)eid;
+}
+
+// one thread per target: its segment of tmp in ascending entry id -> csc_edge (rank sort; segments are in-degree long)
+__global__ __launch_bounds__(GL_BLOCK) void gl_sort_kernel(int64_t n, const int32_t* __restrict__ cursor, int32_t* __restrict__ csc_ptr,
+                                                           const int32_t* __restrict__ tmp, int32_t* __restrict__ csc_edge) {
+  const int64_t t = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  const int p0 = csc_ptr[t], p1 = cursor[t];      // after the fill a cursor stands at the end of its segment
+  if (t == n - 1) csc_ptr[n] = p1;
+  for (int a = p0; a < p1; ++a) {
+    const int32_t v = tmp[a];
+    int rank = 0;
+    for (int b = p0; b < p1; ++b) rank += tmp[b] < v ? 1 : 0;     // entry ids are distinct
+    csc_edge[p0 + rank] = v;
+  }
+}
+
+}  // namespace ng
+
+using namespace ng;
+
+extern "C" size_t ng_incoming_lists_scratch_bytes(int64_t N, int64_t n_entries) {
+  const int64_t nb = cdiv(std::max<int64_t>(N, 1), GL_SCAN_TILE);
+  return (size_t)(2 * N + nb + n_entries + 16) * sizeof(int32_t);
+}
+
+extern "C" int ng_build_incoming_lists(ng_ctx* ctx, void* stream, int64_t N, int K, int64_t n_entries, const int32_t* nlist,
+                                       const float* edges, int32_t* nlist_c, int32_t* csc_ptr, int32_t* csc_edge) {
+  NG_REQUIRE(ctx, N >= 0 && n_entries >= 0 && n_entries < ((int64_t)1 << 31), "incoming lists: sizes out of range");
+  NG_REQUIRE(ctx, csc_ptr && csc_edge, "incoming lists: csc_ptr / csc_edge required");
+  NG_REQUIRE(ctx, nlist_c == nullptr || K > 0, "incoming lists: nlist_c needs the padded form (K > 0)");
+  NG_REQUIRE(ctx, K == 0 || n_entries == N * K, "incoming lists: padded form has N*K entries");
+  hipStream_t st = (hipStream_t)stream;
+  DeviceGuard dg(ctx->device);
+  if (N == 0) { NG_HIP(ctx, hipMemsetAsync(csc_ptr, 0, sizeof(int32_t), st)); return NG_OK; }
+  const int nb = (int)cdiv(N, GL_SCAN_TILE);
+  int32_t* ws = (int32_t*)aux_workspace(ctx, ng_incoming_lists_scratch_bytes(N, n_entries));
+  if (!ws) return NG_ERR_HIP;
+  int32_t* count = ws;                 // [N]  counts -> local prefixes
+  int32_t* cursor = count + N;         // [N]
+  int32_t* bsum = cursor + N;          // [nb]
+  int32_t* tmp = bsum + nb;            // [n_entries]
+  ProfScope ps(ctx, st, "incoming_lists");
+  NG_HIP(ctx, hipMemsetAsync(count, 0, (size_t)N * sizeof(int32_t), st));
+  if (n_entries > 0)
+    hipLaunchKernelGGL(gl_count_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, K, nlist, edges,
+                       nlist_c, count);
+  hipLaunchKernelGGL(gl_scan_local_kernel, dim3(nb), dim3(GL_BLOCK), 0, st, N, count, bsum);
+  hipLaunchKernelGGL(gl_scan_sums_kernel, dim3(1), dim3(GL_BLOCK), 0, st, nb, bsum);
+  hipLaunchKernelGGL(gl_scan_apply_kernel, dim3((unsigned)cdiv(N, GL_BLOCK)), dim3(GL_BLOCK), 0, st, N, count, bsum, csc_ptr,
+                     cursor);
+  if (n_entries > 0)
+    hipLaunchKernelGGL(gl_fill_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, nlist, edges,
+                       cursor, tmp);
+  hipLaunchKernelGGL(gl_sort_kernel, dim3((unsigned)cdiv(N, GL_BLOCK)), dim3(GL_BLOCK), 0, st, N, cursor, csc_ptr, tmp, csc_edge);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}

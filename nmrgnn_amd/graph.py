@@ -67,8 +67,9 @@ class GraphBatch:
         if nlist_c is not None:            # the caller knows the lists carry no padded slot (e.g. kNN with n > K)
             self.nlist_c = nlist_c
         else:
-            own = torch.arange(self.N, dtype=torch.int32, device=self.device)[:, None]
-            self.nlist_c = torch.where(self.edges > 0, self.nlist, own).contiguous()
+            # one library call builds the compute-side list AND the incoming-edge lists (ng_build_incoming_lists)
+            self.nlist_c = torch.empty_like(self.nlist)
+            self._build_lists(self.nlist_c)
 
     # ------------------------------------------------------------------ CSR form
     @classmethod
@@ -146,26 +147,46 @@ class GraphBatch:
     def n_edges(self):
         return self.nnz if self.is_csr else self.N * self.K
 
+    def _build_lists(self, nlist_c=None):
+        """csc_ptr [N+1] / csc_edge [n_entries capacity; csc_ptr[N] live entries] by the library's counting sort — a
+        stable sort of the live entries by target, no host synchronisation, no torch kernels (include/nmrgnn_hip.h:
+        ng_build_incoming_lists; the reference sees a new graph every step, nmrgnn/library.py:88-89)."""
+        if self.device.type != "cuda":
+            return self._build_lists_host(nlist_c)
+        import ctypes as C
+        from . import _lib
+        from ._lib import ptr
+        ctx = _lib.get_context(self.device.index)
+        n_entries = self.n_edges
+        csc_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=self.device)
+        csc_edge = torch.empty(max(n_entries, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            ctx.check(ctx.lib.ng_build_incoming_lists(ctx.handle, st, self.N, 0 if self.is_csr else self.K, n_entries,
+                                                      ptr(self.nlist), None if self.is_csr else ptr(self.edges),
+                                                      ptr(nlist_c), ptr(csc_ptr), ptr(csc_edge)),
+                      "ng_build_incoming_lists")
+        self._csc = (csc_ptr, csc_edge)
+
+    def _build_lists_host(self, nlist_c=None):
+        """the same lists with torch ops, for batches held in HOST memory (shard bookkeeping in the multi-process CPU
+        tests); a device batch never comes here"""
+        if nlist_c is not None:
+            own = torch.arange(self.N, dtype=torch.int32)[:, None]
+            nlist_c.copy_(torch.where(self.edges > 0, self.nlist, own))
+        flat = self.nlist.reshape(-1)
+        eid = torch.arange(flat.shape[0]) if self.is_csr else torch.nonzero((self.edges > 0).reshape(-1)).reshape(-1)
+        tgt = flat[eid].to(torch.int64)
+        order = torch.argsort(tgt, stable=True)
+        ptr = torch.zeros(self.N + 1, dtype=torch.int64)
+        ptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=self.N), 0)
+        self._csc = (ptr.to(torch.int32).contiguous(), eid[order].to(torch.int32).contiguous())
+
     def csc(self):
-        """incoming-edge lists for the backward scatter; built once per batch."""
-        if self._csc is None and self.is_csr:
-            tgt = self.nlist.to(torch.int64)
-            order = torch.argsort(tgt, stable=True)
-            counts = torch.bincount(tgt, minlength=self.N)
-            ptr = torch.zeros(self.N + 1, dtype=torch.int64, device=self.device)
-            ptr[1:] = torch.cumsum(counts, 0)
-            self._csc = (ptr.to(torch.int32).contiguous(), order.to(torch.int32).contiguous())
+        """incoming-edge lists for the backward scatter; built once per batch.  ``csc_edge`` is allocated for every
+        entry; its first ``csc_ptr[N]`` elements are the live ones (the kernels walk it through ``csc_ptr``)."""
         if self._csc is None:
-            N, K = self.N, self.K
-            valid = (self.edges > 0).reshape(-1)
-            eid = torch.nonzero(valid, as_tuple=False).reshape(-1)
-            tgt = self.nlist.reshape(-1)[eid].to(torch.int64)
-            order = torch.argsort(tgt, stable=True)
-            csc_edge = eid[order].to(torch.int32).contiguous()
-            counts = torch.bincount(tgt, minlength=N)
-            ptr = torch.zeros(N + 1, dtype=torch.int64, device=self.device)
-            ptr[1:] = torch.cumsum(counts, 0)
-            self._csc = (ptr.to(torch.int32).contiguous(), csc_edge)
+            self._build_lists(None)
         return self._csc
 
     def as_tuple(self):
