@@ -3,6 +3,7 @@
 #include <map>
 
 #include "ng_common.h"
+#include "ng_internal.h"
 
 namespace ng {
 
@@ -33,6 +34,16 @@ static void load_switches() {
 const Switches& sw() {
   if (!g_sw_loaded) load_switches();
   return g_sw;
+}
+
+// the guard word lives at the END of the small scratch (the gradient-scale slots grow from its start: gemm_h2.hip)
+RangeGuard range_guard_begin(ng_ctx* ctx) {
+  RangeGuard g;
+  char* s = (char*)small_scratch(ctx);
+  g.word = s ? reinterpret_cast<unsigned*>(s + NG_SMALL_BYTES - 64) : nullptr;
+  if (++ctx->range_epoch == 0) ++ctx->range_epoch;
+  g.epoch = ctx->range_epoch;
+  return g;
 }
 
 void* workspace(ng_ctx* ctx, size_t bytes) {
@@ -87,6 +98,7 @@ void* small_scratch(ng_ctx* ctx) {
     ctx->err = std::string("small scratch hipMalloc: ") + hipGetErrorString(e);
     return nullptr;
   }
+  (void)hipMemset(p, 0, NG_SMALL_BYTES);      // the range-guard word must not start out equal to an epoch
   ctx->small = p;
   return p;
 }

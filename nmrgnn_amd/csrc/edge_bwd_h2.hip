@@ -94,6 +94,7 @@ struct EdgeBwdH2Args {
   int E;
   int tape_blocked;     // z_save layout: 1 = blocked inside full 32-edge groups (edge_fused.h), 0 = row-major
   unsigned long long* stamps;
+  RangeGuard guard;     // raised when a partial comes out non-finite (an operand left the fp16 range)
 };
 
 // W^T fragments of the dZ GEMMs: lane (row k = 32 zk + (l&31), k-slot t) = piece_p( 2^8 W[k][n = 16 ks + 8 (l>>5) + t] )
@@ -525,6 +526,21 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   // ---------------------------------------------------------------------- write this workgroup's partial
   float* part = a.partial + (int64_t)blockIdx.x * a.part_stride;
   {
+    // range guard (ng_internal.h): an activation or weight beyond the fp16 range has turned into NaN in the products
+    float chk = 0.f;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) chk += fabsf(accW[l][j][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) chk += fabsf(accB[r]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) chk += fabsf(accWo[n]) + fabsf(accbo[n]);
+    range_guard_raise(a.guard, not_finite(chk * ginv));
+  }
+  {
     const int k = kslab * 32 + l31;
 #pragma unroll
     for (int l = 0; l < 3; ++l)
@@ -636,7 +652,7 @@ size_t edge_bwd_h2_ws_bytes() { return HX_WT_BYTES + (size_t)(HX_SCALE_BLOCKS + 
 // wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_h2_segments(n_edges) * grid][part_stride]
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked) {
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard) {
   float* blockmax = reinterpret_cast<float*>(wt_img + HX_WT_BYTES);
   float* scale = blockmax + HX_SCALE_BLOCKS;
   {
@@ -656,6 +672,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     a.wt_img = wt_img; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH; a.de = de + e0 * E;
     a.partial = partial + (size_t)sg * grid * part_stride; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;
     a.stamps = nullptr;
+    a.guard = guard;
 #ifdef HX_STAMP
     static unsigned long long* dbg = nullptr;
     if (!dbg) { hipMalloc(&dbg, 1024); }

@@ -50,5 +50,5 @@ size_t edge_bwd_h2_ws_bytes();
 // layout of edge_fused_bwd.hip
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked);
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard);
 }  // namespace ng

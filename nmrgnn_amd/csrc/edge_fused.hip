@@ -67,6 +67,8 @@ struct EdgeFwdArgs {
   float* e_out;           // [n_edges][E]
   float* z_save;          // [3][n_edges][128] or nullptr
   float* dummy;           // 128 floats: where rows past the end store
+  int tape_blocked;       // z_save layout (edge_fused.h: edge_tape_blocked): 1 = the split-operand kernels' blocked form
+  RangeGuard guard;       // word != nullptr: run only if the guard carries this epoch (fallback of edge_fwd_h2)
 };
 
 __device__ __forceinline__ void load_wfrag(float (&wf)[64], const float* __restrict__ Wpk, int layer,
@@ -153,16 +155,27 @@ __device__ __forceinline__ void hidden_layer(float (&wf)[64], const float* __res
 // Rows past the end go to a dummy row instead of being skipped: with a fixed number of stores per tile the
 // compiler's vmcnt counts for the next layer's weight slab stay exact (otherwise the last waits of the
 // MFMA chain also wait for these stores to be acknowledged).
+// float offset of (edge gr, features col..col+3) in a tape layer: row-major, or — inside every FULL group of 32 edges of
+// a blocked tape — the split-operand kernels' register order (edge_fused.h)
+__device__ __forceinline__ int64_t tape_offset(int64_t gr, int col, int64_t n_rows, int blocked) {
+  const int64_t g = gr >> 5;
+  if (blocked && (g + 1) * 32 <= n_rows) {
+    const int bo = col >> 5, q = (col >> 3) & 3, hf = (col >> 2) & 1, r = (int)(gr & 31);
+    return g * 4096 + ((bo * 4 + q) * 64 + hf * 32 + r) * 4;
+  }
+  return gr * FH + col;
+}
+
 __device__ __forceinline__ void save_tile(const float* __restrict__ X, float* __restrict__ dst,
                                           float* __restrict__ dummy, int64_t row0, int64_t n_rows, int wave,
-                                          int lane) {
+                                          int lane, int blocked) {
   const int col = (lane & 31) * 4;
   typedef float nt4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = 16 * wave + 2 * i + (lane >> 5);
     const float4 v = *reinterpret_cast<const float4*>(X + r * FLD + col);
-    float* d = row0 + r < n_rows ? dst + (row0 + r) * FH + col : dummy + col;
+    float* d = row0 + r < n_rows ? dst + tape_offset(row0 + r, col, n_rows, blocked) : dummy + col;
     __builtin_nontemporal_store(nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4*>(d));
   }
 }
@@ -174,6 +187,7 @@ __device__ __forceinline__ void save_tile(const float* __restrict__ X, float* __
 template <int E, bool SAVE, int TM>
 __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kernel(EdgeFwdArgs a) {
   constexpr int NTHR = TM * 4;
+  if (a.guard.word && !range_guard_raised(a.guard)) return;      // fallback launch: nothing went out of range
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* X0 = smem;                         // [TM][132]
   float* X1 = smem + TM * FLD;              // [TM][132]
@@ -243,15 +257,15 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
       ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
     }
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X1, a.z_save, a.dummy, row0, a.n_edges, wave, lane);
+    if (SAVE) save_tile(X1, a.z_save, a.dummy, row0, a.n_edges, wave, lane, a.tape_blocked);
     // ---- hidden layer 1: X1 -> X0
     hidden_layer(wf, X1, X0, sBias + FH, slab, rbase, lane, a.Wpk, 2);
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane);
+    if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane, a.tape_blocked);
     // ---- hidden layer 2: X0 -> X1   (reloads layer 0's slab for the next tile)
     hidden_layer(wf, X0, X1, sBias + 2 * FH, slab, rbase, lane, a.Wpk, 0);
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane);
+    if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane, a.tape_blocked);
     // ---- output layer: wave w -> rows 16w..16w+15, 4 lanes per row (k = 16i + 4*(lane&3) + s)
     {
       const int r = 16 * wave + (lane >> 2), qq = lane & 3;
@@ -299,13 +313,25 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* const* b, float* e_out, float* z_save) {
   if (edge_split_enabled()) return edge_h2_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
+  return edge_fused_fwd_f32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save, false, nullptr);
+}
+
+// f32-input MFMA forward.  guard != nullptr: the range fallback of edge_h2_fwd — same launches, but the kernel's
+// workgroups return at once unless the split-operand kernel raised the guard; the tape is then written in the layout
+// that kernel would have used.  Its fragment copy lives in the AUX scratch: the main workspace may hold the
+// split-operand image the first kernel is still reading.
+int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
+                       const float* d_eff, const float* centers, float gap, const float* const* W,
+                       const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard) {
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
-  float* Wpk = (float*)workspace(ctx, (pk_floats + FH) * 4);
+  float* Wpk = (float*)(guard ? aux_workspace(ctx, (pk_floats + FH) * 4) : workspace(ctx, (pk_floats + FH) * 4));
   if (!Wpk) return NG_ERR_NOMEM;
   int rc = edge_fused_pack(ctx, st, W, Wpk, nullptr);
   if (rc) return rc;
   EdgeFwdArgs a;
+  a.tape_blocked = tape_blocked ? 1 : 0;
+  a.guard = guard ? *guard : RangeGuard{nullptr, 0};
   a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
   a.neg_inv_gap = (float)(-1.0 / (double)gap);
   a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
@@ -318,7 +344,7 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const int64_t ntiles = cdiv(n_edges, TMr);
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * 2);
   const size_t lds = (size_t)(2 * TMr * FLD + FH * FMAX_E + TMr + 4 * FH) * 4;
-  ProfScope ps(ctx, st, "edge_fused_fwd");
+  ProfScope ps(ctx, st, guard ? "edge_fwd_range_fallback" : "edge_fused_fwd");
 #define NG_FW1(EE, SV) hipLaunchKernelGGL((edge_fused_fwd_kernel<EE, SV, 64>), dim3(grid), dim3(256), lds, st, a);
 #define NG_FW(EE)                                                                                  \
   case EE:                                                                                         \

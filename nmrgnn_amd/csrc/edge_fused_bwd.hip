@@ -38,13 +38,25 @@ struct EdgeBwdArgs {
   const float* de;      // [n_edges][E]
   float* partial;       // [grid][part_stride]
   int part_stride;
+  int tape_blocked;     // z_save layout (edge_fused.h), 1 = blocked inside full 32-edge groups
+  int zero_rows;        // fallback of a multi-segment split-operand launch: partial rows grid .. zero_rows-1 are cleared
+  RangeGuard guard;     // word != nullptr: run only if the guard carries this epoch (fallback of edge_bwd_h2)
 };
 
 // partial layout (floats): dW[3][128*128] | db[3][128] | dWo[128*E] | dbo[E]
 __host__ __device__ inline int bwd_part_floats(int E) { return 3 * FH * FH + 3 * FH + FH * E + E; }
 
+__device__ __forceinline__ int64_t bw_tape_offset(int64_t gr, int col, int64_t n_rows, int blocked) {
+  const int64_t g = gr >> 5;
+  if (blocked && (g + 1) * 32 <= n_rows) {
+    const int bo = col >> 5, q = (col >> 3) & 3, hf = (col >> 2) & 1, r = (int)(gr & 31);
+    return g * 4096 + ((bo * 4 + q) * 64 + hf * 32 + r) * 4;
+  }
+  return gr * FH + col;
+}
+
 __device__ __forceinline__ void tile_to_regs(float4 (&pz)[4], const float* __restrict__ src,
-                                             int64_t row0, int64_t n_rows, int tid) {
+                                             int64_t row0, int64_t n_rows, int tid, int blocked) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int lin = tid + i * BW_THREADS;
@@ -53,7 +65,7 @@ __device__ __forceinline__ void tile_to_regs(float4 (&pz)[4], const float* __res
     // that every tile re-reads from L2
     typedef float nt4 __attribute__((ext_vector_type(4)));
     if (row0 + row < n_rows) {
-      const nt4 v = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(src + (row0 + row) * FH + c4 * 4));
+      const nt4 v = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(src + bw_tape_offset(row0 + row, c4 * 4, n_rows, blocked)));
       pz[i] = make_float4(v[0], v[1], v[2], v[3]);
     } else {
       pz[i] = f4zero();
@@ -158,6 +170,7 @@ __device__ __forceinline__ void dz_gemm_epilogue(const float* __restrict__ G,
 
 template <int E>
 __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdArgs a) {
+  if (a.guard.word && !range_guard_raised(a.guard)) return;      // fallback launch: nothing went out of range
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufA = smem;                    // Z3 -> G2 -> R
   float* bufB = bufA + FTM * FLD;        // Z2 -> G1
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   float4 pzA[4], pzB[4];
   float pf_ds = 0.f, pf_dn = 0.f, pf_de = 0.f, pf_dm = 0.f;
   auto prefetch = [&](int64_t row0) {
-    tile_to_regs(pzA, Z3g, row0, a.n_edges, tid);
+    tile_to_regs(pzA, Z3g, row0, a.n_edges, tid, a.tape_blocked);
     pf_ds = 0.f; pf_dn = 0.f; pf_de = 0.f; pf_dm = 0.f;
     if (tid < FTM) {
       const int64_t gr = row0 + tid;
@@ -229,9 +242,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
     regs_to_lds(pzA, bufA, tid);
     // Z2 is requested here and lands in bufB at the end of this phase (~6k cycles of cover): holding it in
     // registers across the previous tile's last GEMM cost 16 VGPRs at the kernel's pressure peak
-    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid);
+    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid, a.tape_blocked);
     NG_LDS_BARRIER();
-    tile_to_regs(pzA, Z1g, row0, a.n_edges, tid);   // lands in bufC at the end of phase B
+    tile_to_regs(pzA, Z1g, row0, a.n_edges, tid, a.tape_blocked);   // lands in bufC at the end of phase B
     // G3 = (dE Wo^T) * s'(Z3) -> bufC
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -325,6 +338,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   __syncthreads();
   for (int t = tid; t < red_stride; t += BW_THREADS)
     part[3 * FH * FH + t] = red[t] + red[red_stride + t] + red[2 * red_stride + t] + red[3 * red_stride + t];
+  // rows the (multi-segment) split-operand launch filled beyond this kernel's grid
+  for (int64_t rowz = (int64_t)gridDim.x + blockIdx.x; rowz < a.zero_rows; rowz += gridDim.x)
+    for (int t = tid; t < a.part_stride; t += BW_THREADS) a.partial[rowz * a.part_stride + t] = 0.f;
 }
 
 struct BwdOut {
@@ -384,6 +400,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.neg_inv_gap = (float)(-1.0 / (double)gap);
   a.WpkT = WpkT; a.Wo = W[3]; a.z_save = z_save; a.de = de;
   a.partial = partial; a.part_stride = stride;
+  a.tape_blocked = 0; a.zero_rows = 0; a.guard = RangeGuard{nullptr, 0};
   const size_t lds = (size_t)(3 * FTM * FLD + FH * FMAX_E + FTM * FMAX_E + 2 * FTM + FH) * 4;
   // default: split-operand kernel on the 16-bit matrix pipe (edge_bwd_h2.hip); NG_EDGE_MATH=fp32 (both directions) or
   // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
@@ -392,13 +409,20 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const bool blocked = tape_layout < 0 ? edge_tape_blocked(E, n_edges) : tape_layout == 1;
   if (blocked && !edge_bwd_h2_supported(E, n_edges)) return fail(ctx, NG_ERR_INVALID, "edge_mlp_bwd: blocked tape for an unsupported shape");
   int n_part = grid;
-  if (blocked || edge_tape_blocked(E, n_edges)) {
+  const bool split = blocked || edge_tape_blocked(E, n_edges);
+  if (split) {
+    const RangeGuard guard = range_guard_begin(ctx);
+    if (!guard.word) return NG_ERR_NOMEM;
     int rc3 = edge_bwd_h2_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
-                     (char*)(partial + (size_t)nseg * grid * stride), partial, stride, grid, blocked ? 1 : 0);
+                     (char*)(partial + (size_t)nseg * grid * stride), partial, stride, grid, blocked ? 1 : 0, guard);
     if (rc3) return rc3;
     n_part = nseg * grid;
-  } else {
-    ProfScope ps(ctx, st, "edge_fused_bwd");
+    // range fallback: the f32-input kernel below, executed only if the split-operand kernel raised the guard; it
+    // rewrites the same partial rows (and clears the rows of further segments)
+    a.tape_blocked = blocked ? 1 : 0; a.zero_rows = n_part; a.guard = guard;
+  }
+  {
+    ProfScope ps(ctx, st, split ? "edge_bwd_range_fallback" : "edge_fused_bwd");
 #define NG_BW(EE)                                                                                   \
   case EE:                                                                                          \
     hipLaunchKernelGGL((edge_fused_bwd_kernel<EE>), dim3(grid), dim3(BW_THREADS), lds, st, a);      \

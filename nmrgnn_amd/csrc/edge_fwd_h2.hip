@@ -87,6 +87,7 @@ struct EdgeH2Args {
   float* e_out;
   float* z_save;          // [3][n_edges][128] or nullptr
   float* dummy;           // 128 floats
+  RangeGuard guard;       // raised when an output comes out non-finite (an operand left the fp16 range)
 };
 
 // one chunk = 32 wave-instructions of 1 KB; wave w moves KB w, w+8, w+16, w+24 (scalar resource + scalar offset + one
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   use_s ^= 1;
 
   u32x4 bf[4][2][2];
+  bool bad = false;
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t gr = tile * H2_TM + 32 * wave + l31;
@@ -331,11 +333,16 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ne = r + 4 * hf;
-          if (ne < a.E) a.e_out[gr * a.E + ne] = mask * fmaf(acc[r], H2_WINV, sBo[ne]);
+          if (ne < a.E) {
+            const float v = mask * fmaf(acc[r], H2_WINV, sBo[ne]);
+            bad |= not_finite(v);
+            a.e_out[gr * a.E + ne] = v;
+          }
         }
       }
     }
   }
+  range_guard_raise(a.guard, bad);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
@@ -362,6 +369,8 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.bo = b[3]; a.E = E; a.e_out = e_out; a.z_save = z_save;
   a.dummy = (float*)(img + img_bytes);
+  a.guard = range_guard_begin(ctx);
+  if (!a.guard.word) return NG_ERR_NOMEM;
   const int64_t ntiles = cdiv(n_edges, H2_TM);
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const size_t misc = (size_t)(FH + 3 * FH + 32) * 4;
@@ -373,7 +382,9 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   else
     hipLaunchKernelGGL(edge_fwd_h2_kernel<0>, dim3(grid), dim3(512), 2 * H2_RING + misc, st, a);
   NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  // the same call on f32-input MFMA, executed only if the kernel above raised the guard (operands beyond the fp16 range)
+  return edge_fused_fwd_f32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save,
+                            z_save && edge_tape_blocked(E, n_edges), &a.guard);
 }
 
 }  // namespace ng

@@ -43,6 +43,8 @@ struct ng_ctx {
   int wowner = 0;
   uint64_t wver = 1;
   std::map<std::pair<const void*, int>, WImage> wimg;
+  // operand-range guard of the fp16-piece kernels (ng_internal.h: RangeGuard): call counter behind the epochs
+  uint32_t range_epoch = 0;
 };
 
 namespace ng {

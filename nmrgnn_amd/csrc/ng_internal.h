@@ -6,6 +6,29 @@
 
 namespace ng {
 
+// ---- operand-range guard of the fp16-piece ("h2") kernels (round 3) ------------------------------------------------
+// Two fp16 pieces hold |x| < 65504; the reference's Dense / einsum are plain fp32 (nmrgnn/model.py:132-138,
+// layers.py:39-40) and return finite numbers far beyond that.  An operand outside the range turns into inf - inf = NaN
+// in the piece products, so every h2 kernel checks its OUTPUTS for non-finite values and, if it sees one, stores the
+// call's epoch into a per-context device word; the entry point then launches the f32-input MFMA kernel of the same
+// contract with the same (word, epoch): its workgroups return at once unless the word carries their epoch, in which
+// case they recompute the whole call.  No host synchronisation, no flag to clear (epochs are unique per call, calls on
+// one stream are ordered), ~2 us of empty launch per guarded call.  A genuinely non-finite input takes the fp32 path as
+// well and comes out non-finite there too.
+struct RangeGuard {
+  unsigned* word;     // device word of the context (small scratch)
+  unsigned epoch;     // this call's number, never 0
+};
+RangeGuard range_guard_begin(ng_ctx* ctx);
+// kernels: raise when `bad` (any lane), test at the top of the fallback
+__device__ __forceinline__ void range_guard_raise(RangeGuard g, bool bad) {
+  if (bad) __hip_atomic_store(g.word, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool range_guard_raised(RangeGuard g) {
+  return __hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
+}
+__device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) < INFINITY); }
+
 // Y = act(rowscale[m] * (X @ W) + b) (+ R);  S (optional) receives the activation output.
 int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
               const float* W, const float* b, const float* rowscale, const float* R, float* Y,
@@ -49,6 +72,9 @@ bool edge_fused_supported(int H, int E, int Le);
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
                    const float* const* b, float* e_out, float* z_save);
+int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
+                       const float* d_eff, const float* centers, float gap, const float* const* W,
+                       const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard);
 
 // elementwise helpers (node_ops.hip)
 int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp);

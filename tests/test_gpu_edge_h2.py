@@ -307,25 +307,88 @@ def test_edge_forward_split_across_weight_magnitudes(gpu_device, monkeypatch, ws
         assert dz["f16x2"] < 2.0 * dz["fp32"] + 5e-7, (wscale, l, dz)
 
 
-def test_edge_forward_split_overflow_is_loud(gpu_device, monkeypatch):
-    """The documented range limit of the two-piece fp16 operands: an ACTIVATION at or above 65504 (here: weights 40 times
-    Glorot's, a gain of ~68 per layer, third-layer activations ~1e5) overflows the h piece.  The result must then be
-    non-finite — never a finite wrong number — while NG_EDGE_MATH=fp32 still evaluates the same inputs."""
-    n, E = 1024, 3
-    rng = np.random.default_rng(18)
+def _overflow_case(n=1024, E=3, seed=18, wscale=6.0):
+    rng = np.random.default_rng(seed)
     d_src = rng.uniform(0.05, 1.2, n)
+    d_src[rng.random(n) < 0.1] = 0.0
     centers = np.linspace(0.0, 1.2, H)
     gap = centers[1] - centers[0]
-    Ws = [rng.standard_normal((H, H)) * 6.0 for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2]
+    # weights 40 times Glorot's: a gain of ~68 per layer, third-layer activations ~1e5 — beyond the 65504 of an fp16 piece
+    Ws = [rng.standard_normal((H, H)) * wscale for _ in range(3)] + [rng.standard_normal((H, E)) * 0.2]
     bs = [rng.standard_normal(H) * 0.1 for _ in range(3)] + [rng.standard_normal(E) * 0.1]
+    return d_src, centers, gap, Ws, bs
+
+
+@pytest.mark.parametrize("n", [1024, 1000])          # full 32-edge tape groups only / with a row-major tail group
+def test_edge_forward_beyond_the_fp16_range_equals_float64(gpu_device, monkeypatch, n):
+    """The reference's Dense layers are plain fp32 (nmrgnn/model.py:132-138): an activation of 1e5 is an ordinary number.
+    The default kernels split operands into fp16 pieces (|x| < 65504); when an operand leaves that range the kernel
+    raises the range guard and the entry point re-runs the call on f32-input MFMA by itself (ng_internal.h:
+    RangeGuard) — outputs AND the saved-activation tape (in the layout the split-operand kernel would have written)
+    equal the float64 statement, as they do with NG_EDGE_MATH=fp32."""
+    E = 3
+    d_src, centers, gap, Ws, bs = _overflow_case(n, E)
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     e_ref, z_ref = ref_edge(f32(d_src), f32(d_src), f32(centers), float(np.float32(gap)), [f32(w) for w in Ws], [f32(b) for b in bs])
     assert np.abs(z_ref[2]).max() > 65504                         # the case really leaves the fp16 range
+    out = {}
+    for math in ("f16x2", "fp32"):
+        monkeypatch.setenv("NG_EDGE_MATH", math)
+        out[math] = run_gpu(gpu_device, d_src, d_src, centers, gap, Ws, bs, E, True)
+    tol = 1e-4 * np.abs(e_ref).max()
+    for math in ("f16x2", "fp32"):
+        e, z = out[math]
+        assert np.isfinite(e).all() and np.isfinite(z).all(), math
+        assert np.abs(e - e_ref).max() < tol, math
+        for l in range(3):
+            assert np.abs(z[l] - z_ref[l]).max() < 1e-5 * np.abs(z_ref[l]).max(), (math, l)
+    # the fallback IS the f32-input kernel: same bits as the explicit switch
+    np.testing.assert_array_equal(out["f16x2"][0], out["fp32"][0])
+    assert np.all(out["f16x2"][0][d_src == 0] == 0.0)
+    # and an in-range call right after it is back on the split-operand kernels (the guard is per call)
     monkeypatch.setenv("NG_EDGE_MATH", "f16x2")
-    e_h2, _ = run_gpu(gpu_device, d_src, d_src, centers, gap, Ws, bs, E, False)
-    over = np.abs(z_ref[2]).max(axis=1) > 70000                   # edges with an overflowing activation
-    assert over.any() and not np.isfinite(e_h2[over]).any()
+    Wn = [w * (0.15 / 6.0) for w in Ws[:3]] + [Ws[3]]
+    e2, _ = run_gpu(gpu_device, d_src, d_src, centers, gap, Wn, bs, E, False)
     monkeypatch.setenv("NG_EDGE_MATH", "fp32")
-    e_32, _ = run_gpu(gpu_device, d_src, d_src, centers, gap, Ws, bs, E, False)
-    assert np.isfinite(e_32).all()
-    assert np.abs(e_32 - e_ref).max() < 1e-4 * np.abs(e_ref).max()
+    e3, _ = run_gpu(gpu_device, d_src, d_src, centers, gap, Wn, bs, E, False)
+    assert np.isfinite(e2).all() and not np.array_equal(e2, e3)     # different arithmetic, both fine
+    assert np.abs(e2 - e3).max() < 1e-5 * max(np.abs(e3).max(), 1.0)
+
+
+def test_edge_backward_beyond_the_fp16_range_equals_float64(gpu_device, monkeypatch):
+    """the same for the weight / bias gradients.  The backward splits Z1, Z2 (dW operands) and the weights into fp16 pieces
+    (Z3 only enters fp32 VALU work), so the case needs SECOND-layer activations beyond 65504: weights 200 times Glorot's"""
+    n, E = 3000, 3
+    d_src, centers, gap, Ws, bs = _overflow_case(n, E, seed=4, wscale=30.0)
+    rng = np.random.default_rng(2)
+    de = rng.standard_normal((n, E))
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    Wf, bf = [f32(w) for w in Ws], [f32(b) for b in bs]
+    _, _, zs = ref_edge_bwd(f32(d_src), f32(d_src), f32(centers), float(np.float32(gap)), Wf, bf, f32(de))
+    zs32 = [f32(z) for z in zs]
+    assert np.abs(zs32[1]).max() > 65504 and np.isfinite(zs32[2]).all()
+    m = (f32(d_src) > 0).astype(np.float64)
+    R = np.exp(-(f32(d_src)[:, None] - f32(centers)[None, :]) ** 2 / float(np.float32(gap))) * m[:, None]
+    xs = [R] + zs32
+    dE = f32(de) * m[:, None]
+    ref_dW, ref_db, mag_dW, mag_db = [None] * 4, [None] * 4, [None] * 4, [None] * 4
+    ref_dW[3], ref_db[3] = xs[3].T @ dE, dE.sum(0)
+    mag_dW[3], mag_db[3] = np.abs(xs[3]).T @ np.abs(dE), np.abs(dE).sum(0)
+    g = dE @ Wf[3].T
+    for l in (2, 1, 0):
+        G = g * (1.0 - np.exp(-xs[l + 1]))
+        ref_dW[l], ref_db[l] = xs[l].T @ G, G.sum(0)
+        mag_dW[l], mag_db[l] = np.abs(xs[l]).T @ np.abs(G), np.abs(G).sum(0)
+        g = G @ Wf[l].T
+    out = {}
+    for math in ("f16x2", "fp32"):
+        monkeypatch.setenv("NG_EDGE_MATH", math)
+        out[math] = run_gpu_bwd(gpu_device, d_src, d_src, centers, gap, Ws, zs32, de, E)
+    for l in range(4):
+        for ref, mag, k in ((ref_dW[l], mag_dW[l], 0), (ref_db[l], mag_db[l], 1)):
+            scale = max(mag.max(), 1e-6)
+            for math in ("f16x2", "fp32"):
+                got = out[math][k][l]
+                assert np.isfinite(got).all(), (math, l, k)
+                assert np.abs(got - ref).max() / scale < 2e-6, (math, l, k)
+        np.testing.assert_array_equal(out["f16x2"][0][l], out["fp32"][0][l])
