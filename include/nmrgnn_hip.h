@@ -52,7 +52,11 @@ int ng_reload_env(void);
  * every call.  The images are keyed by the weight tensors' addresses, so `owner` names the model they belong to: a
  * call with a different non-zero owner discards what the cache holds (another model's freed weights may have had the
  * same addresses).  A change of a weight tensor of the current owner must be announced with ng_weights_changed(ctx)
- * (ng_adam_step does so itself).  Off (owner 0) is the default; calls made while it is off never touch the cache. */
+ * (ng_adam_step does so itself).  Off (owner 0) is the default; calls made while it is off never touch the cache.
+ * Contract while frozen: every weight pointer handed to an entry point keeps its contents until ng_weights_changed /
+ * the end of the window (a temporary tensor whose address is later reused for other weights must be announced the
+ * same way).  Weights the library repacks into its own scratch inside a call (the MPLayer backward's Wp) are never
+ * cached, so backward entry points may run inside a frozen window. */
 int ng_weights_frozen(ng_ctx* ctx, int owner);
 int ng_weights_changed(ng_ctx* ctx);
 /* Hint about the batch the following calls work on: the largest number of atoms of one member graph (the reference

@@ -106,6 +106,13 @@ void* small_scratch(ng_ctx* ctx) {
 void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* valid) {
   *valid = false;
   if (!ctx->wcache) return nullptr;
+  // A source inside the context's own scratch is a temporary (a weight matrix repacked for THIS call: the same address
+  // holds another layer's weights on the next call) — never a cache key.  Round-2 advisor finding: with the cache keyed
+  // by such an address a frozen window around a multi-layer backward multiplied with the previous layer's image.
+  auto inside = [&](const void* base, size_t n) {
+    return base && (const char*)src >= (const char*)base && (const char*)src < (const char*)base + n;
+  };
+  if (inside(ctx->ws, ctx->ws_bytes) || inside(ctx->aux, ctx->aux_bytes)) return nullptr;
   ng_ctx::WImage& w = ctx->wimg[std::make_pair(src, kind)];
   if (w.bytes < bytes) {
     DeviceGuard dg(ctx->device);

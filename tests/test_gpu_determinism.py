@@ -114,3 +114,33 @@ def test_frozen_weight_cache_tracks_weight_changes(gpu_device):
             assert torch.equal(late.forward(gb), late_ref.forward(gb))
             assert torch.equal(late.forward(gb), late_ref.forward(gb))
             del late, late_ref
+
+
+def test_backward_inside_a_frozen_window_uses_each_layers_own_weights(gpu_device):
+    """Round-2 advisor finding: the frozen-weight cache was keyed by the raw W pointer, and the MPLayer backward hands the
+    GEMMs a weight matrix it has just repacked into the context's scratch — the same address for every layer.  With
+    ng_weights_frozen on for a whole forward + backward (the C ABI does not forbid it) layer l-1 multiplied with layer
+    l's cached image.  Scratch sources are never cache keys now: gradients inside a frozen window equal the unfrozen ones
+    bit for bit, at the default width (layered GEMM path) and at F = 64."""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    for F in (256, 64):
+        hp = make_hp(atom_feature_size=F)
+        b = synth.make_batch(40, 128, 16, 10, 0.1, seed=6)        # 5120 atoms: the split-operand GEMMs take the products
+        gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+        ref = Engine(hp, 10, device=gpu_device, seed=9)
+        eng = Engine(hp, 10, device=gpu_device, seed=9)
+        dpe = torch.randn(gb.N, device=gpu_device, generator=torch.Generator(device=gpu_device).manual_seed(1))
+        ref.forward(gb, training=True, seed=5)
+        ref.backward(dpe)
+        lib, h = eng.lib, eng.ctx.handle
+        for rep in range(2):                                       # second pass: everything cacheable IS cached
+            assert lib.ng_weights_frozen(h, eng._id) == 0
+            try:
+                eng._forward(gb, True, None, None, 5)
+                eng.backward(dpe)
+            finally:
+                lib.ng_weights_frozen(h, 0)
+            assert torch.equal(eng.params.grad, ref.params.grad), (F, rep)
