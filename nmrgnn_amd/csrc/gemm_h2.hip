@@ -78,6 +78,7 @@ struct GxArgs {
   const float* rs_in;
   int act_in;
   const float* gscale;   // GRAD: {S, 1/S} of the gradient operand (device memory); nullptr: 1
+  RangeGuard guard;      // raised when an accumulator comes out non-finite (an operand beyond the fp16 range)
 };
 
 // ---- power-of-two scale of a gradient operand (header: Ranges).  The context's small scratch (64 KB, never moved)
@@ -184,6 +185,14 @@ template <int NJ>
 __device__ __forceinline__ void gx_epilogue_block(const GxArgs& a, const f32x16 (&acc)[NJ], int64_t m, int n0, float rs) {
   float4 v[NJ][4], r[NJ][4];
   const int64_t o = m * a.N + n0;
+  {   // range guard (ng_internal.h): inf - inf of an out-of-range piece arrives here as NaN
+    float chk = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) chk += fabsf(acc[j][t]);
+    range_guard_raise(a.guard, not_finite(chk * rs));
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -653,8 +662,9 @@ static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int
 }
 
 int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
-                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag) {
+                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag, RangeGuard guard) {
   GxArgs a{};
+  a.guard = guard;
   a.M = M; a.K = K; a.N = N; a.X = X; a.bias = b; a.rowscale = rowscale; a.R = R; a.Y = Y; a.S = S; a.act = act;
   return gx_launch(ctx, st, a, W, 0, false, tag);
 }
@@ -662,8 +672,10 @@ int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, c
 // dX[m][k] = (add ? add[m][k] : 0) + sum_n dP[m][n] W[k][n],  dP = dY * act'(S) * rowscale   (dense_dx's contract);
 // here the contraction runs over Nout and the output has Kin columns
 int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
-               const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag) {
+               const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag,
+               RangeGuard guard) {
   GxArgs a{};
+  a.guard = guard;
   a.M = M; a.K = Nout; a.N = Kin; a.X = dY; a.R = add; a.Y = dX; a.act = NG_ACT_NONE;
   a.Sin = act == NG_ACT_NONE ? nullptr : S; a.rs_in = rowscale; a.act_in = act;
   if (!gscale) {
@@ -696,6 +708,7 @@ struct GtArgs {
   int act;
   float* partial;          // [nz][K][N]
   const float* gscale;     // {S, 1/S} of dP (device memory)
+  RangeGuard guard;        // raised when an accumulator comes out non-finite
 };
 
 __device__ __forceinline__ u32x4 gt_tr_frag(const char* p) {
@@ -790,6 +803,16 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dw_kernel(GtArgs a) {
   }
   // D rows = n (from dP), D cols = k (from X): lane holds k = k0 + 32 (2 kh + i) + l31, n = n0 + 32 (2 nh + j) + 8q + 4 half + (0..3)
   float* part = a.partial + (int64_t)blockIdx.z * a.K * a.N;
+  {
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) chk += fabsf(acc[j][i][t]);
+    range_guard_raise(a.guard, not_finite(chk * gI));
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int k = k0 + 32 * (2 * kh + i) + l31;
@@ -939,6 +962,16 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
   }
   // D rows = n (from dP), D cols = k (from X): lane holds k = k0 + 32 (2 kh + i) + l31, n = n0 + 32 (4 nh + j) + 8q + 4 half + (0..3)
   float* part = a.partial + (int64_t)zc * a.K * a.N;
+  {
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) chk += fabsf(acc[j][i][t]);
+    range_guard_raise(a.guard, not_finite(chk * gI));
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int k = k0 + 32 * (2 * kh + i) + l31;
@@ -965,12 +998,13 @@ bool gemm_h2_dw_ok(int64_t M, int Kin, int Nout) {
 // partial[z][Kin][Nout], z < nz, rows [z * rows_per_z, ...): same partial layout as the f32-input dense_dw GEMM
 int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
                const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const float* gscale,
-               const char* tag) {
+               const char* tag, RangeGuard guard) {
   if (!gscale) {
     int rc = gemm_grad_scale(ctx, st, dY, M, Nout, rowscale, &gscale);
     if (rc) return rc;
   }
   GtArgs a;
+  a.guard = guard;
   a.gscale = gscale;
   a.M = M; a.rows_per_z = rows_per_z; a.K = Kin; a.N = Nout; a.X = X; a.dY = dY; a.S = S; a.rowscale = rowscale;
   a.act = act; a.partial = partial;

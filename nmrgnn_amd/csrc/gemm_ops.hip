@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int N, int64_t r
 // ---------------------------------------------------------------- launch helpers
 template <int BM, int BN, int WM, int WN, bool QKC, bool PKC, class LQ, class LP, class EP>
 static void launch_gemm(hipStream_t st, int64_t M, int N, int64_t K, int64_t k_chunk, int nz,
-                        LQ lq, LP lp, EP ep) {
+                        LQ lq, LP lp, EP ep, RangeGuard guard = RangeGuard{nullptr, 0}) {
   dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN), (unsigned)nz);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, 32, WM, WN, QKC, PKC, LQ, LP, EP>), grid, dim3(256), 0,
-                     st, M, N, K, k_chunk, lq, lp, ep);
+                     st, M, N, K, k_chunk, lq, lp, ep, guard.word, guard.epoch);
 }
 
 int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
@@ -128,18 +128,27 @@ int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act
               float* S, const char* tag) {
   NG_REQUIRE(ctx, Kin % 8 == 0 && Nout % 4 == 0, "dense_fwd: Kin%8, Nout%4");
   if (M == 0) return NG_OK;
-  if (gemm_h2_fwd_ok(M, Kin, Nout)) return gemm_h2_fwd(ctx, st, M, Kin, Nout, act, X, W, b, rowscale, R, Y, S, tag);
-  ProfScope ps(ctx, st, tag);
+  // Split-operand GEMM first where the shape allows; the f32-input GEMM below then runs as its range fallback: its
+  // workgroups return at once unless the first kernel raised the guard (an operand beyond the fp16 range).  Not when
+  // the output aliases an input (the first kernel has already overwritten it).
+  RangeGuard guard{nullptr, 0};
+  if (gemm_h2_fwd_ok(M, Kin, Nout) && Y != X && Y != R && S != X) {
+    guard = range_guard_begin(ctx);
+    if (!guard.word) return NG_ERR_NOMEM;
+    const int rc = gemm_h2_fwd(ctx, st, M, Kin, Nout, act, X, W, b, rowscale, R, Y, S, tag, guard);
+    if (rc) return rc;
+  }
+  ProfScope ps(ctx, st, guard.word ? "gemm_range_fallback" : tag);
   LoadPlain lq{X, M, Kin, Kin};
   LoadPlain lp{W, Kin, Nout, Nout};
   EpiDense ep{Y, S, b, rowscale, R, Nout, act};
   // molecule-sized calls (one 2770-atom frame at the default width: 44 tiles of 128 x 128 on 256 CUs, 75 us): 64 x 64 tiles
   if (M * (int64_t)Nout <= (int64_t)128 * 128 * ctx->num_cu)
-    launch_gemm<64, 64, 2, 2, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep);
+    launch_gemm<64, 64, 2, 2, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep, guard);
   else if (Nout > 64)
-    launch_gemm<128, 128, 2, 2, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep);
+    launch_gemm<128, 128, 2, 2, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep, guard);
   else
-    launch_gemm<128, 64, 4, 1, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep);
+    launch_gemm<128, 64, 4, 1, true, false>(st, M, Nout, Kin, Kin, 1, lq, lp, ep, guard);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -149,15 +158,21 @@ int dense_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
              const char* tag, const float* gscale) {
   NG_REQUIRE(ctx, Nout % 8 == 0 && Kin % 4 == 0, "dense_dx: Nout%8, Kin%4");
   if (M == 0) return NG_OK;
-  if (gemm_h2_fwd_ok(M, Nout, Kin)) return gemm_h2_dx(ctx, st, M, Kin, Nout, act, dY, S, rowscale, W, add, dX, gscale, tag);
-  ProfScope ps(ctx, st, tag);
+  RangeGuard guard{nullptr, 0};
+  if (gemm_h2_fwd_ok(M, Nout, Kin) && dX != dY && dX != add) {      // (see dense_fwd)
+    guard = range_guard_begin(ctx);
+    if (!guard.word) return NG_ERR_NOMEM;
+    const int rc = gemm_h2_dx(ctx, st, M, Kin, Nout, act, dY, S, rowscale, W, add, dX, gscale, tag, guard);
+    if (rc) return rc;
+  }
+  ProfScope ps(ctx, st, guard.word ? "gemm_range_fallback" : tag);
   LoadGradAct lq{dY, act == NG_ACT_NONE ? nullptr : S, rowscale, M, Nout, act};
   LoadPlain lp{W, Kin, Nout, Nout};  // [k_out][n]: K-contiguous along the contraction n
   EpiAdd ep{dX, add, Kin};
   if (Kin > 64)
-    launch_gemm<128, 128, 2, 2, true, true>(st, M, Kin, Nout, Nout, 1, lq, lp, ep);
+    launch_gemm<128, 128, 2, 2, true, true>(st, M, Kin, Nout, Nout, 1, lq, lp, ep, guard);
   else
-    launch_gemm<128, 64, 4, 1, true, true>(st, M, Kin, Nout, Nout, 1, lq, lp, ep);
+    launch_gemm<128, 64, 4, 1, true, true>(st, M, Kin, Nout, Nout, 1, lq, lp, ep, guard);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -213,18 +228,22 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   const DwPlan p = dw_plan(ctx, M, Kin, Nout, db != nullptr);
   float* partial = scratch;
   float* cs_partial = scratch + p.nz * n_elem;
+  RangeGuard guard{nullptr, 0};
   if (gemm_h2_dw_ok(M, Kin, Nout)) {
-    int rc = gemm_h2_dw(ctx, st, M, Kin, Nout, act, X, dY, S, rowscale, partial, (int)p.nz, p.k_chunk, gscale, tag);
+    guard = range_guard_begin(ctx);
+    if (!guard.word) return NG_ERR_NOMEM;
+    int rc = gemm_h2_dw(ctx, st, M, Kin, Nout, act, X, dY, S, rowscale, partial, (int)p.nz, p.k_chunk, gscale, tag, guard);
     if (rc) return rc;
-  } else {
-    ProfScope ps(ctx, st, tag);
+  }
+  {   // the f32-input GEMM: the product itself, or the range fallback of the split-operand one (same partial layout)
+    ProfScope ps(ctx, st, guard.word ? "gemm_range_fallback" : tag);
     LoadPlain lq{X, M, Kin, Kin};
     LoadGradAct lp{dY, S, rowscale, M, Nout, act};
     EpiPartial ep{partial, Kin, Nout};
     if (p.big_n)
-      launch_gemm<128, 128, 2, 2, false, false>(st, Kin, Nout, M, p.k_chunk, (int)p.nz, lq, lp, ep);
+      launch_gemm<128, 128, 2, 2, false, false>(st, Kin, Nout, M, p.k_chunk, (int)p.nz, lq, lp, ep, guard);
     else
-      launch_gemm<128, 64, 4, 1, false, false>(st, Kin, Nout, M, p.k_chunk, (int)p.nz, lq, lp, ep);
+      launch_gemm<128, 64, 4, 1, false, false>(st, Kin, Nout, M, p.k_chunk, (int)p.nz, lq, lp, ep, guard);
     NG_HIP(ctx, hipGetLastError());
   }
   {

@@ -126,7 +126,9 @@ struct GemmTile {
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool Q_KC, bool P_KC, class LoadQ,
           class LoadP, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int N, int64_t K, int64_t k_chunk,
-                                                   LoadQ lq, LoadP lp, Epi epi) {
+                                                   LoadQ lq, LoadP lp, Epi epi, unsigned* guard_word, unsigned guard_epoch) {
+  // range fallback of a split-operand GEMM (ng_internal.h: RangeGuard): run only if that kernel raised the guard
+  if (guard_word && __hip_atomic_load(guard_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != guard_epoch) return;
   using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, Q_KC, P_KC>;
   __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
   float* sQ = smem;

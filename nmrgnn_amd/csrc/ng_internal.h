@@ -49,14 +49,15 @@ size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool h
 // pass over dY); gscale = nullptr makes the call compute it, callers that feed the same dP to dx and dw compute it once.
 bool gemm_h2_fwd_ok(int64_t M, int K, int N);
 int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
-                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag);
+                const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag, RangeGuard guard);
 bool gemm_h2_dw_ok(int64_t M, int Kin, int Nout);
 bool gemm_h2_dw8_ok(int64_t M, int Kin, int Nout);      // 256 x 256 output tiles, one 8-wave workgroup per CU
 int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
                const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const float* gscale,
-               const char* tag);
+               const char* tag, RangeGuard guard);
 int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
-               const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag);
+               const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag,
+               RangeGuard guard);
 // {S, 1/S} for the gradient tensor dY [M][N] (and its row scale); *scale_out stays valid until the next call
 int gemm_grad_scale(ng_ctx* ctx, hipStream_t st, const float* dY, int64_t M, int N, const float* rowscale,
                     const float** scale_out);

@@ -127,3 +127,47 @@ def test_dense_bwd_gradient_scale_is_exact(gpu_device, monkeypatch, shift):
     for a, b in zip(moved, base):
         assert np.isfinite(a).all()
         assert np.array_equal(a, b * 2.0 ** shift)
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 256, 256), (2770, 768, 256), (70000, 256, 768)])
+def test_dense_operands_beyond_the_fp16_range_equal_float64(gpu_device, monkeypatch, M, K, N):
+    """The reference's Dense is plain fp32 (nmrgnn/model.py:191-196): a feature of 3e5 is an ordinary number.  The
+    split-operand GEMMs hold |x| < 65504 per piece; an operand beyond that raises the range guard and the entry point
+    re-runs the product on f32-input MFMA by itself (ng_internal.h: RangeGuard) — forward, dX and dW equal float64 and
+    equal the NG_GEMM_MATH=fp32 bits."""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    rng = np.random.default_rng(M + 3)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    X[rng.integers(0, M, 50), rng.integers(0, K, 50)] = 3.0e5          # a few features far outside the fp16 range
+    W = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    X64, W64 = X.astype(np.float64), W.astype(np.float64)
+    y_ref = X64 @ W64 + b
+    dX_ref = dY.astype(np.float64) @ W64.T
+    dW_ref = X64.T @ dY.astype(np.float64)
+    ctx = _lib.get_context(0)
+    res = {}
+    for math in ("f16x2", "fp32"):
+        monkeypatch.setenv("NG_GEMM_MATH", math)
+        tX, tW, tb, tdY = (torch.from_numpy(a).to(gpu_device) for a in (X, W, b, dY))
+        Y = torch.full((M, N), 7.0, device=gpu_device)
+        dX = torch.full((M, K), 7.0, device=gpu_device)
+        dW = torch.full((K, N), 7.0, device=gpu_device)
+        db = torch.full((N,), 7.0, device=gpu_device)
+        st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+        ctx.check(ctx.lib.ng_dense_fwd(ctx.handle, st, M, K, N, 0, 0, ptr(tX), ptr(tW), ptr(tb), ptr(Y), None), "fwd")
+        ctx.check(ctx.lib.ng_dense_bwd(ctx.handle, st, M, K, N, 0, 0, ptr(tX), ptr(tW), None, ptr(tdY), ptr(dX), ptr(dW),
+                                       ptr(db)), "bwd")
+        torch.cuda.synchronize()
+        res[math] = [t.cpu().numpy().astype(np.float64) for t in (Y, dX, dW)]
+    for math, (y, dx, dw) in res.items():
+        for got, ref, mag in ((y, y_ref, np.abs(X64) @ np.abs(W64)), (dx, dX_ref, np.abs(dY.astype(np.float64)) @ np.abs(W64).T),
+                              (dw, dW_ref, np.abs(X64).T @ np.abs(dY.astype(np.float64)))):
+            assert np.isfinite(got).all(), math
+            assert np.abs(got - ref).max() < 3e-6 * mag.max(), math
+    # Y sees the out-of-range operand X: its fallback is the f32-input kernel, bit for bit (dW too, but its row split
+    # follows the split-operand tiling, so the partial sums differ in the last bits; dX = dY W^T has no such operand)
+    np.testing.assert_array_equal(res["f16x2"][0], res["fp32"][0])
