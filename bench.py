@@ -194,6 +194,46 @@ def cpu_baseline(hp_dict, sample_graphs, seed, budget_s=20.0):
             "ms_per_step": med * 1e3}
 
 
+def cpu_baseline_protein(budget_s=12.0):
+    """configs[4] beside its GPU number: the reference's op order (and the aggregate-then-GEMM order) in torch-CPU fp32,
+    forward only, on ONE frame of 7lgi (2770 atoms, kNN-16 lists) at the baseline architecture (F = 256) — the
+    configuration the north star states its >= 50x for.  Graph build not included (the reference's is MDAnalysis)."""
+    from oracle import nmrgnn_oracle as O
+    from oracle import torch_ref as R
+    from nmrgnn_amd.structure import atoms_onehot, inv_degree_of, knn_graph, read_pdb
+    s = read_pdb(os.path.join(ROOT, "tests", "data", "7lgi.pdb.gz"))
+    atoms = atoms_onehot(s.elements)
+    nlist, edges = knn_graph(s.frames[0], 16)
+    inv = inv_degree_of(nlist)
+    hp = O.hypers()
+    p = R.to_torch_params(O.init_params(hp, atoms.shape[1], dtype=np.float32), dtype=torch.float32)
+    inputs = (atoms, nlist, edges, inv)
+    cores = usable_cores()
+    best = None
+    for thr in sorted({c for c in (cores, 32, 16, 8) if 1 <= c <= cores}, reverse=True):
+        torch.set_num_threads(thr)
+        with torch.no_grad():
+            R.forward(inputs, p, hp, order="ref")
+            t0 = time.perf_counter()
+            R.forward(inputs, p, hp, order="ref")
+            dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (thr, dt)
+    torch.set_num_threads(best[0])
+    out = {"cores": best[0], "cores_available": cores, "kind": "port", "unit": "atoms/s",
+           "sample": f"one 7lgi frame ({atoms.shape[0]} atoms, K=16), forward only, atom_feature_size 256, torch-CPU fp32 eager"}
+    for order, key in (("ref", "value"), ("alg", "aggregate_then_gemm_value")):
+        ts, t_all = [], time.perf_counter()
+        with torch.no_grad():
+            while len(ts) < 3 or (time.perf_counter() - t_all < budget_s / 2 and len(ts) < 30):
+                t0 = time.perf_counter()
+                R.forward(inputs, p, hp, order=order)
+                ts.append(time.perf_counter() - t0)
+        out[key] = atoms.shape[0] / float(np.median(ts))
+        out[key.replace("value", "ms_per_frame")] = float(np.median(ts)) * 1e3
+    return out
+
+
 # kernels whose generic GEMM runs on the fp16 pipe with two-piece split operands when the shape allows (gemm_h2.hip)
 H2_GEMM_TAGS = {"mp_update_fwd", "mp_dw", "mp_dA", "dense_fwd", "dense_dx", "dense_dw", "edge_dense_fwd",
                 "edge_dense_dx", "edge_dense_dw"}
@@ -300,6 +340,17 @@ def event_timed(step_fn, n):
         evs[i + 1].record()
     torch.cuda.synchronize()
     return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+
+
+def collective_library(backend):
+    """what torch.distributed is talking through, for the record of a multi-GPU run ("nccl" IS RCCL on ROCm)"""
+    if backend != "nccl":
+        return backend
+    try:
+        v = torch.cuda.nccl.version()
+        return "rccl " + ".".join(str(x) for x in (v if isinstance(v, tuple) else (v,))) + f" (torch {torch.__version__}, hip {torch.version.hip})"
+    except Exception as ex:
+        return f"nccl (version unavailable: {ex!r})"
 
 
 def free_port():
@@ -438,7 +489,7 @@ def main():
                                   f"layers, noise+dropout on"),
                    "atoms_total": atoms_total, "atoms_this_rank": atoms_local, "edges_this_rank": gb.n_edges,
                    "parallelism": f"graph-parallel dp{world}", "params": eng.params.count(),
-                   "backend": backend},
+                   "backend": backend, "world_size": world, "collective_library": collective_library(backend)},
         "ms_per_step_hipevent_median": float(np.median(ev_ms)),
         "ms_per_step_hipevent_min": float(np.min(ev_ms)),
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
@@ -566,6 +617,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ARCH, sample_graphs=8, seed=42)
         except Exception as ex:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"error": repr(ex)}
+        if isinstance(out.get("configs4"), dict) and "error" not in out["configs4"]:
+            try:
+                out["configs4"]["cpu_baseline"] = cpu_baseline_protein()
+            except Exception as ex:
+                out["configs4"]["cpu_baseline"] = {"error": repr(ex)}
 
     if rank == 0:
         print(json.dumps(out))
