@@ -9,12 +9,12 @@ evaluation of the reference's own graph (NumPy summation order) already sits 1.7
 5.7e-4 (F=256, 108M.pdb) away from its float64 value.  The test therefore asserts
   * 5e-5 on the STANDARDISED prediction ((peaks-avg)/std, the quantity the network computes; half the
     1e-4 budget of the north star at std = 1; measured: <= 2.4e-5), and
-  * on the de-standardised shifts, per element: max error <= max(1e-4, 4 x the error of the
+  * on the de-standardised shifts, per element: max error <= max(1e-4, 1.5 x the error of the
     reference's own float32 evaluation of the same graph) — both are samples of float32 rounding noise
     of the same scale (measured: 0.4x - 3.3x),
 and prints the measured per-element errors (C = 2, N = 3, H = 4).  Measured on MI355X, 108M.pdb, F=256:
 C 1.7e-4, N 6.3e-4, H 1.0e-4 against 1.6e-4 / 5.7e-4 / 1.2e-4 for the reference graph in float32
-(profiles/r02_savedmodel_errors.txt).
+(profiles/r03_savedmodel_errors.txt, regenerated at round 3's kernels).
 """
 import numpy as np
 import pytest
@@ -56,7 +56,9 @@ def _check(tag, c, peaks, ref64, ref32, what):
               f"standardised {err_std:.3e}")
     for e, s, err, err32, err_std in rows:
         assert err_std < STD_ATOL, (tag, what, e, err_std)
-        assert err <= max(1e-4, 4.0 * err32), (tag, what, e, err, err32)
+        # 1e-4 absolute, or 1.5 x what float32 costs the reference's own graph on these inputs (a noisy yardstick on a
+        # small case: also accepted is a tenth of the standardised budget, 5e-6 of the element's peak_std)
+        assert err <= max(1e-4, 1.5 * err32) or err_std < 5e-6, (tag, what, e, err, err32)
         if s == 0:
             assert err == 0.0           # std = avg = 0 elements predict exactly 0 (model.py:272-273)
 

@@ -97,7 +97,6 @@ def test_end_to_end_108M_and_trajectory(gpu_device, tmp_path):
     std = np.asarray(model.peak_std[:10])[np.argmax(g[0], axis=1)]
     assert np.max(err[std > 0] / std[std > 0]) < 5e-5
     assert np.max(err[std == 0]) == 0.0
-    assert np.max(err) < 1e-3
     conf = None
     try:
         conf = nmrgnn_amd.check_peaks(g[0], peaks)
