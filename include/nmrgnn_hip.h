@@ -193,6 +193,22 @@ int ng_mp_layer_bwd_csr(ng_ctx*, void* stream, int64_t N, int64_t nnz, int F, in
                         const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in,
                         float* de, int de_accum, float* dw);
 
+/* ---- molecule-sized inference: FC block + head in one launch ------------------------------------------------------
+ * nmrgnn/model.py:191-196 (FCBlock: L-1 residual softplus Dense F -> F, one softplus Dense F -> F/2) followed by
+ * model.py:268-273 (out Dense F/2 -> C, full * std + avg, one-hot select) for one protein-sized graph (the reference's
+ * eval-struct loop, main.py:236-245): peaks[N] from the MP block's output x[N][F], activations never leave the CU.
+ * Inference only (no dropout, no tape).  Supported: F == 256, L == 4, act softplus, C <= 16, N <= 16384; anything else
+ * returns NG_ERR_UNSUPPORTED and the caller uses ng_fc_block_fwd + ng_head_fwd.  Rows with a feature beyond the fp16
+ * range of the split-operand products are recomputed in plain fp32 inside the kernel. */
+/* One MPLayer forward (nmrgnn/layers.py:26-46; the call of ng_mp_layer_fwd without saved tensors) for a molecule-sized
+ * graph in one launch: the neighbour aggregate of a workgroup's 32 atoms is formed in LDS and multiplied at once.
+ * Supported: F == 256, E <= 3, K <= 32, N <= 16384, h != h_out; otherwise NG_ERR_UNSUPPORTED (use ng_mp_layer_fwd). */
+int ng_mp_layer_fwd_short(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act, int residual, const float* h,
+                          const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out);
+int ng_fc_head_fwd(ng_ctx*, void* stream, int64_t N, int F, int L, int C, int act, const float* x,
+                   const float* const* W, const float* const* b, const float* Wout, const float* bout,
+                   const float* atoms, const float* pstd, const float* pavg, float* peaks);
+
 /* ---- per-batch graph preprocessing: the incoming-edge lists of the deterministic backward scatter --------------
  * The reference hands the model a NEW graph tuple every step (nmrgnn/library.py:88-89, main.py:79); its backward is
  * TensorFlow's unsorted scatter-add behind tf.gather (layers.py:33).  The engine's backward pulls over incoming edges

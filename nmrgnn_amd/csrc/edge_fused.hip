@@ -325,9 +325,12 @@ int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
                        const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard) {
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
-  float* Wpk = (float*)(guard ? aux_workspace(ctx, (pk_floats + FH) * 4) : workspace(ctx, (pk_floats + FH) * 4));
+  // (frozen weights: the fragment copy is kept like every other packed image — one launch less per call)
+  bool have = false;
+  float* Wpk = (float*)cached_image(ctx, W[0], 11, (pk_floats + FH) * 4, &have);
+  if (!Wpk) Wpk = (float*)(guard ? aux_workspace(ctx, (pk_floats + FH) * 4) : workspace(ctx, (pk_floats + FH) * 4));
   if (!Wpk) return NG_ERR_NOMEM;
-  int rc = edge_fused_pack(ctx, st, W, Wpk, nullptr);
+  int rc = have ? NG_OK : edge_fused_pack(ctx, st, W, Wpk, nullptr);
   if (rc) return rc;
   EdgeFwdArgs a;
   a.tape_blocked = tape_blocked ? 1 : 0;

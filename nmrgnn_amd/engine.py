@@ -18,6 +18,9 @@ from .params import ParamStore
 
 ACT = {None: 0, "linear": 0, "softplus": 1, "relu": 2, "tanh": 3}
 DROPOUT_RATE = 0.2   # nmrgnn/model.py:217
+# batches up to this many atoms take the fused FC-block + head launch in inference (above it the per-layer GEMMs have
+# enough rows to fill the chip and the launch chain no longer sets the pace)
+FUSED_TAIL_MAX_ATOMS = 16384
 
 
 def rbf_grid(low, high, count):
@@ -173,6 +176,11 @@ class Engine:
                                                  ptr(batch.row_ptr), ptr(batch.nlist), ptr(e),
                                                  ptr(batch.inv_degree), ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A),
                                                  ptr(S)), "ng_mp_layer_fwd_csr")
+            elif not tape and N <= FUSED_TAIL_MAX_ATOMS and F == 256 and E <= 3 and K <= 32:
+                # molecule-sized inference: aggregate + update of the layer in ONE launch (csrc/frame_fused.hip)
+                A = None
+                self._ck(lib.ng_mp_layer_fwd_short(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]), ptr(batch.nlist_c), ptr(e),
+                                                   ptr(batch.inv_degree), ptr(P[f"mp/{l}/w"]), ptr(hn)), "ng_mp_layer_fwd_short")
             else:
                 A = self._new(N, E, F) if (tape and lib.ng_mp_layer_wants_aggregate(F, E, K)) else None
                 self._ck(lib.ng_mp_layer_fwd(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]),
@@ -182,14 +190,21 @@ class Engine:
             hs.append(hn)
             As.append(A)
             Ss.append(S)
+        Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
+        Bfc = [P[f"fc/{t}/bias"] for t in range(self.Lf)]
+        # molecule-sized inference: FC block + head in ONE launch (csrc/frame_fused.hip)
+        if not tape and N <= FUSED_TAIL_MAX_ATOMS and F == 256 and self.Lf == 4 and self.fc_act == 1 and self.C <= 16:
+            peaks = self._new(N)
+            self._ck(lib.ng_fc_head_fwd(h, st, N, F, self.Lf, self.C, self.fc_act, ptr(hs[-1]), ptr_array(Wfc), ptr_array(Bfc),
+                                        ptr(P["out/kernel"]), ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
+                                        ptr(self.peak_avg), ptr(peaks)), "ng_fc_head_fwd")
+            return peaks
         # FC block: every layer in one call; the tape keeps the layer inputs only (nmrgnn/model.py:191-196)
         fx, fs = [hs[-1]], []
         for t in range(self.Lf - 1):
             fx.append(self._new(N, F))
         Fh = F // 2
         g = self._new(N, Fh)
-        Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
-        Bfc = [P[f"fc/{t}/bias"] for t in range(self.Lf)]
         self._ck(lib.ng_fc_block_fwd(h, st, N, F, self.Lf, self.fc_act, ptr(fx[0]), ptr_array(Wfc),
                                      ptr_array(Bfc), ptr_array(fx[1:]), ptr(g)), "ng_fc_block_fwd")
         mask = None
