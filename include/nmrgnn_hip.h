@@ -205,6 +205,8 @@ int ng_mp_layer_bwd_csr(ng_ctx*, void* stream, int64_t N, int64_t nnz, int F, in
  * Supported: F == 256, E <= 3, K <= 32, N <= 16384, h != h_out; otherwise NG_ERR_UNSUPPORTED (use ng_mp_layer_fwd). */
 int ng_mp_layer_fwd_short(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act, int residual, const float* h,
                           const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out);
+int ng_mp_layer_short_ok(int64_t N, int K, int F, int E);        /* 1: ng_mp_layer_fwd_short takes this shape now */
+int ng_fc_head_ok(int64_t N, int F, int L, int C, int act);      /* 1: ng_fc_head_fwd takes this shape now */
 int ng_fc_head_fwd(ng_ctx*, void* stream, int64_t N, int F, int L, int C, int act, const float* x,
                    const float* const* W, const float* const* b, const float* Wout, const float* bout,
                    const float* atoms, const float* pstd, const float* pavg, float* peaks);

@@ -78,6 +78,8 @@ SIGNATURES = {
     "ng_fc_block_scratch_floats": (_i64, [_i64, _int, _int]),
     "ng_fc_block_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_mp_layer_fwd_short": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_mp_layer_short_ok": (_int, [_i64, _int, _int, _int]),
+    "ng_fc_head_ok": (_int, [_i64, _int, _int, _int, _int]),
     "ng_fc_head_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp,
                               _vp, _vp, _vp]),
     "ng_knn_graph": (_int, [_vp, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _vp]),

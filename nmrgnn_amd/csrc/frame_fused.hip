@@ -483,10 +483,12 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
 }
 
 bool mp_layer_short_supported(int64_t N, int K, int F, int E) {
+  if (sw().mp_layered || sw().gemm_math_fp32) return false;       // the any-shape / strict-fp32 paths were asked for
   return F == FFW && E >= 1 && E <= 3 && K >= 1 && K <= 32 && N > 0 && N <= (int64_t)FF_ROWS * 512;
 }
 
 bool fc_head_short_supported(int64_t N, int F, int L, int C, int act) {
+  if (sw().fc_layered || sw().gemm_math_fp32 || sw().head_generic) return false;
   return F == FFW && L == 4 && C <= FF_MAXC && act == NG_ACT_SOFTPLUS && N > 0 && N <= (int64_t)FF_ROWS * 512;
 }
 
@@ -560,3 +562,8 @@ extern "C" int ng_mp_layer_fwd_short(ng_ctx* ctx, void* stream, int64_t N, int K
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
+
+/* 1 when the fused molecule-sized kernels take this shape under the path switches in force (NG_MP_PATH / NG_FC_PATH =
+ * layered, NG_GEMM_MATH = fp32 and NG_HEAD_PATH = generic select the per-operation kernels) */
+extern "C" int ng_mp_layer_short_ok(int64_t N, int K, int F, int E) { return mp_layer_short_supported(N, K, F, E) ? 1 : 0; }
+extern "C" int ng_fc_head_ok(int64_t N, int F, int L, int C, int act) { return fc_head_short_supported(N, F, L, C, act) ? 1 : 0; }

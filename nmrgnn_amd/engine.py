@@ -176,7 +176,7 @@ class Engine:
                                                  ptr(batch.row_ptr), ptr(batch.nlist), ptr(e),
                                                  ptr(batch.inv_degree), ptr(P[f"mp/{l}/w"]), ptr(hn), ptr(A),
                                                  ptr(S)), "ng_mp_layer_fwd_csr")
-            elif not tape and N <= FUSED_TAIL_MAX_ATOMS and F == 256 and E <= 3 and K <= 32:
+            elif not tape and N <= FUSED_TAIL_MAX_ATOMS and lib.ng_mp_layer_short_ok(N, K, F, E):
                 # molecule-sized inference: aggregate + update of the layer in ONE launch (csrc/frame_fused.hip)
                 A = None
                 self._ck(lib.ng_mp_layer_fwd_short(h, st, N, K, F, E, self.mp_act, 1, ptr(hs[-1]), ptr(batch.nlist_c), ptr(e),
@@ -193,7 +193,7 @@ class Engine:
         Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
         Bfc = [P[f"fc/{t}/bias"] for t in range(self.Lf)]
         # molecule-sized inference: FC block + head in ONE launch (csrc/frame_fused.hip)
-        if not tape and N <= FUSED_TAIL_MAX_ATOMS and F == 256 and self.Lf == 4 and self.fc_act == 1 and self.C <= 16:
+        if not tape and N <= FUSED_TAIL_MAX_ATOMS and lib.ng_fc_head_ok(N, F, self.Lf, self.C, self.fc_act):
             peaks = self._new(N)
             self._ck(lib.ng_fc_head_fwd(h, st, N, F, self.Lf, self.C, self.fc_act, ptr(hs[-1]), ptr_array(Wfc), ptr_array(Bfc),
                                         ptr(P["out/kernel"]), ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
