@@ -7,7 +7,7 @@ from nmrgnn_amd.structure import atoms_onehot, read_pdb
 warnings.simplefilter("ignore")
 s = read_pdb("tests/data/7lgi.pdb.gz")
 atoms = atoms_onehot(s.elements)
-model = nmrgnn_amd.load_model(); model.build(atoms.shape[1])
+model = nmrgnn_amd.load_model(); model.build(atoms.shape[1]); model.freeze()      # eval-struct's use: constant weights
 eng = model.engine; dev = eng.device
 gb = frames_to_batch(atoms, s.frames[:1], 16, device=dev)
 for _ in range(3): model(gb)

@@ -12,6 +12,8 @@ python tools/f256_ab.py > gpurun_out/${TAG}_f256_table.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_f256 -o f256 -- python tools/f256_ab.py > /dev/null 2>&1
 find gpurun_out/prof_${TAG}_f256 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_f256_kernel_stats.csv \;
 bash tools/pmc_f256.sh > gpurun_out/${TAG}_pmc_f256.txt 2>&1
+bash tools/pmc_traffic_f256.sh > gpurun_out/${TAG}_pmc_traffic_f256.log 2>&1
+cp gpurun_out/pmc_traffic_f256.txt gpurun_out/${TAG}_pmc_traffic_f256.txt; cp gpurun_out/pmc_traffic_f256.json gpurun_out/${TAG}_pmc_traffic_f256.json
 cp gpurun_out/pmc_f256.json gpurun_out/${TAG}_pmc_f256.json
 python tools/aggbench.py > gpurun_out/${TAG}_aggbench.txt 2>&1
 cp gpurun_out/aggbench.json gpurun_out/${TAG}_aggbench.json
@@ -19,4 +21,6 @@ python tools/eval_bench.py > gpurun_out/${TAG}_eval_bench.txt 2>&1
 python tools/graph_frame.py > gpurun_out/${TAG}_graph_frame.txt 2>&1
 python tools/edge_ab.py > gpurun_out/${TAG}_edge_ab.txt 2>&1
 python tools/frame_loop.py > gpurun_out/${TAG}_frame_loop.txt 2>&1
+bash tools/frame_trace.sh > gpurun_out/${TAG}_frame_trace.txt 2>&1
+tools/ubench/mfma_fill > gpurun_out/${TAG}_mfma_fill.txt 2>&1 || true
 tail -3 gpurun_out/${TAG}_bench.err; head -c 400 gpurun_out/${TAG}_bench.json; echo; tail -4 gpurun_out/${TAG}_eval_bench.txt
