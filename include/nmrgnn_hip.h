@@ -205,6 +205,9 @@ int ng_mp_layer_bwd_csr(ng_ctx*, void* stream, int64_t N, int64_t nnz, int F, in
  * Supported: F == 256, E <= 3, K <= 32, N <= 16384, h != h_out; otherwise NG_ERR_UNSUPPORTED (use ng_mp_layer_fwd). */
 int ng_mp_layer_fwd_short(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act, int residual, const float* h,
                           const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out);
+int ng_mp_layer_fwd_short_csr(ng_ctx*, void* stream, int64_t N, int F, int E, int act, int residual, const float* h,
+                              const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree,
+                              const float* w, float* h_out);      /* the same over CSR lists, any degree */
 int ng_mp_layer_short_ok(int64_t N, int K, int F, int E);        /* 1: ng_mp_layer_fwd_short takes this shape now */
 int ng_fc_head_ok(int64_t N, int F, int L, int C, int act);      /* 1: ng_fc_head_fwd takes this shape now */
 int ng_fc_head_fwd(ng_ctx*, void* stream, int64_t N, int F, int L, int C, int act, const float* x,
@@ -233,6 +236,11 @@ size_t ng_incoming_lists_scratch_bytes(int64_t N, int64_t n_entries);
 int ng_cutoff_count(ng_ctx*, void* stream, int G, int n, float cutoff, const float* pos, int32_t* deg);
 int ng_cutoff_fill(ng_ctx*, void* stream, int G, int n, float cutoff, float scale, const float* pos,
                    const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree);
+/* ng_cutoff_fill that also writes row_of[nnz], the row of every entry (NULL: not written) */
+int ng_cutoff_fill_rows(ng_ctx*, void* stream, int G, int n, float cutoff, float scale, const float* pos,
+                        const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree, int32_t* row_of);
+/* out[0..n] = exclusive prefix sums of in[0..n-1], out[n] = total (row_ptr from ng_cutoff_count's degrees) */
+int ng_exclusive_scan_i32(ng_ctx*, void* stream, int64_t n, const int32_t* in, int32_t* out);
 
 /* ---- graph front end: K nearest neighbours per atom, per frame --------------------------------
  * Replaces the neighbour search behind nmrgnn.universe2graph (nmrgnn/library.py:106-117, external

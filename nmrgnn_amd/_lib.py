@@ -68,6 +68,8 @@ SIGNATURES = {
     "ng_incoming_lists_scratch_bytes": (C.c_size_t, [_i64, _i64]),
     "ng_cutoff_count": (_int, [_vp, _vp, _int, _int, _f, _vp, _vp]),
     "ng_cutoff_fill": (_int, [_vp, _vp, _int, _int, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ng_cutoff_fill_rows": (_int, [_vp, _vp, _int, _int, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_exclusive_scan_i32": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "ng_dense_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ng_dense_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "ng_fc_block_scratch_floats": (_i64, [_i64, _int, _int]),
     "ng_fc_block_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_mp_layer_fwd_short": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_mp_layer_fwd_short_csr": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_mp_layer_short_ok": (_int, [_i64, _int, _int, _int]),
     "ng_fc_head_ok": (_int, [_i64, _int, _int, _int, _int]),
     "ng_fc_head_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp,

@@ -304,6 +304,7 @@ struct MpShortArgs {
   int64_t N;
   int K, act, residual;
   const float* h;            // [N][256]
+  const int32_t* row_ptr;    // CSR form: [N+1] (then nlist = col [nnz], e [nnz][E], K unused); nullptr: padded lists
   const int32_t* nlist;      // [N][K]
   const float* e;            // [N][K][E]
   const float* inv_degree;   // [N]
@@ -328,7 +329,7 @@ __global__ void ff_pack_mp_kernel(int E, const float* __restrict__ w, unsigned* 
   for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
 }
 
-template <int E>
+template <int E, bool CSR>
 __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
   constexpr int KF = E * FFW, XROW = KF * 2 + 16, XPLANE = FF_ROWS * XROW;
   extern __shared__ __attribute__((aligned(16))) char smem_mp[];
@@ -344,9 +345,11 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
   const int n_at = (int)std::min<int64_t>(FF_ROWS, a.N - m0);
   const int64_t m = std::min<int64_t>(m0 + l31, a.N - 1);
 
-  // lists of the tile (rows past the end: neighbour 0 with weight 0)
-  for (int t = tid; t < FF_ROWS * K; t += 256) s_nl[t] = t < n_at * K ? a.nlist[m0 * K + t] : 0;
-  for (int t = tid; t < FF_ROWS * K * E; t += 256) s_e[t] = t < n_at * K * E ? a.e[m0 * K * E + t] : 0.f;
+  // lists of the tile (rows past the end: neighbour 0 with weight 0); the CSR form reads its entries from global memory
+  if (!CSR) {
+    for (int t = tid; t < FF_ROWS * K; t += 256) s_nl[t] = t < n_at * K ? a.nlist[m0 * K + t] : 0;
+    for (int t = tid; t < FF_ROWS * K * E; t += 256) s_e[t] = t < n_at * K * E ? a.e[m0 * K * E + t] : 0.f;
+  }
   // this lane's slice of its own row in the accumulator layout: the residual term (requested early)
   float xr[2][16];
 #pragma unroll
@@ -368,29 +371,37 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) acc[n][c] = 0.f;
     const float4* h4 = reinterpret_cast<const float4*>(a.h);
+    // entry range of this row: [p0, p1) of the flat lists (padded form: r*K .. r*K + K of the staged tile)
+    int p0 = r * K, p1 = r * K + K;
+    if (CSR) {
+      p0 = r < n_at ? a.row_ptr[m0 + r] : 0;
+      p1 = r < n_at ? a.row_ptr[m0 + r + 1] : 0;
+    }
+    const int32_t* nl = CSR ? a.nlist : s_nl;
+    const float* ee = CSR ? a.e : s_e;
     // FF_NB neighbour rows (8 x 16 B each) requested before the first is consumed: the phase is a chain of L2 round trips
     // with one wave per SIMD, and the kernel has the registers (512 per lane) to keep 56-64 loads in flight
 #ifdef FF_SKIP_AGG
-    for (int j0 = 0; j0 < 0; j0 += FF_NB) {
+    for (int j0 = p0; j0 < p0; j0 += FF_NB) {
 #else
-    for (int j0 = 0; j0 < K; j0 += FF_NB) {
+    for (int j0 = p0; j0 < p1; j0 += FF_NB) {
 #endif
       float4 hv[FF_NB][8];
 #pragma unroll
       for (int u = 0; u < FF_NB; ++u) {
-        const int j = j0 + u < K ? j0 + u : K - 1;
+        const int j = j0 + u < p1 ? j0 + u : p1 - 1;
         // lane cc takes the float4 columns cc, cc + 8, ..: the eight lanes of a row read 128 contiguous bytes per load
         // instruction (contiguous 32-column slices per lane made every instruction touch 64 different cache lines)
-        const int64_t base = (int64_t)s_nl[r * K + j] * (FFW / 4) + cc;
+        const int64_t base = (int64_t)nl[j] * (FFW / 4) + cc;
 #pragma unroll
         for (int v = 0; v < 8; ++v) hv[u][v] = h4[base + 8 * v];
       }
 #pragma unroll
       for (int u = 0; u < FF_NB; ++u) {
-        if (j0 + u < K) {
+        if (j0 + u < p1) {
 #pragma unroll
           for (int n = 0; n < E; ++n) {
-            const float ev = s_e[(r * K + j0 + u) * E + n];
+            const float ev = ee[(int64_t)(j0 + u) * E + n];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
               acc[n][4 * v + 0] = fmaf(ev, hv[u][v].x, acc[n][4 * v + 0]);
@@ -441,11 +452,14 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
     if (mask != 0u) {
       float* sA = sRow;             // [KF] the row's aggregate
       float* sY = sRow + KF;        // [256] its pre-activations
+      const int32_t* nl = CSR ? a.nlist : s_nl;
+      const float* ee = CSR ? a.e : s_e;
       for (int r = 0; r < FF_ROWS; ++r) {
         if (!((mask >> r) & 1u)) continue;
+        const int q0 = CSR ? a.row_ptr[m0 + r] : r * K, q1 = CSR ? a.row_ptr[m0 + r + 1] : r * K + K;   // (bad rows are < n_at)
         for (int n = 0; n < E; ++n) {
           float s = 0.f;
-          for (int j = 0; j < K; ++j) s = fmaf(s_e[(r * K + j) * E + n], a.h[(int64_t)s_nl[r * K + j] * FFW + tid], s);
+          for (int j = q0; j < q1; ++j) s = fmaf(ee[(int64_t)j * E + n], a.h[(int64_t)nl[j] * FFW + tid], s);
           sA[n * FFW + tid] = s;
         }
         __syncthreads();
@@ -530,9 +544,9 @@ extern "C" int ng_fc_head_fwd(ng_ctx* ctx, void* stream, int64_t N, int F, int L
   return NG_OK;
 }
 
-extern "C" int ng_mp_layer_fwd_short(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act, int residual,
-                                     const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
-                                     const float* w, float* h_out) {
+static int mp_layer_short_launch(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act, int residual,
+                                 const float* h, const int32_t* row_ptr, const int32_t* nlist, const float* e,
+                                 const float* inv_degree, const float* w, float* h_out) {
   if (!ctx) return NG_ERR_INVALID;
   if (!mp_layer_short_supported(N, K, F, E)) return NG_ERR_UNSUPPORTED;
   NG_REQUIRE(ctx, h != h_out, "mp_layer_fwd_short: in-place update not supported (other atoms still gather the input)");
@@ -549,18 +563,35 @@ extern "C" int ng_mp_layer_fwd_short(ng_ctx* ctx, void* stream, int64_t N, int K
     NG_HIP(ctx, hipGetLastError());
   }
   MpShortArgs a;
-  a.N = N; a.K = K; a.act = act; a.residual = residual; a.h = h; a.nlist = nlist; a.e = e; a.inv_degree = inv_degree;
+  a.N = N; a.K = K; a.act = act; a.residual = residual; a.h = h; a.row_ptr = row_ptr; a.nlist = nlist; a.e = e; a.inv_degree = inv_degree;
   a.img = img; a.w = w; a.h_out = h_out;
-  const size_t lds = (size_t)2 * FF_ROWS * (KF * 2 + 16) + (size_t)(KF + FFW + 4) * 4 + (size_t)FF_ROWS * K * (1 + E) * 4;
+  const size_t lds = (size_t)2 * FF_ROWS * (KF * 2 + 16) + (size_t)(KF + FFW + 4) * 4 + (row_ptr ? 0 : (size_t)FF_ROWS * K * (1 + E) * 4);
   ProfScope ps(ctx, st, "mp_layer_short");
   const dim3 grid((unsigned)cdiv(N, FF_ROWS));
   switch (E) {
-    case 1: hipLaunchKernelGGL((mp_layer_short_kernel<1>), grid, dim3(256), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((mp_layer_short_kernel<2>), grid, dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL((mp_layer_short_kernel<3>), grid, dim3(256), lds, st, a); break;
+    case 1: if (row_ptr) hipLaunchKernelGGL((mp_layer_short_kernel<1, true>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((mp_layer_short_kernel<1, false>), grid, dim3(256), lds, st, a); break;
+    case 2: if (row_ptr) hipLaunchKernelGGL((mp_layer_short_kernel<2, true>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((mp_layer_short_kernel<2, false>), grid, dim3(256), lds, st, a); break;
+    default: if (row_ptr) hipLaunchKernelGGL((mp_layer_short_kernel<3, true>), grid, dim3(256), lds, st, a);
+             else hipLaunchKernelGGL((mp_layer_short_kernel<3, false>), grid, dim3(256), lds, st, a); break;
   }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
+}
+
+extern "C" int ng_mp_layer_fwd_short(ng_ctx* ctx, void* stream, int64_t N, int K, int F, int E, int act, int residual,
+                                     const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
+                                     const float* w, float* h_out) {
+  return mp_layer_short_launch(ctx, stream, N, K, F, E, act, residual, h, nullptr, nlist, e, inv_degree, w, h_out);
+}
+
+// the same over CSR lists (row_ptr [N+1], col [nnz], e [nnz][E]): any degree
+extern "C" int ng_mp_layer_fwd_short_csr(ng_ctx* ctx, void* stream, int64_t N, int F, int E, int act, int residual,
+                                         const float* h, const int32_t* row_ptr, const int32_t* col, const float* e,
+                                         const float* inv_degree, const float* w, float* h_out) {
+  if (ctx && !row_ptr) return fail(ctx, NG_ERR_INVALID, "mp_layer_fwd_short_csr: row_ptr required");
+  return mp_layer_short_launch(ctx, stream, N, 1, F, E, act, residual, h, row_ptr, col, e, inv_degree, w, h_out);
 }
 
 /* 1 when the fused molecule-sized kernels take this shape under the path switches in force (NG_MP_PATH / NG_FC_PATH =

@@ -120,9 +120,66 @@ __global__ __launch_bounds__(GL_BLOCK) void gl_sort_kernel(int64_t n, const int3
   }
 }
 
+// offsets of a scan over n + 1 elements applied in place; element n (a zero before the scan) ends up as the total
+__global__ __launch_bounds__(GL_BLOCK) void gl_scan_offsets_kernel(int64_t n1, int32_t* __restrict__ data, const int32_t* __restrict__ block_sum) {
+  const int64_t i = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
+  if (i < n1) data[i] += block_sum[i / GL_SCAN_TILE];
+}
+
+// short vectors: one workgroup, one launch (a molecule-sized frame: the multi-launch scan above costs 18 us of
+// boundaries for 3k integers)
+__global__ __launch_bounds__(1024) void gl_scan_small_kernel(int n, const int32_t* __restrict__ in, int32_t* __restrict__ out) {
+  __shared__ int32_t s[1024];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < n; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int32_t v = i < n ? in[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n) out[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
 }  // namespace ng
 
 using namespace ng;
+
+// out[0..n] = exclusive prefix sums of in[0..n-1] (out[n] = total): row_ptr from a degree vector, on the device
+extern "C" int ng_exclusive_scan_i32(ng_ctx* ctx, void* stream, int64_t n, const int32_t* in, int32_t* out) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) - 1 && out && (in || n == 0), "exclusive scan: arguments");
+  hipStream_t st = (hipStream_t)stream;
+  DeviceGuard dg(ctx->device);
+  const int64_t n1 = n + 1;
+  const int nb = (int)cdiv(n1, GL_SCAN_TILE);
+  int32_t* bsum = (int32_t*)aux_workspace(ctx, (size_t)(nb + 16) * sizeof(int32_t));
+  if (!bsum) return NG_ERR_HIP;
+  ProfScope ps(ctx, st, "exclusive_scan");
+  if (n <= 32768 && in != out) {
+    hipLaunchKernelGGL(gl_scan_small_kernel, dim3(1), dim3(1024), 0, st, (int)n, in, out);
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
+  if (n > 0) NG_HIP(ctx, hipMemcpyAsync(out, in, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  NG_HIP(ctx, hipMemsetAsync(out + n, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(gl_scan_local_kernel, dim3(nb), dim3(GL_BLOCK), 0, st, n1, out, bsum);
+  hipLaunchKernelGGL(gl_scan_sums_kernel, dim3(1), dim3(GL_BLOCK), 0, st, nb, bsum);
+  hipLaunchKernelGGL(gl_scan_offsets_kernel, dim3((unsigned)cdiv(n1, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n1, out, bsum);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
 
 extern "C" size_t ng_incoming_lists_scratch_bytes(int64_t N, int64_t n_entries) {
   const int64_t nb = cdiv(std::max<int64_t>(N, 1), GL_SCAN_TILE);

@@ -499,7 +499,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float scale, const float* __restrict__ pos,
                                                      int32_t* __restrict__ deg, const int32_t* __restrict__ row_ptr,
                                                      int32_t* __restrict__ col, float* __restrict__ dist,
-                                                     float* __restrict__ inv_degree) {
+                                                     float* __restrict__ inv_degree, int32_t* __restrict__ row_of) {
   __shared__ float sx[CUT_TILE], sy[CUT_TILE], sz[CUT_TILE];
   const int frame = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -526,6 +526,7 @@ __global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float
           if (FILL) {
             col[out + cnt] = frame * n + j;
             dist[out + cnt] = sqrtf(d2) * scale;
+            if (row_of) row_of[out + cnt] = (int32_t)row;
           }
           ++cnt;
           cnt_pos += j > 0 ? 1 : 0;
@@ -534,6 +535,79 @@ __global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float
     }
   }
   if (i >= n) return;
+  if (FILL) inv_degree[row] = cnt_pos > 0 ? 1.0f / (float)cnt_pos : 0.f;
+  else deg[row] = cnt;
+}
+
+// The same with 16 lanes per query atom (round 3): lane s of an atom's group tests candidates s, s + 16, ..; a wave
+// ballot per 16-candidate chunk gives the hits in ascending candidate order, so rows come out exactly as the
+// one-thread-per-atom kernel writes them.  One thread per atom left a 2770-atom frame with 11 workgroups walking 2770
+// candidates each, its hits stored one by one: 80 us (count) + 295 us (fill) per frame; this form: 256 threads = 16 atoms.
+template <bool FILL>
+__global__ __launch_bounds__(256) void cutoff_s16_kernel(int n, float cutoff2, float scale, const float* __restrict__ pos,
+                                                         int32_t* __restrict__ deg, const int32_t* __restrict__ row_ptr,
+                                                         int32_t* __restrict__ col, float* __restrict__ dist,
+                                                         float* __restrict__ inv_degree, int32_t* __restrict__ row_of) {
+  __shared__ float sx[CUT_TILE], sy[CUT_TILE], sz[CUT_TILE];
+  const int frame = blockIdx.y;
+  const int s = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const float* fp = pos + (int64_t)frame * n * 3;
+  const int ic = i < n ? i : n - 1;
+  const float qx = fp[3 * ic], qy = fp[3 * ic + 1], qz = fp[3 * ic + 2];
+  const int64_t row = (int64_t)frame * n + i;
+  int cnt = 0, cnt_pos = 0;
+  int64_t out = 0;
+  if (FILL && i < n) out = row_ptr[row];
+  for (int t0 = 0; t0 < n; t0 += CUT_TILE) {
+    const int m = min(CUT_TILE, n - t0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < m; t += 256) {
+      sx[t] = fp[3 * (t0 + t)]; sy[t] = fp[3 * (t0 + t) + 1]; sz[t] = fp[3 * (t0 + t) + 2];
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < m; c0 += 64) {          // wave-uniform trip count: every lane takes part in the ballots
+      // four 16-candidate chunks per trip: their LDS reads are in flight together (a ballot per chunk in a plain loop
+      // serialises on the LDS latency of each)
+      bool hit[4];
+      float d2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = c0 + 16 * u + s;
+        hit[u] = false;
+        d2[u] = 0.f;
+        if (t < m && i < n) {
+          const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
+          d2[u] = dx * dx + dy * dy + dz * dz;
+          hit[u] = d2[u] < cutoff2 && t0 + t != i;
+        }
+      }
+      if (!FILL) {        // counting needs no order: per-lane tallies, summed over the 16 lanes at the end
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += hit[u] ? 1 : 0;
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = t0 + c0 + 16 * u + s;
+        const unsigned long long b = __ballot(hit[u]);
+        const unsigned mine = (unsigned)(b >> (16 * grp)) & 0xFFFFu;
+        if (FILL && hit[u]) {
+          const int p = cnt + __popc(mine & ((1u << s) - 1u));
+          col[out + p] = frame * n + j;
+          dist[out + p] = sqrtf(d2[u]) * scale;
+          if (row_of) row_of[out + p] = (int32_t)row;
+        }
+        cnt += __popc(mine);
+        // local neighbour index > 0 (library.py:115-116): candidate 0 of the frame does not count
+        cnt_pos += __popc(t0 + c0 + 16 * u == 0 ? (mine & ~1u) : mine);
+      }
+    }
+  }
+  if (!FILL) {
+    cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 4, 64); cnt += __shfl_xor(cnt, 8, 64);
+  }
+  if (i >= n || s != 0) return;
   if (FILL) inv_degree[row] = cnt_pos > 0 ? 1.0f / (float)cnt_pos : 0.f;
   else deg[row] = cnt;
 }
@@ -582,21 +656,37 @@ extern "C" int ng_cutoff_count(ng_ctx* ctx, void* stream, int G, int n, float cu
   NG_REQUIRE(ctx, (int64_t)G * n < (int64_t)1 << 31 && G <= 65535, "cutoff graph: batch too large");
   if (G == 0 || n == 0) return NG_OK;
   ProfScope ps(ctx, (hipStream_t)stream, "cutoff_count");
-  hipLaunchKernelGGL((cutoff_kernel<false>), dim3((unsigned)cdiv(n, 256), (unsigned)G), dim3(256), 0,
-                     (hipStream_t)stream, n, cutoff * cutoff, 1.0f, pos, deg, nullptr, nullptr, nullptr, nullptr);
+  if (sw().knn_serial)
+    hipLaunchKernelGGL((cutoff_kernel<false>), dim3((unsigned)cdiv(n, 256), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, n, cutoff * cutoff, 1.0f, pos, deg, nullptr, nullptr, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((cutoff_s16_kernel<false>), dim3((unsigned)cdiv(n, 16), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, n, cutoff * cutoff, 1.0f, pos, deg, nullptr, nullptr, nullptr, nullptr, nullptr);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
 
+extern "C" int ng_cutoff_fill_rows(ng_ctx* ctx, void* stream, int G, int n, float cutoff, float scale, const float* pos,
+                                   const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree, int32_t* row_of);
 extern "C" int ng_cutoff_fill(ng_ctx* ctx, void* stream, int G, int n, float cutoff, float scale, const float* pos,
                               const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree) {
+  return ng_cutoff_fill_rows(ctx, stream, G, n, cutoff, scale, pos, row_ptr, col, dist, inv_degree, nullptr);
+}
+
+// the same, also writing row_of[nnz] (the row of every entry: what the CSR backward walks) when it is not NULL
+extern "C" int ng_cutoff_fill_rows(ng_ctx* ctx, void* stream, int G, int n, float cutoff, float scale, const float* pos,
+                                   const int32_t* row_ptr, int32_t* col, float* dist, float* inv_degree, int32_t* row_of) {
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, G >= 0 && n >= 0 && cutoff > 0.f, "cutoff graph: sizes >= 0, cutoff > 0");
   NG_REQUIRE(ctx, (int64_t)G * n < (int64_t)1 << 31 && G <= 65535, "cutoff graph: batch too large");
   if (G == 0 || n == 0) return NG_OK;
   ProfScope ps(ctx, (hipStream_t)stream, "cutoff_fill");
-  hipLaunchKernelGGL((cutoff_kernel<true>), dim3((unsigned)cdiv(n, 256), (unsigned)G), dim3(256), 0,
-                     (hipStream_t)stream, n, cutoff * cutoff, scale, pos, nullptr, row_ptr, col, dist, inv_degree);
+  if (sw().knn_serial)
+    hipLaunchKernelGGL((cutoff_kernel<true>), dim3((unsigned)cdiv(n, 256), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, n, cutoff * cutoff, scale, pos, nullptr, row_ptr, col, dist, inv_degree, row_of);
+  else
+    hipLaunchKernelGGL((cutoff_s16_kernel<true>), dim3((unsigned)cdiv(n, 16), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, n, cutoff * cutoff, scale, pos, nullptr, row_ptr, col, dist, inv_degree, row_of);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

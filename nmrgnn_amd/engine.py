@@ -170,7 +170,12 @@ class Engine:
         for l in range(self.L):
             hn = self._new(N, F)
             S = self._new(N, F) if (tape and self.mp_act != 0) else None
-            if batch.is_csr:        # variable-degree lists: row_ptr / col instead of [N,K]
+            if batch.is_csr and not tape and N <= FUSED_TAIL_MAX_ATOMS and lib.ng_mp_layer_short_ok(N, 1, F, E):
+                A = None        # molecule-sized inference over CSR lists: one launch per layer
+                self._ck(lib.ng_mp_layer_fwd_short_csr(h, st, N, F, E, self.mp_act, 1, ptr(hs[-1]), ptr(batch.row_ptr),
+                                                       ptr(batch.nlist), ptr(e), ptr(batch.inv_degree), ptr(P[f"mp/{l}/w"]),
+                                                       ptr(hn)), "ng_mp_layer_fwd_short_csr")
+            elif batch.is_csr:        # variable-degree lists: row_ptr / col instead of [N,K]
                 A = self._new(N, E, F) if tape else None
                 self._ck(lib.ng_mp_layer_fwd_csr(h, st, N, ne, F, E, self.mp_act, 1, ptr(hs[-1]),
                                                  ptr(batch.row_ptr), ptr(batch.nlist), ptr(e),

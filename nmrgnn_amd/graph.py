@@ -73,7 +73,7 @@ class GraphBatch:
 
     # ------------------------------------------------------------------ CSR form
     @classmethod
-    def from_csr(cls, atoms, row_ptr, col, dist, inv_degree=None, graph_ptr=None, device=None, validate=True):
+    def from_csr(cls, atoms, row_ptr, col, dist, inv_degree=None, graph_ptr=None, device=None, validate=True, row_of=None):
         """Variable-degree graph(s): row i owns the entries [row_ptr[i], row_ptr[i+1]) of ``col`` (neighbour
         atom, batch-global) and ``dist`` (distance > 0).  ``inv_degree`` defaults to the reference's rule
         1 / #(graph-local neighbour index > 0), 0 when that count is 0 (nmrgnn/library.py:115-116)."""
@@ -108,9 +108,12 @@ class GraphBatch:
                     raise ValueError(f"col entries must lie in [0,{self.N}); got [{lo},{hi}]")
                 if bool((self.edges <= 0).any()):
                     raise ValueError("CSR distances must be > 0 (zero-distance slots are the padded form's mask)")
-        deg = (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
-        self.row_of = torch.repeat_interleave(torch.arange(self.N, device=self.device, dtype=torch.int32),
-                                              deg).contiguous()
+        if row_of is not None:             # the builder already knows the row of every entry
+            self.row_of = _to_dev(row_of, torch.int32, self.device).reshape(-1)
+        else:
+            deg = (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+            self.row_of = torch.repeat_interleave(torch.arange(self.N, device=self.device, dtype=torch.int32),
+                                                  deg).contiguous()
         if inv_degree is None:
             gp = torch.as_tensor(self.graph_ptr_host.astype(np.int64), device=self.device)
             rows = self.row_of.to(torch.int64)
@@ -267,18 +270,19 @@ def frames_to_batch_cutoff(atoms, frames, cutoff=4.0, scale=0.1, device=None):
     ctx = _lib.get_context(device.index)
     with torch.cuda.device(device):
         st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        deg = torch.zeros(G * n, dtype=torch.int32, device=device)
+        deg = torch.empty(G * n, dtype=torch.int32, device=device)
         ctx.check(ctx.lib.ng_cutoff_count(ctx.handle, st, G, n, float(cutoff), ptr(pos), ptr(deg)), "ng_cutoff_count")
-        row_ptr = torch.zeros(G * n + 1, dtype=torch.int64, device=device)
-        row_ptr[1:] = torch.cumsum(deg.to(torch.int64), 0)
+        row_ptr = torch.empty(G * n + 1, dtype=torch.int32, device=device)
+        ctx.check(ctx.lib.ng_exclusive_scan_i32(ctx.handle, st, G * n, ptr(deg), ptr(row_ptr)), "ng_exclusive_scan_i32")
         nnz = int(row_ptr[-1])                      # the one host synchronisation: the list length sizes the buffers
-        if nnz >= 2 ** 31:
+        if nnz < 0:
             raise ValueError("cutoff graph: more than 2^31 edges in one batch")
-        row_ptr = row_ptr.to(torch.int32)
         col = torch.empty(nnz, dtype=torch.int32, device=device)
         dist = torch.empty(nnz, dtype=torch.float32, device=device)
+        row_of = torch.empty(nnz, dtype=torch.int32, device=device)
         inv = torch.empty(G * n, dtype=torch.float32, device=device)
-        ctx.check(ctx.lib.ng_cutoff_fill(ctx.handle, st, G, n, float(cutoff), float(scale), ptr(pos), ptr(row_ptr),
-                                         ptr(col), ptr(dist), ptr(inv)), "ng_cutoff_fill")
+        ctx.check(ctx.lib.ng_cutoff_fill_rows(ctx.handle, st, G, n, float(cutoff), float(scale), ptr(pos), ptr(row_ptr),
+                                              ptr(col), ptr(dist), ptr(inv), ptr(row_of)), "ng_cutoff_fill_rows")
     ptrs = np.arange(G + 1, dtype=np.int64) * n
-    return GraphBatch.from_csr(at.repeat(G, 1), row_ptr, col, dist, inv, graph_ptr=ptrs, device=device, validate=False)
+    return GraphBatch.from_csr(at.repeat(G, 1) if G > 1 else at, row_ptr, col, dist, inv, graph_ptr=ptrs, device=device,
+                               validate=False, row_of=row_of)

@@ -142,3 +142,43 @@ def test_fused_mp_layer_equals_float64_and_the_layered_path(gpu_device, N, K, E,
     assert np.max(np.abs(lay - ref) / mag) < 5e-6
     # in-place use is refused (other atoms still gather the input rows)
     assert ctx.lib.ng_mp_layer_fwd_short(ctx.handle, st, N, K, F, E, act, 1, ptr(th), ptr(tn), ptr(te), ptr(ti), ptr(tw), ptr(th)) != 0
+
+
+@pytest.mark.parametrize("N,E", [(2770, 3), (77, 2)])
+def test_fused_mp_layer_over_csr_lists(gpu_device, N, E):
+    """variable degree (0 ... 40 entries per row, one row with 300): the CSR form of the one-launch MPLayer"""
+    import torch
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    rng = np.random.default_rng(N)
+    deg = rng.integers(0, 41, N)
+    deg[3] = 0
+    deg[N // 2] = 300
+    row_ptr = np.zeros(N + 1, np.int32)
+    row_ptr[1:] = np.cumsum(deg)
+    nnz = int(row_ptr[-1])
+    col = rng.integers(0, N, nnz).astype(np.int32)
+    e = (rng.standard_normal((nnz, E)) * 0.3).astype(np.float32)
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    inv = (1.0 / np.maximum(deg, 1)).astype(np.float32)
+    w = (rng.standard_normal((F, F, E)) * 0.02).astype(np.float32)
+    rows = np.repeat(np.arange(N), deg)
+    A = np.zeros((N, E, F))
+    np.add.at(A, rows, e.astype(np.float64)[:, :, None] * h.astype(np.float64)[col][:, None, :])
+    pre = inv[:, None].astype(np.float64) * np.einsum("inl,lmn->im", A, w.astype(np.float64))
+    ref = softplus(pre) + h
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+    th, tr, tc, te, ti, tw = t(h), t(row_ptr), t(col), t(e), t(inv), t(w)
+    ctx = _lib.get_context(0)
+    st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    out = torch.full((N, F), 7.0, device=gpu_device)
+    ctx.check(ctx.lib.ng_mp_layer_fwd_short_csr(ctx.handle, st, N, F, E, 1, 1, ptr(th), ptr(tr), ptr(tc), ptr(te), ptr(ti), ptr(tw),
+                                                ptr(out)), "ng_mp_layer_fwd_short_csr")
+    lay = torch.full((N, F), 7.0, device=gpu_device)
+    ctx.check(ctx.lib.ng_mp_layer_fwd_csr(ctx.handle, st, N, nnz, F, E, 1, 1, ptr(th), ptr(tr), ptr(tc), ptr(te), ptr(ti), ptr(tw),
+                                          ptr(lay), None, None), "ng_mp_layer_fwd_csr")
+    torch.cuda.synchronize()
+    mag = np.maximum(inv[:, None] * np.einsum("inl,lmn->im", np.abs(A), np.abs(w.astype(np.float64))) + np.abs(h), 1.0)
+    for got in (out.cpu().numpy().astype(np.float64), lay.cpu().numpy().astype(np.float64)):
+        assert np.isfinite(got).all()
+        assert np.max(np.abs(got - ref) / mag) < 5e-6
