@@ -52,10 +52,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // mode 1 (back to nodes): Wsrc(k = n*64 + m, o = l) = w[l][m][n]
 // mode 2 (dA = dP Wp^T):  Wsrc(k = m, o = n*64 + l) = w[l][m][n]
 // blockIdx.y selects the job: the backward packs its two images (modes 2 and 1) in one launch
-__global__ void mpw_pack_kernel(int E, int mode0, const float* __restrict__ w, float* __restrict__ out0, int mode1,
-                                float* __restrict__ out1) {
-  const int mode = blockIdx.y == 0 ? mode0 : mode1;
-  float* out = blockIdx.y == 0 ? out0 : out1;
+__device__ __forceinline__ void mpw_pack_f32_body(int E, int mode, const float* __restrict__ w, float* __restrict__ out) {
   const int KF = E * WF;
   const int kdim = mode == 2 ? WF : KF;
   const int odim = mode == 2 ? KF : WF;
@@ -80,24 +77,44 @@ __global__ void mpw_pack_kernel(int E, int mode0, const float* __restrict__ w, f
   }
 }
 
+__global__ void mpw_pack_kernel(int E, int mode0, const float* __restrict__ w, float* __restrict__ out0, int mode1,
+                                float* __restrict__ out1) {
+  mpw_pack_f32_body(E, blockIdx.y == 0 ? mode0 : mode1, w, blockIdx.y == 0 ? out0 : out1);
+}
+
+// a weight whose fp16 pieces (of 2^8 w) leave the fp16 range: the piece kernels hand the call to the fp32-input ones
+// (RangeGuard, ng_internal.h)
+__device__ __forceinline__ bool mpw_out_of_range(float w256) { return !(fabsf(w256) < 65504.0f); }
+
 // ---- weight fragments for v_mfma_f32_16x16x32_f16 with two-piece operands (forward, h2_common.cuh) ----
 // out[(((ct*NT2 + T)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of 2^8 Wsrc(k = 32T + 8(lane>>4) + t,
 // o = 16ct + (lane&15)),  Wsrc(k = n*64 + l, o = m) = w[l][m][n]  (mode 0 above)
-__global__ void mpw_pack_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ out) {
+// blockIdx.y == 1 (when launched so): the fp32 fragment image (mode 0 above) for the fallback launch.  A weight out of
+// the piece range raises the guard and, for an image kept over calls (ng_weights_frozen), the image's own flag word.
+__global__ void mpw_pack_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ out, float* __restrict__ out_f32,
+                                   RangeGuard guard, unsigned* __restrict__ wflag) {
+  if (blockIdx.y == 1) { mpw_pack_f32_body(E, 0, w, out_f32); return; }
   const int KF = E * WF, NT2 = KF / 32;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (ct, T, lane)
-  if (idx >= 4 * NT2 * 64) return;
-  const int lane = idx & 63, T = (idx >> 6) % NT2, ct = (idx >> 6) / NT2;
-  const int o = 16 * ct + (lane & 15);
-  unsigned h[4], l[4];
+  bool bad = false;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 4 * NT2 * 64; idx += gridDim.x * blockDim.x) {   // (ct, T, lane)
+    const int lane = idx & 63, T = (idx >> 6) % NT2, ct = (idx >> 6) / NT2;
+    const int o = 16 * ct + (lane & 15);
+    unsigned h[4], l[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k0 = 32 * T + 8 * (lane >> 4) + 2 * j, k1 = k0 + 1;
-    split2_pair(256.0f * w[((k0 % WF) * WF + o) * E + k0 / WF], 256.0f * w[((k1 % WF) * WF + o) * E + k1 / WF], h[j], l[j]);
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = 32 * T + 8 * (lane >> 4) + 2 * j, k1 = k0 + 1;
+      const float v0 = 256.0f * w[((k0 % WF) * WF + o) * E + k0 / WF], v1 = 256.0f * w[((k1 % WF) * WF + o) * E + k1 / WF];
+      bad |= mpw_out_of_range(v0) || mpw_out_of_range(v1);
+      split2_pair(v0, v1, h[j], l[j]);
+    }
+    unsigned* d = out + ((size_t)((ct * NT2 + T) * 2) * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
   }
-  unsigned* d = out + ((size_t)((ct * NT2 + T) * 2) * 64 + lane) * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
+  if (bad && guard.word) {
+    range_guard_raise(guard, true);
+    if (wflag) *wflag = 1u;
+  }
 }
 
 int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
@@ -111,8 +128,12 @@ int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float
 //   outT[(((ctile*2 + Ts)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of
 //   2^8 Wsrc2(k = 32 Ts + 8 (lane>>4) + t, o = 16 ctile + (lane&15)),  Wsrc2(k = m, o = n*64 + l) = w[l][m][n];
 // blockIdx.y = 1 -> the dh = B Wn image in the same fp16 piece form (mp_win_bwd_node_kernel<E, true>)
-__global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ outT, float* __restrict__ outN) {
+__global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ outT, float* __restrict__ outN,
+                                       float* __restrict__ f32T, float* __restrict__ f32N, RangeGuard guard) {
   const int KF = E * WF;
+  // blockIdx.y = 2, 3 (when launched so): the fp32 fragment images (modes 2 and 1) for the fallback launches
+  if (blockIdx.y >= 2) { mpw_pack_f32_body(E, blockIdx.y == 2 ? 2 : 1, w, blockIdx.y == 2 ? f32T : f32N); return; }
+  bool bad = false;
   if (blockIdx.y == 0) {
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (KF / 16) * 2 * 64; idx += gridDim.x * blockDim.x) {
       const int lane = idx & 63, Ts = (idx >> 6) & 1, ctile = idx >> 7;
@@ -121,7 +142,9 @@ __global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsig
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k0 = 32 * Ts + 8 * (lane >> 4) + 2 * j;
-        split2_pair(256.0f * w[((o % WF) * WF + k0) * E + o / WF], 256.0f * w[((o % WF) * WF + k0 + 1) * E + o / WF], h[j], l[j]);
+        const float v0 = 256.0f * w[((o % WF) * WF + k0) * E + o / WF], v1 = 256.0f * w[((o % WF) * WF + k0 + 1) * E + o / WF];
+        bad |= mpw_out_of_range(v0) || mpw_out_of_range(v1);
+        split2_pair(v0, v1, h[j], l[j]);
       }
       unsigned* d = outT + ((size_t)((ctile * 2 + Ts) * 2) * 64 + lane) * 4;
 #pragma unroll
@@ -145,10 +168,13 @@ __global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsig
       for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
     }
   }
+  if (bad && guard.word) range_guard_raise(guard, true);       // the first image sees every weight
 }
 
-int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN) {
-  hipLaunchKernelGGL(mpw_pack_bwd_h2_kernel, dim3(24, 2), dim3(256), 0, st, E, w, (unsigned*)outT, outN);
+int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN, float* f32T, float* f32N,
+                    RangeGuard guard) {
+  hipLaunchKernelGGL(mpw_pack_bwd_h2_kernel, dim3(24, f32T ? 4 : 2), dim3(256), 0, st, E, w, (unsigned*)outT, outN, f32T, f32N,
+                     guard);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -300,9 +326,39 @@ struct WinTile {
   static constexpr int BYTES_F32 = WTA * LD * 4, BYTES_H2 = 2 * PLANE;
 };
 
+template <int S>
+__device__ __forceinline__ int ror_i(int v) {
+  if (S == 0) return v;
+  return __builtin_amdgcn_update_dpp(0, v, 0x120 + (S & 15), 0xf, 0xf, false);
+}
+template <int S>
+__device__ __forceinline__ float ror_f(float v) {
+  return __builtin_bit_cast(float, ror_i<S>(__builtin_bit_cast(int, v)));
+}
+
+// H2 rows carry a power-of-two scale when their largest entry reaches 2^15 (an aggregate of features is a forward quantity
+// of any size — the reference's MPLayer is plain fp32): the 16 lanes of the row's DPP row hold all of it, the inverse goes
+// to rs[atom] for the epilogue.  Every ordinary row has scale 1 and the same bits as without.
 template <int E, bool H2>
-__device__ __forceinline__ void tile_put(float* __restrict__ tb, int al, int c, const f32x2 (&lo)[E], const f32x2 (&hi)[E]) {
+__device__ __forceinline__ void tile_put(float* __restrict__ tb, int al, int c, f32x2 (&lo)[E], f32x2 (&hi)[E],
+                                         float* __restrict__ rs) {
   if (H2) {
+    float m = 0.f;
+#pragma unroll
+    for (int n = 0; n < E; ++n)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(lo[n][0]), fabsf(lo[n][1]))), fmaxf(fabsf(hi[n][0]), fabsf(hi[n][1])));
+    float rsv = 1.0f;
+    if (__builtin_amdgcn_ballot_w64(m >= 32768.0f) != 0) {      // wave-uniform and never taken for ordinary activations
+      m = fmaxf(m, ror_f<8>(m)); m = fmaxf(m, ror_f<4>(m)); m = fmaxf(m, ror_f<2>(m)); m = fmaxf(m, ror_f<1>(m));
+      const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
+      const bool big = ef >= 127 + 15 && ef != 255;
+      const float S = big ? __builtin_bit_cast(float, (268 - ef) << 23) : 1.0f;       // 2^(14 - e): |S x| < 2^15
+      rsv = big ? __builtin_bit_cast(float, (ef - 14) << 23) : 1.0f;
+      const f32x2 S2 = {S, S};
+#pragma unroll
+      for (int n = 0; n < E; ++n) { lo[n] *= S2; hi[n] *= S2; }
+    }
+    if (c == 0) rs[al] = rsv;
     char* p = reinterpret_cast<char*>(tb) + al * WinTile<E>::ROWB + 8 * c;
 #pragma unroll
     for (int n = 0; n < E; ++n) {
@@ -325,16 +381,6 @@ __device__ __forceinline__ void tile_put(float* __restrict__ tb, int al, int c, 
 // step s the lane uses the slot of lane (c + s) mod 16, fetched over the DPP network (row_ror:s) —
 // each lane walks the neighbours in its own rotated order, the sum is the same.  All sixteen lanes of
 // a row read the SAME bank group (4c..4c+3) of sixteen DIFFERENT window rows: still conflict-free.
-template <int S>
-__device__ __forceinline__ int ror_i(int v) {
-  if (S == 0) return v;
-  return __builtin_amdgcn_update_dpp(0, v, 0x120 + (S & 15), 0xf, 0xf, false);
-}
-template <int S>
-__device__ __forceinline__ float ror_f(float v) {
-  return __builtin_bit_cast(float, ror_i<S>(__builtin_bit_cast(int, v)));
-}
-
 // four rotation steps: row reads and FMAs are separate so that the reads of the NEXT four steps can be
 // issued before the FMAs of the current four (the LDS latency is otherwise exposed: both waves of a SIMD
 // run this phase in lockstep and wait at the same time)
@@ -360,7 +406,8 @@ __device__ __forceinline__ void rot_fma4(const float4 (&h)[4], const float (&w)[
 template <int E, bool H2>
 __device__ __forceinline__ void win_gather_rot(int K, int wave, int lane, int wlo,
                                                const int32_t* __restrict__ nl, const float* __restrict__ ee,
-                                               float* __restrict__ tb, const float4* __restrict__ win4) {
+                                               float* __restrict__ tb, const float4* __restrict__ win4,
+                                               float* __restrict__ rs) {
   const int c = lane & 15;
   const int al = wave * 4 + (lane >> 4);
   const int slot = al * K + (c < K ? c : 0);
@@ -386,7 +433,7 @@ __device__ __forceinline__ void win_gather_rot(int K, int wave, int lane, int wl
   __builtin_amdgcn_sched_barrier(0);
   rot_fma4<E, 8>(ha, w, lo, hi);
   rot_fma4<E, 12>(hb, w, lo, hi);
-  tile_put<E, H2>(tb, al, c, lo, hi);
+  tile_put<E, H2>(tb, al, c, lo, hi, rs);
 }
 
 // gather + edge-weighted sum of one 32-atom tile: 16 lanes per atom, 4 atoms per wave, 8 waves.
@@ -397,7 +444,7 @@ template <int E, bool K4, int MODE, bool H2>
 __device__ __forceinline__ void win_gather(int K, int wave, int lane, int wlo,
                                            const int32_t* __restrict__ nl, const float* __restrict__ ee,
                                            float* __restrict__ tb, const float4* __restrict__ win4,
-                                           const float4* __restrict__ src4) {
+                                           const float4* __restrict__ src4, float* __restrict__ rs) {
   const int c = lane & 15;
   const int al = wave * 4 + (lane >> 4);
   const float4* wbase = win4 + c;
@@ -464,7 +511,7 @@ __device__ __forceinline__ void win_gather(int K, int wave, int lane, int wlo,
       for (int n = 0; n < E; ++n) pk_axpy(lo[n], hi[n], ee[(al * K + j) * E + n], hv);
     }
   }
-  tile_put<E, H2>(tb, al, c, lo, hi);
+  tile_put<E, H2>(tb, al, c, lo, hi, rs);
 }
 
 // The global-memory variant is kept out of line: inlined next to the window variant it makes the
@@ -472,8 +519,8 @@ __device__ __forceinline__ void win_gather(int K, int wave, int lane, int wlo,
 // stalls on the list prefetch in flight.
 template <int E, bool K4, bool H2>
 __device__ __noinline__ void win_gather_global(int K, int wave, int lane, const int32_t* nl, const float* ee,
-                                               float* tb, const float4* src4) {
-  win_gather<E, K4, 1, H2>(K, wave, lane, 0, nl, ee, tb, nullptr, src4);
+                                               float* tb, const float4* src4, float* rs) {
+  win_gather<E, K4, 1, H2>(K, wave, lane, 0, nl, ee, tb, nullptr, src4, rs);
 }
 
 // ---- forward ------------------------------------------------------------------------------------------
@@ -492,10 +539,13 @@ struct MpWinFwdArgs {
   float* S_save;           // [N][64] or nullptr
   int act;
   float* dummy;            // 64 floats: where the lanes of rows >= N store
+  RangeGuard guard;        // word == nullptr: unguarded (NG_GEMM_MATH=fp32)
+  const unsigned* wflag;   // flag word of a weight image kept over calls (weights out of the piece range), or nullptr
+  const float* Wfrag32;    // fp32 fragments (mpw_pack mode 0) a guarded call switches to when its weights leave the range
 };
 
 template <int E, bool K4, bool H2>
-__global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a) {
+__device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
   constexpr int NT = KF / 16, NT2 = KF / 32;
@@ -506,6 +556,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
   int32_t* s_nl = reinterpret_cast<int32_t*>(tile + TILE_FLOATS);      // [2][32*K]
   float* s_e = reinterpret_cast<float*>(s_nl + 2 * WTA * a.K);         // [2][32*K*E]
   int* ctl = reinterpret_cast<int*>(s_e + 2 * WTA * a.K * E);          // [2][16]
+  float* s_rs = reinterpret_cast<float*>(ctl + 32);                    // [32]  inverse row scale of the piece tile (H2)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -576,9 +627,9 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
     {
       const int32_t* nl = s_nl + (t & 1) * per_tile;
       const float* ee = s_e + (t & 1) * per_tile * E;
-      if (mode == 0 && K <= 16) win_gather_rot<E, H2>(K, wave, lane, wlo, nl, ee, tile, win4);
-      else if (mode == 0) win_gather<E, K4, 0, H2>(K, wave, lane, wlo, nl, ee, tile, win4, src4);
-      else win_gather_global<E, K4, H2>(K, wave, lane, nl, ee, tile, src4);
+      if (mode == 0 && K <= 16) win_gather_rot<E, H2>(K, wave, lane, wlo, nl, ee, tile, win4, s_rs);
+      else if (mode == 0) win_gather<E, K4, 0, H2>(K, wave, lane, wlo, nl, ee, tile, win4, src4, s_rs);
+      else win_gather_global<E, K4, H2>(K, wave, lane, nl, ee, tile, src4, s_rs);
     }
     NG_LDS_BARRIER();
     // ---- phase 2: tile x weights on the matrix cores, epilogue
@@ -607,7 +658,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[T]), __builtin_bit_cast(f16x8, xl[T]), acc0, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        rsx = rs * (1.0f / 256.0f);
+        rsx = rs * (1.0f / 256.0f) * s_rs[16 * hh + a16];
       } else {
         const float* xrow = tile + (16 * hh + a16) * LD + 4 * g;
         // operand reads run two k-steps ahead of the MFMAs that consume them (pinned: left alone the
@@ -650,6 +701,20 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a)
       win_stage(win4, src4, wlo, a.N, tid);
       NG_LDS_BARRIER();
     }
+  }
+}
+
+// Range guard (ng_internal.h).  The aggregate rows of the piece form carry their own scale (tile_put), so the only operand
+// that can leave the fp16 range is a weight (|2^8 w| >= 65504) — known at the kernel's first instruction: the pack launch
+// of this call raised the guard, or the image kept over calls (ng_weights_frozen) has its flag word set.  Both bodies live
+// in the one kernel; the choice is uniform over the launch and costs no second launch.
+template <int E, bool K4, bool H2>
+__global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag != 0u))) {
+    a.Wfrag = a.Wfrag32;
+    mp_win_fwd_body<E, K4, false>(a);
+  } else {
+    mp_win_fwd_body<E, K4, H2>(a);
   }
 }
 
@@ -1047,7 +1112,7 @@ int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const f
 size_t mp_win_lds_bytes(int K, int E) {
   // the larger of the two tile forms (fp32 rows, fp16 piece planes): the budget check is the same for both
   const int tile_bytes = std::max(WTA * (E * WF + 4) * 4, 2 * WTA * (E * WF + 8) * 2);
-  return (size_t)(WROWS * WF + 2 * WTA * K * (1 + E) + 32) * 4 + tile_bytes;
+  return (size_t)(WROWS * WF + 2 * WTA * K * (1 + E) + 32 + 32) * 4 + tile_bytes;
 }
 
 // matrix phase of the forward window kernel on the fp16 pipe with two-piece operands unless NG_GEMM_MATH=fp32
@@ -1066,17 +1131,35 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
                float* s_save) {
   if (N == 0) return NG_OK;
   const int KF = E * WF;
-  bool have = false;
   const bool h2 = mp_win_h2();
-  // both images take KF*64*4 bytes (fp32 fragments / two fp16 pieces); different cache kinds
-  float* Wfrag = (float*)cached_image(ctx, w, h2 ? 7 : 4, (size_t)(KF * WF + 64) * 4, &have);
-  if (!Wfrag) Wfrag = (float*)workspace(ctx, (size_t)(KF * WF + 64) * 4);
-  if (!Wfrag) return NG_ERR_NOMEM;
+  // guarded call: the pack launch checks the weights against the piece range and the kernel takes its fp32-input body
+  // (second image, same launch) when they do not fit
+  const bool guarded = h2;
+  RangeGuard guard{nullptr, 0};
+  if (guarded) {
+    guard = range_guard_begin(ctx);
+    if (!guard.word) return NG_ERR_NOMEM;
+  }
+  // image: KF*64 floats (fp32 fragments / two fp16 pieces) + 64 floats of dummy row + the flag word; different cache kinds
+  const size_t img_floats = (size_t)KF * WF + 64 + 16;
+  bool have = false, have32 = false;
+  float* Wfrag = (float*)cached_image(ctx, w, h2 ? 7 : 4, img_floats * 4, &have);
+  float* Wf32 = guarded && Wfrag ? (float*)cached_image(ctx, w, 4, img_floats * 4, &have32) : nullptr;
+  if (Wfrag && guarded && !Wf32) return NG_ERR_NOMEM;
+  const bool cached = Wfrag != nullptr;
+  if (!cached) {
+    Wfrag = (float*)workspace(ctx, 2 * img_floats * 4);
+    if (!Wfrag) return NG_ERR_NOMEM;
+    Wf32 = guarded ? Wfrag + img_floats : nullptr;
+    have = have32 = false;
+  }
+  unsigned* wflag = cached && guarded ? reinterpret_cast<unsigned*>(Wfrag + KF * WF + 64) : nullptr;
   int rc = NG_OK;
-  if (!have && h2) {
-    hipLaunchKernelGGL(mpw_pack_h2_kernel, dim3((unsigned)cdiv(4 * (KF / 32) * 64, 256)), dim3(256), 0, st, E, w, (unsigned*)Wfrag);
+  if (h2 && !(have && (have32 || !guarded))) {
+    if (wflag) NG_HIP(ctx, hipMemsetAsync(wflag, 0, 4, st));
+    hipLaunchKernelGGL(mpw_pack_h2_kernel, dim3(24, guarded ? 2 : 1), dim3(256), 0, st, E, w, (unsigned*)Wfrag, Wf32, guard, wflag);
     NG_HIP(ctx, hipGetLastError());
-  } else if (!have) {
+  } else if (!h2 && !have) {
     rc = mpw_pack(ctx, st, E, 0, w, Wfrag);
   }
   if (rc) return rc;
@@ -1090,23 +1173,26 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   a.out = h_out; a.S_save = s_save; a.act = act; a.dummy = Wfrag + KF * WF;
   const int grid = (int)cdiv(a.ntiles, per);
   const size_t lds = mp_win_lds_bytes(K, E);
-  ProfScope ps(ctx, st, "mp_win_fwd");
-#define CALL(EE)                                                                                          \
-  if (K % 4 == 0 && h2)                                                                                   \
-    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true, true>), dim3(grid), dim3(WTHREADS), lds, st, a);      \
-  else if (K % 4 == 0)                                                                                    \
-    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true, false>), dim3(grid), dim3(WTHREADS), lds, st, a);     \
-  else if (h2)                                                                                            \
-    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false, true>), dim3(grid), dim3(WTHREADS), lds, st, a);     \
+  a.guard = guard; a.wflag = wflag;
+#define CALL(EE, HH)                                                                                      \
+  if (K % 4 == 0)                                                                                         \
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true, HH>), dim3(grid), dim3(WTHREADS), lds, st, a);        \
   else                                                                                                    \
-    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false, false>), dim3(grid), dim3(WTHREADS), lds, st, a);
-  switch (E) {
-    case 1: { CALL(1) } break;
-    case 2: { CALL(2) } break;
-    case 3: { CALL(3) } break;
+    hipLaunchKernelGGL((mp_win_fwd_kernel<EE, false, HH>), dim3(grid), dim3(WTHREADS), lds, st, a);
+#define CALLE(HH)                                                                                         \
+  switch (E) {                                                                                            \
+    case 1: { CALL(1, HH) } break;                                                                        \
+    case 2: { CALL(2, HH) } break;                                                                        \
+    case 3: { CALL(3, HH) } break;                                                                        \
   }
+  a.Wfrag32 = Wf32;
+  {
+    ProfScope ps(ctx, st, "mp_win_fwd");
+    if (h2) { CALLE(true) } else { CALLE(false) }
+    NG_HIP(ctx, hipGetLastError());
+  }
+#undef CALLE
 #undef CALL
-  NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
 

@@ -107,6 +107,8 @@ struct MpWinEdgeArgs {
   float* dummy;            // >= 64 floats
   int act;
   int accumulate;
+  RangeGuard guard;        // word == nullptr: unguarded
+  const float* WfragT32;   // fp32 fragments (mpw_pack mode 2) for a guarded call whose weights leave the piece range
 };
 
 // one rotation step of the edge-gradient dot: this lane's chunk of dA[i][n][:] against the row of the slot
@@ -175,7 +177,7 @@ __device__ __noinline__ void edge_dot_global(int K, int wave, int lane, const in
 // (columns 64 / 65 of the padded dP tile: S and 1/S); the lane that multiplies a row splits S * dP in registers and
 // multiplies its outputs by 2^-8 / S.  Scaling dH by 2^k moves every S by 2^-k: bit-identical scaled results.
 template <int E, bool H2>
-__global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeArgs a) {
+__device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
   constexpr int NCT = KF / 16 / 4;          // column tiles per wave (4 waves per atom half)
@@ -375,6 +377,20 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeA
   }
 }
 
+// Range guard (ng_internal.h).  The gradient operand of the piece form carries its own per-row scale, so the only thing
+// that can leave the fp16 range here is a weight (|2^8 w| >= 65504) — known when the kernel starts: the pack launch in
+// front raised the guard.  Both forms live in the one kernel and the launch picks, uniformly, at its first instruction:
+// no second launch on the timeline (an empty one costs ~4.6 us on this part, profiles/r03b).
+template <int E, bool H2>
+__global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeArgs a) {
+  if (H2 && a.guard.word && range_guard_raised(a.guard)) {
+    a.WfragT = a.WfragT32;
+    mp_win_bwd_edge_body<E, false>(a);
+  } else {
+    mp_win_bwd_edge_body<E, H2>(a);
+  }
+}
+
 // ---- node kernel ---------------------------------------------------------------------------------------
 // Incoming-edge records in CSC order, 16 bytes each: { source atom (int bits), e[p][0..2] } — built once
 // per backward pass (the edge features are the same for every layer).
@@ -393,6 +409,8 @@ struct MpWinNodeArgs {
   float* dh;                // [N][64] out
   float* partial;           // [grid][64*E*64] dw partials, layout [(n,m)][l]
   float* dummy;
+  RangeGuard guard;         // word == nullptr: unguarded
+  const float* WfragN32;    // fp32 fragments (mpw_pack mode 1) for a guarded call whose weights leave the piece range
 };
 
 __device__ __forceinline__ void pk_axpy(f32x2& lo, f32x2& hi, float w, const float4& h) {
@@ -503,7 +521,7 @@ __device__ __noinline__ void node_gather_global(int wave, int lane, const int* s
 }
 
 template <int E, bool H2>
-__global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeArgs a) {
+__device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
   constexpr int NT = KF / 16, NT2 = KF / 32;
@@ -702,6 +720,26 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
           const float ratio = sba < sbref ? 1.0f : __builtin_bit_cast(float, max(sbref - sba + 127, 0) << 23);
           hv[tt] = htile[at * SDP_LD + 16 * ct + a16] * ratio;
         }
+        // the layer input is a forward quantity of any size (the reference's MPLayer is plain fp32): row l of h'^T (this
+        // lane's l = 16 ct + a16 over the tile's 32 atoms: 8 here, the rest in the lanes 16 / 32 / 48 further on) gets a
+        // power-of-two scale when its largest entry reaches 2^15, and the output rows take the inverse.  1 (bit-neutral)
+        // for every ordinary input.
+        float hm = fmaxf(fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), fmaxf(fabsf(hv[2]), fabsf(hv[3]))),
+                         fmaxf(fmaxf(fabsf(hv[4]), fabsf(hv[5])), fmaxf(fabsf(hv[6]), fabsf(hv[7]))));
+        f32x4 osc4 = {inv_ref, inv_ref, inv_ref, inv_ref};
+        if (__builtin_amdgcn_ballot_w64(hm >= 32768.0f) != 0) {      // wave-uniform, never taken for ordinary activations
+          hm = fmaxf(hm, __shfl_xor(hm, 16));
+          hm = fmaxf(hm, __shfl_xor(hm, 32));
+          const int hef = (__builtin_bit_cast(int, hm) >> 23) & 255;
+          const bool hbig = hef >= 127 + 15 && hef != 255;
+          const float hs = hbig ? __builtin_bit_cast(float, (268 - hef) << 23) : 1.0f;
+          const float hsi = hbig ? __builtin_bit_cast(float, (hef - 14) << 23) : 1.0f;
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt) hv[tt] *= hs;
+          // accumulator element r of this lane is output row l = 16 ct + 4 g4 + r: its inverse scale sits in lane 4 g4 + r
+#pragma unroll
+          for (int r = 0; r < 4; ++r) osc4[r] = __shfl(hsi, 4 * g4 + r) * inv_ref;
+        }
         unsigned h0, l0, h1, l1, h2, l2, h3, l3;
         split2_pair(hv[0], hv[1], h0, l0); split2_pair(hv[2], hv[3], h1, l1);
         split2_pair(hv[4], hv[5], h2, l2); split2_pair(hv[6], hv[7], h3, l3);
@@ -722,7 +760,7 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
           at = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), at, 0, 0, 0);
           at = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), at, 0, 0, 0);
           at = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), at, 0, 0, 0);
-          accW[u] += at * inv_ref;
+          accW[u] += at * osc4;
         }
       } else {
         // D[i = l][j = (n,m)] += sum_atoms h[atom][l] B[atom][(n,m)]: l-tile ct, column tiles NCT*hh + u
@@ -755,6 +793,18 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
       *reinterpret_cast<float4*>(part + cidx * WF + 16 * ct + 4 * g4) =
           make_float4(accW[u][0], accW[u][1], accW[u][2], accW[u][3]);
     }
+  }
+}
+
+// Range guard: as in the edge kernel — the piece operands B (per-row scale) and h' (per-row scale, above) are range-safe by
+// construction, a weight image out of range is known at the first instruction and selects the fp32-input body.
+template <int E, bool H2>
+__global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeArgs a) {
+  if (H2 && a.guard.word && range_guard_raised(a.guard)) {
+    a.WfragN = a.WfragN32;
+    mp_win_bwd_node_body<E, false>(a);
+  } else {
+    mp_win_bwd_node_body<E, H2>(a);
   }
 }
 
@@ -801,31 +851,32 @@ int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const i
 
 size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E) { return (size_t)(ctx->num_cu + 1) * E * WF * WF; }
 
-// dh_in = dh_out + B Wn,  dw = h^T B  with B the incoming-edge aggregate of dP (never materialised)
+// dh_in = dh_out + B Wn,  dw = h^T B  with B the incoming-edge aggregate of dP (never materialised).
+// guard.word != nullptr: WfragN is the piece image, WfragN32 the fp32 one the kernel switches to when the guard is up.
 int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
-                    float* dh_in, float* dw, float* scratch, float* dummy) {
+                    float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32) {
   MpWinNodeArgs a{};
   a.N = N; a.ntiles = cdiv(N, WTA);
   const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.dP = dP; a.dH = dh_out; a.h = h; a.csc_ptr = csc_ptr; a.rec = reinterpret_cast<const float4*>(rec);
-  a.WfragN = WfragN; a.dh = dh_in; a.partial = scratch; a.dummy = dummy;
+  a.WfragN = WfragN; a.dh = dh_in; a.partial = scratch; a.dummy = dummy; a.guard = guard;
   const int grid = (int)cdiv(a.ntiles, per);
   const bool h2 = mp_win_bwd_h2();
-  const size_t lds = node_lds_bytes(E, h2);
+#define NODE(HH)                                                                                                        \
+  switch (E) {                                                                                                          \
+    case 1: hipLaunchKernelGGL((mp_win_bwd_node_kernel<1, HH>), dim3(grid), dim3(WTHREADS), node_lds_bytes(E, HH), st, a); break; \
+    case 2: hipLaunchKernelGGL((mp_win_bwd_node_kernel<2, HH>), dim3(grid), dim3(WTHREADS), node_lds_bytes(E, HH), st, a); break; \
+    case 3: hipLaunchKernelGGL((mp_win_bwd_node_kernel<3, HH>), dim3(grid), dim3(WTHREADS), node_lds_bytes(E, HH), st, a); break; \
+  }
+  a.WfragN32 = WfragN32;
   {
     ProfScope ps(ctx, st, "mp_win_bwd_node");
-    switch (E) {
-      case 1: if (h2) hipLaunchKernelGGL((mp_win_bwd_node_kernel<1, true>), dim3(grid), dim3(WTHREADS), lds, st, a);
-              else hipLaunchKernelGGL((mp_win_bwd_node_kernel<1, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 2: if (h2) hipLaunchKernelGGL((mp_win_bwd_node_kernel<2, true>), dim3(grid), dim3(WTHREADS), lds, st, a);
-              else hipLaunchKernelGGL((mp_win_bwd_node_kernel<2, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 3: if (h2) hipLaunchKernelGGL((mp_win_bwd_node_kernel<3, true>), dim3(grid), dim3(WTHREADS), lds, st, a);
-              else hipLaunchKernelGGL((mp_win_bwd_node_kernel<3, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-    }
+    if (h2) { NODE(true) } else { NODE(false) }
     NG_HIP(ctx, hipGetLastError());
   }
+#undef NODE
   ProfScope ps(ctx, st, "reduce_partials");
   // partial idx = (n*64 + m)*64 + l  ->  dw[(l*64 + m)*E + n]
   launch_reduce_z(st, scratch, grid, (int64_t)E * WF * WF, dw, 2, WF, E, WF, (int64_t)E * WF * WF);
@@ -839,31 +890,31 @@ bool mp_win_bwd_supported(int F, int E, int K) {
 
 int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
                     const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
-                    const float* dh_out, float* dP, float* de, int de_accum, float* dummy) {
+                    const float* dh_out, float* dP, float* de, int de_accum, float* dummy, RangeGuard guard,
+                    const float* WfragT32) {
   MpWinEdgeArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
   const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.dH = dh_out; a.S = act == NG_ACT_NONE ? nullptr : s_save; a.rowscale = inv_degree; a.h = h;
   a.nlist = nlist; a.WfragT = WfragT; a.dP = dP; a.de = de; a.dummy = dummy; a.act = act;
-  a.accumulate = de_accum;
+  a.accumulate = de_accum; a.guard = guard;
   const int grid = (int)cdiv(a.ntiles, per);
   const size_t lds = edge_lds_bytes(K, E);
-  ProfScope ps(ctx, st, "mp_win_bwd_edge");
-  if (mp_win_bwd_h2()) {
-    switch (E) {
-      case 1: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<1, true>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2, true>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3, true>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-    }
-  } else {
-    switch (E) {
-      case 1: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<1, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-      case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3, false>), dim3(grid), dim3(WTHREADS), lds, st, a); break;
-    }
+  const bool h2 = mp_win_bwd_h2();
+#define EDGE(HH)                                                                                                  \
+  switch (E) {                                                                                                    \
+    case 1: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<1, HH>), dim3(grid), dim3(WTHREADS), lds, st, a); break;   \
+    case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2, HH>), dim3(grid), dim3(WTHREADS), lds, st, a); break;   \
+    case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3, HH>), dim3(grid), dim3(WTHREADS), lds, st, a); break;   \
   }
-  NG_HIP(ctx, hipGetLastError());
+  a.WfragT32 = WfragT32;
+  {
+    ProfScope ps(ctx, st, "mp_win_bwd_edge");
+    if (h2) { EDGE(true) } else { EDGE(false) }
+    NG_HIP(ctx, hipGetLastError());
+  }
+#undef EDGE
   return NG_OK;
 }
 
@@ -878,27 +929,40 @@ int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, co
                const float* csc_rec) {
   const int KF = E * WF;
   const size_t dw_scr = mp_win_node_scratch_floats(ctx, E);
-  // scratch: two packed weight images | dP [N,64] | records [N*K,4] (when the caller has none) | dw partials
+  const bool h2 = mp_win_bwd_h2();
+  // guarded call (RangeGuard, ng_internal.h): the pack launch raises the guard for weights out of the piece range and
+  // both kernels then run their fp32-input bodies
+  const bool guarded = h2;
+  RangeGuard guard{nullptr, 0};
+  if (guarded) {
+    guard = range_guard_begin(ctx);
+    if (!guard.word) return NG_ERR_NOMEM;
+  }
+  // scratch: four packed weight images (piece T, N; fp32 T, N) | dP [N,64] | records [N*K,4] (when the caller has none)
+  // | dw partials
   const size_t rec_floats = csc_rec ? 0 : (size_t)N * K * 4;
-  float* ws = (float*)workspace(ctx, (size_t)(2 * KF * WF + N * WF + rec_floats + dw_scr + 64) * 4);
+  float* ws = (float*)workspace(ctx, (size_t)(4 * KF * WF + N * WF + rec_floats + dw_scr + 64) * 4);
   if (!ws) return NG_ERR_NOMEM;
   float* WfragT = ws;
   float* WfragN = WfragT + KF * WF;
-  float* dP = WfragN + KF * WF;
+  float* WfragT32 = WfragN + KF * WF;
+  float* WfragN32 = WfragT32 + KF * WF;
+  float* dP = WfragN32 + KF * WF;
   float* rec = dP + N * WF;
   float* scr = rec + rec_floats;
   float* dummy = scr + dw_scr;
-  int rc = mp_win_bwd_h2() ? mpw_pack_bwd_h2(ctx, st, E, w, WfragT, WfragN)
-                           : mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // both weight images in one launch
+  int rc = h2 ? mpw_pack_bwd_h2(ctx, st, E, w, WfragT, WfragN, guarded ? WfragT32 : nullptr, guarded ? WfragN32 : nullptr, guard)
+              : mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // all weight images in one launch
   if (rc) return rc;
-  rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum, dummy);
+  rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum, dummy, guard,
+                       WfragT32);
   if (rc) return rc;
   if (!csc_rec) {
     rc = mp_win_records(ctx, st, N, K, E, csc_ptr, csc_edge, e, rec);
     if (rc) return rc;
     csc_rec = rec;
   }
-  return mp_win_bwd_node(ctx, st, N, E, h, dP, csc_ptr, csc_rec, WfragN, dh_out, dh_in, dw, scr, dummy);
+  return mp_win_bwd_node(ctx, st, N, E, h, dP, csc_ptr, csc_rec, WfragN, dh_out, dh_in, dw, scr, dummy, guard, WfragN32);
 }
 
 }  // namespace ng

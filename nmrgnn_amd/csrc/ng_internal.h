@@ -154,7 +154,9 @@ int egrad_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const
 int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
             const float* e, float* A);
 // backward images, the dA image as fp16 piece fragments (mp_win.hip)
-int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN);
+// f32T / f32N (optional): the fp32 fragment images of the same launch, for the guarded fallback kernels
+int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN, float* f32T, float* f32N,
+                    RangeGuard guard);
 int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
                const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
                float* s_save);
@@ -163,14 +165,15 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
 bool mp_win_bwd_supported(int F, int E, int K);
 int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
                     const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
-                    const float* dh_out, float* dP, float* de, int de_accum, float* dummy);
+                    const float* dh_out, float* dP, float* de, int de_accum, float* dummy, RangeGuard guard,
+                    const float* WfragT32);
 
 int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
                    const int32_t* csc_edge, const float* e, float* rec);
 size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E);
 int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
-                    float* dh_in, float* dw, float* scratch, float* dummy);
+                    float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32);
 
 // window-resident MPLayer backward, both kernels (mp_win_bwd.hip)
 bool mp_win_bwd_enabled(int F, int E, int K);
