@@ -967,16 +967,26 @@ __device__ __forceinline__ void eg_tile(int K, int wave, int lane, int wlo, cons
   eg_step<E, 15, MODE>(wb, src4, f4n, slab, c, roff, idx, da, out);
 }
 
+// operands and results of the out-of-line variant travel in registers (vector arguments, a vector back): arrays passed
+// by pointer, and structs of vectors passed by value, lived on the stack
 template <int E>
-__device__ __noinline__ void eg_tile_global(int K, int wave, int lane, const int32_t* nl, const float4* src4, int f4n, int slab,
-                                            const float4* da_flat, float* out_flat) {
+__device__ __noinline__ f32x4 eg_tile_global(int K, const int32_t* nl, const float4* src4, int f4n, int slab,
+                                                 f32x4 r0, f32x4 r1, f32x4 r2, f32x4 r3, f32x4 r4, f32x4 r5) {
+  // (arguments beyond 32 dwords go over the stack: wave and lane are taken from the thread id here)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const f32x4 rows[6] = {r0, r1, r2, r3, r4, r5};      // [chunk][n], E entries per chunk
   float4 da[2][E];
   float out[E];
 #pragma unroll
-  for (int n = 0; n < E; ++n) { da[0][n] = da_flat[n]; da[1][n] = da_flat[E + n]; }
+  for (int n = 0; n < E; ++n) {
+    da[0][n] = make_float4(rows[n][0], rows[n][1], rows[n][2], rows[n][3]);
+    da[1][n] = make_float4(rows[E + n][0], rows[E + n][1], rows[E + n][2], rows[E + n][3]);
+  }
   eg_tile<E, 1>(K, wave, lane, 0, nl, nullptr, src4, f4n, slab, da, out);
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int n = 0; n < E; ++n) out_flat[n] = out[n];
+  for (int n = 0; n < E; ++n) r[n] = out[n];
+  return r;
 }
 
 template <int E>
@@ -1048,10 +1058,17 @@ __global__ __launch_bounds__(WTHREADS, 1) void egrad_win_kernel(EGradWinArgs a) 
       if (mode == 0) {
         eg_tile<E, 0>(K, wave, lane, wlo, nl, win4, src4, f4n, slab, da, out);
       } else {
-        float4 daf[2 * E];
+        f32x4 rows[6];
 #pragma unroll
-        for (int n = 0; n < E; ++n) { daf[n] = da[0][n]; daf[E + n] = da[1][n]; }
-        eg_tile_global<E>(K, wave, lane, nl, src4, f4n, slab, daf, out);
+        for (int n = 0; n < 6; ++n) rows[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+          rows[n] = f32x4{da[0][n].x, da[0][n].y, da[0][n].z, da[0][n].w};
+          rows[E + n] = f32x4{da[1][n].x, da[1][n].y, da[1][n].z, da[1][n].w};
+        }
+        const f32x4 r = eg_tile_global<E>(K, nl, src4, f4n, slab, rows[0], rows[1], rows[2], rows[3], rows[4], rows[5]);
+#pragma unroll
+        for (int n = 0; n < E; ++n) out[n] = r[n];
       }
       if (owner) {
 #pragma unroll

@@ -163,12 +163,17 @@ __device__ __forceinline__ void edge_dot(int K, int wave, int lane, int wlo, con
 // kept out of line: inlined next to the window variant its global loads make the compiler put vmcnt
 // waits into the window path (see mp_win.hip)
 template <int E>
-__device__ __noinline__ void edge_dot_global(int K, int wave, int lane, const int32_t* nl, const float* tb,
-                                             int ld, const float4* src4, float* out3) {
+struct EdgeDots { float v[E]; };      // returned in registers: an array passed out by pointer lived on the stack
+
+template <int E>
+__device__ __noinline__ EdgeDots<E> edge_dot_global(int K, int wave, int lane, const int32_t* nl, const float* tb,
+                                                    int ld, const float4* src4) {
   float out[E];
   edge_dot<E, 1>(K, wave, lane, 0, nl, tb, ld, nullptr, src4, out);
+  EdgeDots<E> r;
 #pragma unroll
-  for (int n = 0; n < E; ++n) out3[n] = out[n];
+  for (int n = 0; n < E; ++n) r.v[n] = out[n];
+  return r;
 }
 
 // H2: the dA product on the fp16 pipe with two-piece operands (h2_common.cuh).  dP is a gradient of arbitrary
@@ -363,7 +368,11 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
       float out[E];
       const int32_t* nl = s_nl + (t & 1) * per_tile;
       if (mode == 0) edge_dot<E, 0>(K, wave, lane, wlo, nl, tile, LD, win4, src4, out);
-      else edge_dot_global<E>(K, wave, lane, nl, tile, LD, src4, out);
+      else {
+        const EdgeDots<E> r = edge_dot_global<E>(K, wave, lane, nl, tile, LD, src4);
+#pragma unroll
+        for (int n = 0; n < E; ++n) out[n] = r.v[n];
+      }
       const int64_t row = t * WTA + prow;
       const bool live = row < a.N && pc < K;
       float* dst = live ? a.de + (row * K + pc) * E : a.dummy;
@@ -577,7 +586,8 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
 
   if (T0 < T1) {
     // per-tile inputs in flight
-    float4 p_rec0, p_rec1, p_h, p_dH;
+    f32x4 p_rec0, p_rec1;      // native vectors: as HIP float4 (a union type) the two stayed in a 32-byte stack slot
+    float4 p_h, p_dH;
     int p_ptr;
     const int a16 = lane & 15, g4 = lane >> 4;
     const int col = 16 * ct + 4 * g4;
@@ -593,19 +603,19 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
       p_end = a.csc_ptr[std::min<int64_t>(r0 + WTA, a.N)];
       p_base = base_next;
       const int64_t q0 = (int64_t)p_base + tid, q1 = q0 + WTHREADS;
-      p_rec0 = a.rec[q0 < nnz ? q0 : (nnz > 0 ? nnz - 1 : 0)];
-      p_rec1 = a.rec[q1 < nnz ? q1 : (nnz > 0 ? nnz - 1 : 0)];
+      p_rec0 = *reinterpret_cast<const f32x4*>(a.rec + (q0 < nnz ? q0 : (nnz > 0 ? nnz - 1 : 0)));
+      p_rec1 = *reinterpret_cast<const f32x4*>(a.rec + (q1 < nnz ? q1 : (nnz > 0 ? nnz - 1 : 0)));
       base_next = a.csc_ptr[std::min<int64_t>(r0 + WTA, a.N)];
     };
     auto commit = [&](int64_t t) {
       float4* rc = s_rec + (t & 1) * NREC_CAP;
       int* pp = s_ptr + (t & 1) * 36;
-      rc[tid] = p_rec0;
-      if (tid + WTHREADS < NREC_CAP) rc[tid + WTHREADS] = p_rec1;
+      *reinterpret_cast<f32x4*>(rc + tid) = p_rec0;
+      if (tid + WTHREADS < NREC_CAP) *reinterpret_cast<f32x4*>(rc + tid + WTHREADS) = p_rec1;
       if (tid <= WTA) pp[tid] = p_ptr;
       // row range over the tile's OWN records only (the staging area also holds the head of later tiles)
       int lo = 0x7fffffff, hi = -1;
-      const int s0 = __builtin_bit_cast(int, p_rec0.x), s1 = __builtin_bit_cast(int, p_rec1.x);
+      const int s0 = __builtin_bit_cast(int, p_rec0[0]), s1 = __builtin_bit_cast(int, p_rec1[0]);
       if (p_base + tid < p_end) { lo = s0; hi = s0; }
       if (p_base + tid + WTHREADS < p_end) { lo = min(lo, s1); hi = max(hi, s1); }
       lo = wave_min_i32(lo);
