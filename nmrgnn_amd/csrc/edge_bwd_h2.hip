@@ -587,18 +587,23 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
 // ---- the power-of-two gradient scale (header: Ranges).  Stage 1: per-block max |de|; stage 2 (one block): the
 // largest absolute row sums of Wo, W3, W2 and S = 2^floor(log2(2^15 / bound)).  max is exact and order-free, so the
 // scale — and with it every bit of the result — does not depend on the launch geometry.
-constexpr int HX_SCALE_BLOCKS = 256;
+constexpr int HX_SCALE_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void hx_absmax_kernel(const float* __restrict__ de, int64_t n, float* __restrict__ blockmax) {
-  __shared__ float red[256];
+  __shared__ float red[4];
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(de[i]));
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
+  // float4 body when the tensor starts 16-byte aligned (a torch allocation does), the rest element by element
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(de) & 15) == 0 ? n >> 2 : 0;
+  const float4* de4 = reinterpret_cast<const float4*>(de);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = de4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-  if (threadIdx.x == 0) blockmax[blockIdx.x] = red[0];
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(de[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 __global__ __launch_bounds__(128) void hx_scale_kernel(const float* __restrict__ blockmax, int nblocks, const float* __restrict__ W2,
@@ -658,7 +663,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
   {
     ProfScope ps(ctx, st, "edge_bwd_h2_prep");
     hipLaunchKernelGGL(h2_pack_wt_kernel, dim3(16), dim3(256), 0, st, W[1], W[2], (unsigned*)wt_img);
-    const int nb = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 256));
+    const int nb = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
     hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb), dim3(256), 0, st, de, n_edges * E, blockmax);
     hipLaunchKernelGGL(hx_scale_kernel, dim3(1), dim3(128), 0, st, blockmax, nb, W[1], W[2], W[3], E, scale);
     NG_HIP(ctx, hipGetLastError());

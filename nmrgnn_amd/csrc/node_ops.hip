@@ -61,6 +61,30 @@ __global__ void embed_fwd_kernel(int64_t N, int C, int F, const float* __restric
   }
 }
 
+// The same for rows of 16 / 32 / 64 float4 (F = 64 / 128 / 256) and C <= 16: a row is one lane group, lane j of the group
+// reads atoms[i][j] once and the group passes the C values round (no per-lane re-read of the row, no branch); the lane's
+// column chunk of every Wemb row stays in registers across the grid-stride loop (its chunk index never changes).
+template <int C4N>
+__global__ __launch_bounds__(256) void embed_fwd_rows_kernel(int64_t N, int C, const float* __restrict__ atoms,
+                                                             const float* __restrict__ Wemb, float* __restrict__ h0) {
+  constexpr int F = 4 * C4N;
+  const int c4 = threadIdx.x % C4N;
+  float4 w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w[c] = c < C ? *reinterpret_cast<const float4*>(Wemb + (int64_t)c * F + c4 * 4) : f4zero();
+  const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / C4N);
+  for (int64_t i = (int64_t)blockIdx.x * (256 / C4N) + threadIdx.x / C4N; i < N; i += rows_per_pass) {
+    const float mine = c4 < C ? atoms[i * C + c4] : 0.f;
+    float4 acc = f4zero();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float a = __shfl(mine, c, C4N);
+      acc.x = fmaf(a, w[c].x, acc.x); acc.y = fmaf(a, w[c].y, acc.y); acc.z = fmaf(a, w[c].z, acc.z); acc.w = fmaf(a, w[c].w, acc.w);
+    }
+    *reinterpret_cast<float4*>(h0 + i * F + c4 * 4) = acc;
+  }
+}
+
 // dWemb[c][f] = sum_i atoms[i][c] dh0[i][f]  — stage 1: partial[blk][c][f] over a row chunk
 __global__ __launch_bounds__(256) void embed_bwd_kernel(int64_t N, int C, int F,
                                                         int64_t rows_per_block,
@@ -667,8 +691,15 @@ extern "C" int ng_embed_fwd(ng_ctx* ctx, void* stream, int64_t N, int C, int F, 
   NG_REQUIRE(ctx, F % 4 == 0, "embed: F % 4");
   if (N == 0) return NG_OK;
   ProfScope ps(ctx, (hipStream_t)stream, "embed_fwd");
-  hipLaunchKernelGGL(embed_fwd_kernel, ew_grid(N * (F / 4)), dim3(256), 0, (hipStream_t)stream, N,
-                     C, F, atoms, Wemb, h0);
+  const dim3 grid = ew_grid(N * (F / 4));
+  if (C <= 16 && F == 64 && !sw().head_generic)
+    hipLaunchKernelGGL((embed_fwd_rows_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, N, C, atoms, Wemb, h0);
+  else if (C <= 16 && F == 128 && !sw().head_generic)
+    hipLaunchKernelGGL((embed_fwd_rows_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, N, C, atoms, Wemb, h0);
+  else if (C <= 16 && F == 256 && !sw().head_generic)
+    hipLaunchKernelGGL((embed_fwd_rows_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, N, C, atoms, Wemb, h0);
+  else
+    hipLaunchKernelGGL(embed_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, C, F, atoms, Wemb, h0);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
