@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 3
+#define NG_ABI_VERSION 4
 
 enum {
   NG_OK = 0,
@@ -320,6 +320,22 @@ int ng_loss_name(ng_ctx*, void* stream, int64_t N, int G, const int32_t* graph_p
  *   g is first multiplied by grad_scale (1/world_size after a summing all-reduce). */
 int ng_adam_step(ng_ctx*, void* stream, int64_t n, float* p, const float* g, float* m, float* v,
                  float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
+
+/* Gradient exchange for a caller without torch.distributed (SURVEY §8(b) suggested export, §8(e): graph-parallel data
+ * parallelism needs ONE all-reduce(sum, fp32) over the flat gradient bucket per step; the reference, nmrgnn/main.py:74-80,
+ * is single-device).  RCCL is bound at first use (dlopen of librccl.so): NG_ERR_UNSUPPORTED where it is absent.
+ *   ng_comm_unique_id   rank 0 only: 128 opaque bytes the caller hands to every rank (MPI, a file, a socket)
+ *   ng_comm_init        every rank, collectively: binds the context's GPU to a communicator of `world` ranks; world == 1
+ *                       needs no id and no RCCL.  One communicator per context.
+ *   ng_allreduce_grads  in-place sum of flat_grad[n] over the ranks on `stream`, asynchronous; identity in a world of one.
+ *                       Divide by the world size in ng_adam_step (grad_scale).
+ *   ng_comm_world       the world size of the context (1 without a communicator) */
+#define NG_COMM_ID_BYTES 128
+int ng_comm_unique_id(void* id_out);
+int ng_comm_init(ng_ctx*, int rank, int world, const void* id);
+int ng_comm_destroy(ng_ctx*);
+int ng_comm_world(ng_ctx*);
+int ng_allreduce_grads(ng_ctx*, void* stream, float* flat_grad, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,11 @@ SIGNATURES = {
     "ng_loss_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_loss_name": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "ng_adam_step": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _f]),
+    "ng_comm_unique_id": (_int, [_vp]),
+    "ng_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "ng_comm_destroy": (_int, [_vp]),
+    "ng_comm_world": (_int, [_vp]),
+    "ng_allreduce_grads": (_int, [_vp, _vp, _vp, _i64]),
 }
 
 _lib = None
@@ -116,7 +121,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 3:
+        if lib.ng_abi_version() != 4:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -191,8 +191,11 @@ extern "C" int ng_ctx_create(int device, ng_ctx** out) {
   return NG_OK;
 }
 
+extern "C" int ng_comm_destroy(ng_ctx* ctx);
+
 extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   if (!ctx) return;
+  (void)ng_comm_destroy(ctx);
   ng::DeviceGuard dg(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->aux) (void)hipFree(ctx->aux);

@@ -45,6 +45,9 @@ struct ng_ctx {
   std::map<std::pair<const void*, int>, WImage> wimg;
   // operand-range guard of the fp16-piece kernels (ng_internal.h: RangeGuard): call counter behind the epochs
   uint32_t range_epoch = 0;
+  // gradient exchange for a C-ABI caller (comm.hip): RCCL communicator of this rank, nullptr = none / world of one
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };
 
 namespace ng {

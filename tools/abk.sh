@@ -14,7 +14,7 @@ f = glob.glob('gpurun_out/abk_prof/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e6
 print(sys.argv[1], 'step %.3f ms (under rocprof)' % d['ms_per_step'], 'kernel time total %.1f ms' % tot)
-print('   ', {r['Name'].split('(')[0].split('::')[-1][:26]: round(float(r['AverageNs']) / 1e3, 1) for r in rows if float(r['AverageNs']) > 3000 and int(r['Calls']) >= 20})
+print('   ', {r['Name'].replace('(anonymous namespace)::','').split('(')[0].split('::')[-1][:26]: round(float(r['AverageNs']) / 1e3, 1) for r in rows if float(r['AverageNs']) > 3000 and int(r['Calls']) >= 20})
 PY
   done
 done

@@ -13,7 +13,7 @@ import csv, glob, json, collections
 val = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
 for f in glob.glob("gpurun_out/pmc_f256_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         val[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 res = {}
 for k, d in val.items():

@@ -20,7 +20,7 @@ for f in glob.glob("gpurun_out/pmc_mfma_*/**/*counter_collection.csv", recursive
     if rows:
         print(f, list(rows[0].keys()))
     for r in rows:
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         val[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
         if "Start_Timestamp" in r and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
