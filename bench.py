@@ -398,7 +398,9 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
-    backend = dist.get_backend() if world > 1 else None
+    # (a process group can exist in a world of one: NMRGNN_FORCE_COLLECTIVES=1 runs the gradient all-reduces through the real
+    # backend on a single-GPU box)
+    backend = dist.get_backend() if dist.is_initialized() else None
     if world > 1:
         assert dist.get_world_size() == args.gpus
         if backend != "nccl" and os.environ.get("NMRGNN_DIST_BACKEND") != backend:
@@ -439,7 +441,7 @@ def main():
     y = torch.from_numpy(b["y"]).to(dev)
     w = torch.from_numpy(b["w"]).to(dev)
     tr = Trainer(eng, lr=1e-4)
-    tr.measure_comm = world > 1
+    tr.measure_comm = world > 1 or (parallel.force_collectives() and dist.is_initialized())
 
     def step():
         return tr.step(gb, y, w, total_graphs=total_graphs)
@@ -625,7 +627,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,6 +17,10 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    return os.environ.get("NMRGNN_FORCE_COLLECTIVES") == "1"
+
+
 def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), \
         int(os.environ.get("LOCAL_RANK", "0"))
@@ -25,7 +29,9 @@ def env_world():
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment.  Returns (world, rank, local)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    # NMRGNN_FORCE_COLLECTIVES=1: build the process group and run the gradient all-reduces even in a world of one — a sum
+    # over one rank is the identity, so a single-GPU box can exercise the real RCCL path (tests/test_gpu_dist_trainer.py)
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -70,12 +76,15 @@ class GradBuckets:
     def rank(self):
         return dist.get_rank() if dist.is_initialized() else 0
 
+    def _exchanging(self):
+        return self.world() > 1 or (force_collectives() and dist.is_initialized())
+
     def launch_node(self):
-        if self.world() > 1 and self.node.numel():
+        if self._exchanging() and self.node.numel():
             self._pending.append(dist.all_reduce(self.node, op=dist.ReduceOp.SUM, async_op=True))
 
     def launch_edge(self):
-        if self.world() > 1 and self.edge.numel():
+        if self._exchanging() and self.edge.numel():
             self._pending.append(dist.all_reduce(self.edge, op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self):

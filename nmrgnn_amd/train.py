@@ -48,7 +48,7 @@ class Trainer:
             dpred.mul_(wgt)
         eng.backward(dpred, on_node_grads=self.buckets.launch_node)
         self.buckets.launch_edge()
-        if self.measure_comm and world > 1:
+        if self.measure_comm:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.buckets.wait()

@@ -47,7 +47,7 @@ if __name__ == "__main__":
     world, rank, local = parallel.init_distributed()
     dev = torch.device("cuda", 0)
     run(out_path, n_graphs, steps, world, rank, dev)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

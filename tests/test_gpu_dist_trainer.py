@@ -36,3 +36,25 @@ def test_two_rank_trainer_step_equals_the_full_batch_step(gpu_device, tmp_path, 
     g = np.abs(b["grad"]).max()
     assert np.abs(a["grad"] / 2.0 - b["grad"]).max() < 2e-4 * g
     assert abs(float(b["losses"][-1])) > 0
+
+
+def test_one_rank_trainer_step_through_rccl_is_the_plain_step(gpu_device, tmp_path):
+    """The gradient all-reduces of Trainer.step on the REAL backend ("nccl" = RCCL), in a world of one
+    (NMRGNN_FORCE_COLLECTIVES=1: the box has one GPU): async collectives on RCCL's stream launched from inside the backward,
+    waited for on the compute stream before the fused Adam.  A sum over one rank is the identity: bit-identical to the step
+    without a process group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1")
+    rccl = str(tmp_path / "rccl.npz")
+    env_r = dict(env, NMRGNN_DIST_BACKEND="nccl", NMRGNN_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29557", WORKER, rccl, "6", "3"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env_r, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    plain = str(tmp_path / "plain.npz")
+    res = subprocess.run([sys.executable, WORKER, plain, "6", "3"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    a, b = np.load(rccl), np.load(plain)
+    np.testing.assert_array_equal(a["flat"], b["flat"])
+    np.testing.assert_array_equal(a["grad"], b["grad"])
+    np.testing.assert_array_equal(a["losses"], b["losses"])
