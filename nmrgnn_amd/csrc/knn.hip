@@ -6,8 +6,8 @@
 // [TILE] position tile shared by the workgroup, the K best (distance, index) pairs live in registers
 // as a sorted list updated by a fully unrolled, branch-free insertion.  Ties keep the lower index
 // first (candidates are visited in ascending index and comparisons are strict).  At protein sizes
-// (n ~ 3-5k, 8-24 M pairs per frame) this is far below a millisecond per frame; a cell list only pays
-// beyond ~100k atoms.
+// (n ~ 3-5k, 8-24 M pairs per frame) this is far below a millisecond per frame; frames of 16384 atoms
+// and more take the cell grid of knn_cells.hip (same lists).
 //
 // Conventions (ours; nmrdata is not part of the reference tree): self excluded, ascending distance,
 // distances * scale (0.1: Angstrom -> nm), unused slots (n-1 < K) are (0, 0.0); nlist holds
@@ -15,10 +15,14 @@
 #include <string>
 
 #include "ng_common.h"
+#include "ng_internal.h"
 
 namespace ng {
 
 constexpr int KNN_TILE = 1024;
+
+// the distance expression of every kNN kernel (knn_cells.hip has the same one): identical lists need identical rounding
+__device__ __forceinline__ float knn_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
 
 template <int KMAX>
 __global__ __launch_bounds__(256) void knn_kernel(int n, int K, float scale,
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void knn_kernel(int n, int K, float scale,
     if (i < n) {
       for (int t = 0; t < cnt; ++t) {
         const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float d2 = knn_dist2(dx, dy, dz);
         const int j = t0 + t;
         if (d2 < bd[KMAX - 1] && j != i) {
 #pragma unroll
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void knn_kernel_s8(int n, int K, float scale, 
     if (i < n) {
       for (int t = sl; t < cnt; t += S) {
         const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float d2 = knn_dist2(dx, dy, dz);
         const int j = t0 + t;
         if (d2 < bd[KMAX - 1] && j != i) {
 #pragma unroll
@@ -181,6 +185,9 @@ extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, floa
   NG_REQUIRE(ctx, (int64_t)G * n < (int64_t)1 << 31, "knn: batch exceeds int32 indices");
   NG_REQUIRE(ctx, G <= 65535, "knn: at most 65535 frames per call");
   if (G == 0 || n == 0) return NG_OK;
+  // large frames: cell grid (knn_cells.hip), the same lists in O(n) instead of O(n^2); NG_KNN=cells / brute force the choice
+  if (!sw().knn_brute && !sw().knn_serial && knn_cells_supported(G, n, K) && (n >= 16384 || sw().knn_cells))
+    return knn_cells(ctx, st, G, n, K, scale, pos, nlist, edges, inv_degree);
   ProfScope ps(ctx, st, "knn_graph");
   const dim3 grid((unsigned)cdiv(n, 256), (unsigned)G), block(256);
   if (K <= 16 && !sw().knn_serial)      // NG_KNN=serial: one lane per query (the first kernel)

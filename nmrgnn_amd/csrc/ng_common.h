@@ -63,10 +63,11 @@ namespace ng {
 //   NG_DENSE_PATH=generic  no register-resident tall-skinny kernels
 //   NG_HEAD_PATH=generic   the first head / embedding-gradient kernels
 //   NG_KNN=serial          one lane per query atom in the kNN graph kernel
+//   NG_KNN=cells / brute   the cell-grid neighbour search for every frame size / for none (default: frames >= 16384 atoms)
 struct Switches {
   bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
   bool edge_layered = false, mp_layered = false, fc_layered = false;
-  bool dense_generic = false, head_generic = false, knn_serial = false;
+  bool dense_generic = false, head_generic = false, knn_serial = false, knn_cells = false, knn_brute = false;
   bool gemm_4wave = false;      // NG_GEMM_TILE=4wave: the un-pipelined 4-wave split-operand GEMM (A/B measurements)
 };
 const Switches& sw();

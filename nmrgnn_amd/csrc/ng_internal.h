@@ -127,6 +127,11 @@ int tall_tn(ng_ctx* ctx, hipStream_t st, int64_t N, const float* A, int lda, int
             int ldb, int kb_valid, const float* S_in, int act_in, float* dW, float* db, int w_map, int F,
             int E, float* scratch, const char* tag);
 
+// K nearest neighbours through a cell grid, for large frames (knn_cells.hip); the same lists as the brute-force kernels
+bool knn_cells_supported(int G, int n, int K);
+int knn_cells(ng_ctx* ctx, hipStream_t st, int G, int n, int K, float scale, const float* pos, int32_t* nlist, float* edges,
+              float* inv_degree);
+
 // window-resident fused MPLayer kernels (mp_win.hip): atom_feature_size == 64, edge_feature_size <= 3
 bool mp_win_supported(int F, int E, int K);
 bool mp_win_enabled(int F, int E, int K);
