@@ -28,7 +28,6 @@ static void load_switches() {
   s.knn_serial = env_is("NG_KNN", "serial");
   s.knn_cells = env_is("NG_KNN", "cells");
   s.knn_brute = env_is("NG_KNN", "brute");
-  s.gemm_4wave = env_is("NG_GEMM_TILE", "4wave");
   g_sw = s;
   g_sw_loaded = true;
 }

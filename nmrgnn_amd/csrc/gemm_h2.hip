@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_short_kernel(GxArgs a) {
 }
 
 // the short kernel: N % 256 (its column tiling), K % 128 (its k-tiles)
-static bool gx_short_ok(int K, int N) { return N % 256 == 0 && K % 128 == 0 && !sw().gemm_4wave; }
+static bool gx_short_ok(int K, int N) { return N % 256 == 0 && K % 128 == 0; }
 
 bool gemm_h2_fwd_ok(int64_t M, int K, int N) {
   if (sw().gemm_math_fp32) return false;
@@ -647,12 +647,9 @@ static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int
     const dim3 grid1((unsigned)cdiv(a.M, 32), (unsigned)(a.N / 256));
     if (grad) hipLaunchKernelGGL((gemm_h2_short_kernel<true>), grid1, dim3(256), GS_LDS, st, a);
     else hipLaunchKernelGGL((gemm_h2_short_kernel<false>), grid1, dim3(256), GS_LDS, st, a);
-  } else if (nbw == 4 && !sw().gemm_4wave) {
+  } else if (nbw == 4) {
     if (grad) hipLaunchKernelGGL((gemm_h2_fwdr_kernel<true>), grid, dim3(256), G4_LDS, st, a);
     else hipLaunchKernelGGL((gemm_h2_fwdr_kernel<false>), grid, dim3(256), G4_LDS, st, a);
-  } else if (nbw == 4) {
-    if (grad) hipLaunchKernelGGL((gemm_h2_fwd_kernel<true, 4>), grid, dim3(256), gx_lds(4), st, a);
-    else hipLaunchKernelGGL((gemm_h2_fwd_kernel<false, 4>), grid, dim3(256), gx_lds(4), st, a);
   } else {
     if (grad) hipLaunchKernelGGL((gemm_h2_fwd_kernel<true, 2>), grid, dim3(256), gx_lds(2), st, a);
     else hipLaunchKernelGGL((gemm_h2_fwd_kernel<false, 2>), grid, dim3(256), gx_lds(2), st, a);
@@ -987,7 +984,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_dw8_kernel(GtArgs a) {
 }
 
 bool gemm_h2_dw8_ok(int64_t M, int Kin, int Nout) {
-  return !sw().gemm_math_fp32 && !sw().gemm_4wave && Kin % 256 == 0 && Nout % 256 == 0 && M >= 4096;
+  return !sw().gemm_math_fp32 && Kin % 256 == 0 && Nout % 256 == 0 && M >= 4096;
 }
 
 bool gemm_h2_dw_ok(int64_t M, int Kin, int Nout) {

@@ -68,7 +68,6 @@ struct Switches {
   bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false, knn_cells = false, knn_brute = false;
-  bool gemm_4wave = false;      // NG_GEMM_TILE=4wave: the un-pipelined 4-wave split-operand GEMM (A/B measurements)
 };
 const Switches& sw();
 
