@@ -33,8 +33,14 @@ constexpr int FF_WCHUNK = 2 * 4 * 2 * 2 * 1024; // gx_wchunk(4): [n-block 8][k-s
 constexpr float FF_WSCALE = 256.0f, FF_WINV = 1.0f / 256.0f;
 constexpr int FF_GLD = FFW / 2 + 4;            // row stride (floats) of the g tile [32][128]
 constexpr int FF_MAXC = 16;
+#ifndef FF_MAX_TILES
+#define FF_MAX_TILES 512          // batches up to 16384 atoms (above: the per-layer GEMMs have enough rows to fill the chip)
+#endif
 #ifndef FF_RING
 #define FF_RING 16
+#endif
+#ifndef FF_NO_SPLIT
+#define FF_NO_SPLIT 0
 #endif
 #ifndef FF_NB
 #define FF_NB 8
@@ -75,29 +81,29 @@ struct FcHeadArgs {
   float* peaks;              // [N]
 };
 
-// acc[j] += X[32 rows][K] (pieces in LDS planes) x W-image columns 64 nq + 32 j + ..;  K = 32 KT
-template <int KT, int XROW = FF_XROW>
-__device__ __forceinline__ void ff_gemm(f32x16 (&acc)[2], const char* __restrict__ sX, const char* __restrict__ img, int nq,
-                                        int lane) {
+// acc[j] += X[32 rows][K] (pieces in LDS planes) x W-image column block cb0 + j (32 columns each), j < NJ;  K = 32 KT
+template <int KT, int XROW, int NJ>
+__device__ __forceinline__ void ff_gemm_n(f32x16 (&acc)[NJ], const char* __restrict__ sX, const char* __restrict__ img, int cb0,
+                                          int lane) {
   constexpr int XPLANE = FF_ROWS * XROW;
   const int half = lane >> 5, l31 = lane & 31;
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (unsigned)(KT * FF_WCHUNK), 0x00020000);
-  auto w_request = [&](u32x4 (&wa)[2][2], int q) {       // k-half q = (32-wide step q >> 1, half q & 1)
+  auto w_request = [&](u32x4 (&wa)[NJ][2], int q) {       // k-half q = (32-wide step q >> 1, half q & 1)
     const int qc = q;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const auto raw = __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, lane * 16, (qc >> 1) * FF_WCHUNK + (((2 * nq + j) * 2 + (qc & 1)) * 2 + p) * 1024, 0);
+            wrs, lane * 16, (qc >> 1) * FF_WCHUNK + (((cb0 + j) * 2 + (qc & 1)) * 2 + p) * 1024, 0);
         wa[j][p] = __builtin_bit_cast(u32x4, raw);
       }
   };
   // One wave per SIMD and one workgroup per CU: nothing covers the L2 round trip of a fragment (~0.6-1 us = 3-5 k-halves
   // of MFMAs) but the wave's own requests in flight.  The kernel has 512 registers per lane to itself, so the ring is
   // FF_RING k-halves deep (64 registers per 4): with 16, a 256-deep contraction has every fragment requested up front.
-  u32x4 w[FF_RING][2][2];
+  u32x4 w[FF_RING][NJ][2];
 #pragma unroll
   for (int q = 0; q < FF_RING - 1; ++q) w_request(w[q], q);
 #pragma unroll
@@ -107,9 +113,17 @@ __device__ __forceinline__ void ff_gemm(f32x16 (&acc)[2], const char* __restrict
 #pragma unroll
     for (int p = 0; p < 2; ++p)
       xb[p] = *reinterpret_cast<const u32x4*>(sX + p * XPLANE + l31 * XROW + (16 * q + 8 * half) * 2);
-    mma3_2a(w[q % FF_RING][0], w[q % FF_RING][1], xb, acc[0], acc[1]);
+    if (NJ == 2) mma3_2a(w[q % FF_RING][0], w[q % FF_RING][NJ - 1], xb, acc[0], acc[NJ - 1]);
+    else acc[0] = mma3(w[q % FF_RING][0], xb, acc[0]);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// the 64 columns 64 nq .. of a wave (two blocks): the form the FC chain uses
+template <int KT, int XROW = FF_XROW>
+__device__ __forceinline__ void ff_gemm(f32x16 (&acc)[2], const char* __restrict__ sX, const char* __restrict__ img, int nq,
+                                        int lane) {
+  ff_gemm_n<KT, XROW, 2>(acc, sX, img, 2 * nq, lane);
 }
 
 // this lane's 32 values (row l31; columns 64 nq + 32 j + 8 q + 4 half + r in v[j][4 q + r]) -> the X piece planes
@@ -329,8 +343,12 @@ __global__ void ff_pack_mp_kernel(int E, const float* __restrict__ w, unsigned* 
   for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
 }
 
-template <int E, bool CSR>
+// NS = 2: TWO workgroups per 32-atom tile (blockIdx.y), each with 128 of the 256 output columns — wave nq owns ONE block of 32
+// columns.  Both gather the tile's aggregate (the gather is a chain of L2 round trips, not bandwidth), each streams half of
+// the weight image: for a single molecule (2770 atoms = 87 tiles on 256 CUs) the image stream per workgroup set the pace.
+template <int E, bool CSR, int NS>
 __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
+  constexpr int NJ = 2 / NS;                     // 32-column blocks per wave
   constexpr int KF = E * FFW, XROW = KF * 2 + 16, XPLANE = FF_ROWS * XROW;
   extern __shared__ __attribute__((aligned(16))) char smem_mp[];
   char* sX = smem_mp;                                                    // [2][32][XROW]
@@ -340,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
   float* s_e = reinterpret_cast<float*>(s_nl + FF_ROWS * a.K);           // [32][K][E]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int nq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb0 = NS == 1 ? 2 * nq : 4 * (int)blockIdx.y + nq;      // first 32-column block of this wave
   const int K = a.K;
   const int64_t m0 = (int64_t)blockIdx.x * FF_ROWS;
   const int n_at = (int)std::min<int64_t>(FF_ROWS, a.N - m0);
@@ -351,12 +370,12 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
     for (int t = tid; t < FF_ROWS * K * E; t += 256) s_e[t] = t < n_at * K * E ? a.e[m0 * K * E + t] : 0.f;
   }
   // this lane's slice of its own row in the accumulator layout: the residual term (requested early)
-  float xr[2][16];
+  float xr[NJ][16];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(a.h + m * FFW + 64 * nq + 32 * j + 8 * q + 4 * half);
+      const float4 v = *reinterpret_cast<const float4*>(a.h + m * FFW + 32 * (cb0 + j) + 8 * q + 4 * half);
       xr[j][4 * q + 0] = v.x; xr[j][4 * q + 1] = v.y; xr[j][4 * q + 2] = v.z; xr[j][4 * q + 3] = v.w;
     }
   const float rs = a.inv_degree[m];
@@ -428,20 +447,20 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
   }
   NG_LDS_BARRIER();
 
-  f32x16 acc[2];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #ifndef FF_SKIP_GEMM
-  ff_gemm<KF / 32, XROW>(acc, sX, a.img, nq, lane);
+  ff_gemm_n<KF / 32, XROW, NJ>(acc, sX, a.img, cb0, lane);
 #endif
 
   // ---- range repair (file header): rows with non-finite accumulators, recomputed by the whole workgroup in fp32
   {
     float chk = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int t = 0; t < 16; ++t) chk += fabsf(acc[j][t]);
     if (tid == 0) *sMask = 0u;
@@ -471,9 +490,9 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
         __syncthreads();
         if (l31 == r) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[j][t] = sY[64 * nq + 32 * j + 8 * (t >> 2) + 4 * half + (t & 3)] * FF_WSCALE;
+            for (int t = 0; t < 16; ++t) acc[j][t] = sY[32 * (cb0 + j) + 8 * (t >> 2) + 4 * half + (t & 3)] * FF_WSCALE;
         }
         __syncthreads();
       }
@@ -484,26 +503,26 @@ __global__ __launch_bounds__(256, 1) void mp_layer_short_kernel(MpShortArgs a) {
   if (m0 + l31 < a.N) {
     const float sc = rs * FF_WINV;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 y;
         y.x = act_apply(a.act, acc[j][4 * q + 0] * sc); y.y = act_apply(a.act, acc[j][4 * q + 1] * sc);
         y.z = act_apply(a.act, acc[j][4 * q + 2] * sc); y.w = act_apply(a.act, acc[j][4 * q + 3] * sc);
         if (a.residual) { y.x += xr[j][4 * q + 0]; y.y += xr[j][4 * q + 1]; y.z += xr[j][4 * q + 2]; y.w += xr[j][4 * q + 3]; }
-        *reinterpret_cast<float4*>(a.h_out + m * FFW + 64 * nq + 32 * j + 8 * q + 4 * half) = y;
+        *reinterpret_cast<float4*>(a.h_out + m * FFW + 32 * (cb0 + j) + 8 * q + 4 * half) = y;
       }
   }
 }
 
 bool mp_layer_short_supported(int64_t N, int K, int F, int E) {
   if (sw().mp_layered || sw().gemm_math_fp32) return false;       // the any-shape / strict-fp32 paths were asked for
-  return F == FFW && E >= 1 && E <= 3 && K >= 1 && K <= 32 && N > 0 && N <= (int64_t)FF_ROWS * 512;
+  return F == FFW && E >= 1 && E <= 3 && K >= 1 && K <= 32 && N > 0 && N <= (int64_t)FF_ROWS * FF_MAX_TILES;
 }
 
 bool fc_head_short_supported(int64_t N, int F, int L, int C, int act) {
   if (sw().fc_layered || sw().gemm_math_fp32 || sw().head_generic) return false;
-  return F == FFW && L == 4 && C <= FF_MAXC && act == NG_ACT_SOFTPLUS && N > 0 && N <= (int64_t)FF_ROWS * 512;
+  return F == FFW && L == 4 && C <= FF_MAXC && act == NG_ACT_SOFTPLUS && N > 0 && N <= (int64_t)FF_ROWS * FF_MAX_TILES;
 }
 
 }  // namespace ng
@@ -567,15 +586,19 @@ static int mp_layer_short_launch(ng_ctx* ctx, void* stream, int64_t N, int K, in
   a.img = img; a.w = w; a.h_out = h_out;
   const size_t lds = (size_t)2 * FF_ROWS * (KF * 2 + 16) + (size_t)(KF + FFW + 4) * 4 + (row_ptr ? 0 : (size_t)FF_ROWS * K * (1 + E) * 4);
   ProfScope ps(ctx, st, "mp_layer_short");
-  const dim3 grid((unsigned)cdiv(N, FF_ROWS));
+  // two workgroups per tile (128 output columns each) while that still fits the chip in one round
+  const int64_t tiles = cdiv(N, FF_ROWS);
+  const bool split = 2 * tiles <= ctx->num_cu && !FF_NO_SPLIT;
+  const dim3 grid((unsigned)tiles, split ? 2u : 1u);
+#define NG_MPS(EE, CC)                                                                                               \
+  if (split) hipLaunchKernelGGL((mp_layer_short_kernel<EE, CC, 2>), grid, dim3(256), lds, st, a);                     \
+  else hipLaunchKernelGGL((mp_layer_short_kernel<EE, CC, 1>), grid, dim3(256), lds, st, a);
   switch (E) {
-    case 1: if (row_ptr) hipLaunchKernelGGL((mp_layer_short_kernel<1, true>), grid, dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((mp_layer_short_kernel<1, false>), grid, dim3(256), lds, st, a); break;
-    case 2: if (row_ptr) hipLaunchKernelGGL((mp_layer_short_kernel<2, true>), grid, dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((mp_layer_short_kernel<2, false>), grid, dim3(256), lds, st, a); break;
-    default: if (row_ptr) hipLaunchKernelGGL((mp_layer_short_kernel<3, true>), grid, dim3(256), lds, st, a);
-             else hipLaunchKernelGGL((mp_layer_short_kernel<3, false>), grid, dim3(256), lds, st, a); break;
+    case 1: if (row_ptr) { NG_MPS(1, true) } else { NG_MPS(1, false) } break;
+    case 2: if (row_ptr) { NG_MPS(2, true) } else { NG_MPS(2, false) } break;
+    default: if (row_ptr) { NG_MPS(3, true) } else { NG_MPS(3, false) } break;
   }
+#undef NG_MPS
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
