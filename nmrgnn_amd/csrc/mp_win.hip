@@ -542,7 +542,15 @@ struct MpWinFwdArgs {
   RangeGuard guard;        // word == nullptr: unguarded (NG_GEMM_MATH=fp32)
   const unsigned* wflag;   // flag word of a weight image kept over calls (weights out of the piece range), or nullptr
   const float* Wfrag32;    // fp32 fragments (mpw_pack mode 0) a guarded call switches to when its weights leave the range
+#ifdef MPW_STAMP
+  unsigned long long* stamps;
+#endif
 };
+#ifdef MPW_STAMP
+#define MPW_T(k) do { if (a.stamps && blockIdx.x == 3 && lane == 0 && t - T0 >= 2 && t - T0 < 6) a.stamps[((t - T0 - 2) * 8 + wave) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MPW_T(k) do {} while (0)
+#endif
 
 template <int E, bool K4, bool H2>
 __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
@@ -618,12 +626,14 @@ __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
     const int64_t row = t * WTA + 16 * hh + a16;          // this lane's atom in the matrix phase
     const bool live = row < a.N;
     const int64_t rowc = live ? row : a.N - 1;
+    MPW_T(0);
     if (t + 1 < T1)
       lists.commit(s_nl + ((t + 1) & 1) * per_tile, s_e + ((t + 1) & 1) * per_tile * E,
                    ctl + ((t + 1) & 1) * 16, K, tid, wave, lane);
     lists.issue(a.nlist, a.e, t + 2 < T1 ? t + 2 : t, K, a.N, tid);
     const float rs = a.rowscale[rowc];
     const float4 re = *reinterpret_cast<const float4*>(a.h + rowc * WF + col);
+    MPW_T(1);
     {
       const int32_t* nl = s_nl + (t & 1) * per_tile;
       const float* ee = s_e + (t & 1) * per_tile * E;
@@ -631,7 +641,9 @@ __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
       else if (mode == 0) win_gather<E, K4, 0, H2>(K, wave, lane, wlo, nl, ee, tile, win4, src4, s_rs);
       else win_gather_global<E, K4, H2>(K, wave, lane, nl, ee, tile, src4, s_rs);
     }
+    MPW_T(2);
     NG_LDS_BARRIER();
+    MPW_T(3);
     // ---- phase 2: tile x weights on the matrix cores, epilogue
     {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -677,6 +689,7 @@ __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      MPW_T(4);
       float4 v = make_float4((acc0[0] + acc1[0]) * rsx, (acc0[1] + acc1[1]) * rsx, (acc0[2] + acc1[2]) * rsx,
                              (acc0[3] + acc1[3]) * rsx);
       if (a.act == NG_ACT_SOFTPLUS) {
@@ -694,9 +707,11 @@ __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
       if (a.S_save) *reinterpret_cast<float4*>(live ? a.S_save + o : a.dummy + col) = v;
       *reinterpret_cast<float4*>(live ? a.out + o : a.dummy + col) = vo;
     }
+    MPW_T(5);
     bool restage = false;
     if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * 16, wlo, mode);
     NG_LDS_BARRIER();
+    MPW_T(6);
     if (restage) {                       // uniform over the workgroup
       win_stage(win4, src4, wlo, a.N, tid);
       NG_LDS_BARRIER();
@@ -1203,6 +1218,12 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
     case 3: { CALL(3, HH) } break;                                                                        \
   }
   a.Wfrag32 = Wf32;
+#ifdef MPW_STAMP
+  static unsigned long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { (void)hipMalloc(&dbg, 4 * 8 * 8 * 8); (void)hipMemset(dbg, 0, 4 * 8 * 8 * 8); }
+  a.stamps = dbg;
+#endif
   {
     ProfScope ps(ctx, st, "mp_win_fwd");
     if (h2) { CALLE(true) } else { CALLE(false) }
@@ -1210,6 +1231,20 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   }
 #undef CALLE
 #undef CALL
+#ifdef MPW_STAMP
+  if (++calls == 40) {
+    unsigned long long h[4 * 8 * 8];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    for (int tt = 0; tt < 4; ++tt)
+      for (int w = 0; w < 8; w += 1) {
+        const unsigned long long* p = h + (tt * 8 + w) * 8;
+        fprintf(stderr, "MPW tile %d wave %d: commit/issue %5lld  gather %5lld  barrier %5lld  mfma %5lld  epilogue %5lld  end-barrier %5lld | total %6lld\n",
+                tt, w, (long long)(p[1] - p[0]), (long long)(p[2] - p[1]), (long long)(p[3] - p[2]), (long long)(p[4] - p[3]),
+                (long long)(p[5] - p[4]), (long long)(p[6] - p[5]), (long long)(p[6] - p[0]));
+      }
+  }
+#endif
   return NG_OK;
 }
 
