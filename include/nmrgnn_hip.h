@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 4
+#define NG_ABI_VERSION 5
 
 enum {
   NG_OK = 0,
@@ -59,6 +59,15 @@ int ng_reload_env(void);
  * cached, so backward entry points may run inside a frozen window. */
 int ng_weights_frozen(ng_ctx* ctx, int owner);
 int ng_weights_changed(ng_ctx* ctx);
+/* Deferred weight-gradient sums (ABI 5).  The backward entry points end in a second-stage reduction of per-workgroup
+ * partials into the gradient tensor (deterministic, fixed order): seven launches of 5-12 us in a training step's
+ * backward (head, FC block, four MPLayers, embedding; nmrgnn/model.py:262-273 differentiated).  Between
+ * ng_defer_reductions(ctx, stream, 1) and the matching ng_defer_reductions(ctx, stream, 0) the entry points keep their
+ * partials in a context-owned arena and only QUEUE the reduction; ng_flush_reductions(ctx, stream) runs everything
+ * queued so far in one launch on `stream` (switching deferral off flushes too).  A gradient tensor is defined only
+ * after the flush that follows its entry point; the bits are those of the eager form.  Off by default. */
+int ng_defer_reductions(ng_ctx* ctx, void* stream, int on);
+int ng_flush_reductions(ng_ctx* ctx, void* stream);
 /* Hint about the batch the following calls work on: the largest number of atoms of one member graph (the reference
  * concatenates molecules with offset neighbour indices, nmrgnn/library.py:106-117, so a neighbour index lies within its
  * own graph).  0 = unknown (default).  With 0 < span <= 272 the default-width neighbour aggregation (F % 128 == 0) keeps

@@ -34,6 +34,8 @@ SIGNATURES = {
     "ng_reload_env": (_int, []),
     "ng_weights_frozen": (_int, [_vp, _int]),
     "ng_weights_changed": (_int, [_vp]),
+    "ng_defer_reductions": (_int, [_vp, _vp, _int]),
+    "ng_flush_reductions": (_int, [_vp, _vp]),
     "ng_ctx_set_graph_span": (_int, [_vp, _i64]),
     "ng_prof_enable": (_int, [_vp, _int]),
     "ng_prof_reset": (_int, [_vp]),
@@ -121,7 +123,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 4:
+        if lib.ng_abi_version() != 5:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -1,9 +1,12 @@
 // Context, error reporting, scratch workspace and per-kernel hipEvent profiling.
+#include <algorithm>
 #include <cstring>
 #include <map>
+#include <new>
 
 #include "ng_common.h"
 #include "ng_internal.h"
+#include "reduce.cuh"
 
 namespace ng {
 
@@ -127,6 +130,137 @@ void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* v
   return w.buf;
 }
 
+// ---- deferred second-stage reductions (reduce.cuh) ------------------------------------------------------------------
+constexpr int RB_MAX_JOBS = 24;
+struct ReduceBatch {
+  int njobs;
+  unsigned block0[RB_MAX_JOBS + 1];      // first block of job j; block0[njobs] = grid
+  ReduceJob job[RB_MAX_JOBS];
+};
+
+// The job of a block is picked with compile-time indices (scalar selects over the kernel arguments): a run-time index
+// into the argument struct made the compiler copy the struct to scratch per thread — 0.45 ms for seven jobs.
+static __global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch b) {
+  __shared__ float red[16][64];
+  ReduceJob job = b.job[0];
+  unsigned b0 = 0;
+#pragma unroll
+  for (int k = 1; k < RB_MAX_JOBS; ++k)
+    if (k < b.njobs && blockIdx.x >= b.block0[k]) { job = b.job[k]; b0 = b.block0[k]; }
+  reduce_job_block(job, nullptr, blockIdx.x - b0, red);
+}
+
+struct ReduceQueue {
+  ReduceBatch batch{};
+  // partial arena: chunks live until the flush; more than one chunk = the arena was too small this round, the flush
+  // replaces them by one chunk of the total size
+  struct Chunk { char* p; size_t bytes, used; };
+  std::vector<Chunk> chunks;
+};
+
+static ReduceQueue* rqueue(ng_ctx* ctx) {
+  if (!ctx->rq) ctx->rq = new (std::nothrow) ReduceQueue();
+  return (ReduceQueue*)ctx->rq;
+}
+
+float* deferred_partials(ng_ctx* ctx, size_t floats) {
+  if (!ctx->defer_reduce) return nullptr;
+  ReduceQueue* q = rqueue(ctx);
+  if (!q) return nullptr;
+  const size_t bytes = (floats * 4 + 255) / 256 * 256;
+  if (!q->chunks.empty()) {
+    ReduceQueue::Chunk& c = q->chunks.back();
+    if (c.used + bytes <= c.bytes) { char* r = c.p + c.used; c.used += bytes; return (float*)r; }
+  }
+  DeviceGuard dg(ctx->device);
+  const size_t want = std::max(bytes * 2, (size_t)32 << 20);
+  void* p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) return nullptr;      // the caller falls back to its own scratch + eager reduction
+  q->chunks.push_back({(char*)p, want, bytes});
+  return (float*)p;
+}
+
+static bool in_arena(ng_ctx* ctx, const float* p) {
+  ReduceQueue* q = (ReduceQueue*)ctx->rq;
+  if (!q) return false;
+  for (auto& c : q->chunks)
+    if ((const char*)p >= c.p && (const char*)p < c.p + c.bytes) return true;
+  return false;
+}
+
+static int run_queue(ng_ctx* ctx, hipStream_t st, ReduceQueue* q);
+
+int flush_reductions(ng_ctx* ctx, hipStream_t st) {
+  ReduceQueue* q = (ReduceQueue*)ctx->rq;
+  if (!q) return NG_OK;
+  {
+    const int rc = run_queue(ctx, st, q);
+    if (rc) return rc;
+  }
+  if (q->chunks.size() > 1) {
+    DeviceGuard dg(ctx->device);
+    size_t total = 0;
+    (void)hipDeviceSynchronize();
+    for (auto& c : q->chunks) { total += c.bytes; (void)hipFree(c.p); }
+    q->chunks.clear();
+    void* p = nullptr;
+    if (hipMalloc(&p, total) == hipSuccess) q->chunks.push_back({(char*)p, total, 0});
+  } else if (!q->chunks.empty()) {
+    q->chunks[0].used = 0;
+  }
+  return NG_OK;
+}
+
+static int run_queue(ng_ctx* ctx, hipStream_t st, ReduceQueue* q) {
+  if (q->batch.njobs == 0) return NG_OK;
+  ProfScope ps(ctx, st, "reduce_partials");
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3(q->batch.block0[q->batch.njobs]), dim3(1024), 0, st, q->batch);
+  NG_HIP(ctx, hipGetLastError());
+  q->batch.njobs = 0;
+  return NG_OK;
+}
+
+static int queue_job(ng_ctx* ctx, hipStream_t st, const ReduceJob& j) {
+  ReduceQueue* q = rqueue(ctx);
+  if (q->batch.njobs == RB_MAX_JOBS) {
+    // queue full: run what is queued (the arena keeps its contents: only the job list is emptied here)
+    const int rc = run_queue(ctx, st, q);
+    if (rc) return rc;
+  }
+  ReduceBatch& b = q->batch;
+  const int k = b.njobs++;
+  if (k == 0) b.block0[0] = 0;
+  b.job[k] = j;
+  b.block0[k + 1] = b.block0[k] + (unsigned)cdiv(j.n_elem, 64);
+  return NG_OK;
+}
+
+int reduce_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out, int w_map, int F,
+                    int E, int Nout, int64_t z_stride) {
+  if (ctx->defer_reduce && in_arena(ctx, partial))
+    return queue_job(ctx, st, ReduceJob{partial, out, n_elem, z_stride ? z_stride : n_elem, nz, w_map, F, E, Nout});
+  launch_reduce_z(st, partial, nz, n_elem, out, w_map, F, E, Nout, z_stride);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+int reduce_seg_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, int64_t z_stride,
+                        const ReduceSegs& sg) {
+  if (ctx->defer_reduce && in_arena(ctx, partial)) {
+    // a segment is a plain job of its own on the segment's slice of the partial rows (an element's sum does not
+    // depend on which block holds it: the bits are those of reduce_z_seg_kernel)
+    (void)n_elem;
+    for (int k = 0; k < sg.n; ++k) {
+      const int rc = queue_job(ctx, st, ReduceJob{partial + sg.begin[k], sg.dst[k], (int64_t)sg.len[k], z_stride, nz, 0, 0, 0, 1});
+      if (rc) return rc;
+    }
+    return NG_OK;
+  }
+  launch_reduce_z_seg(st, partial, nz, n_elem, z_stride, sg);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 ProfScope::ProfScope(ng_ctx* c, hipStream_t s, const char* name) : ctx(c), stream(s) {
   if (!ctx || !ctx->prof) return;
   hipEvent_t a = nullptr, b = nullptr;
@@ -171,6 +305,21 @@ extern "C" int ng_weights_changed(ng_ctx* ctx) {
   return NG_OK;
 }
 
+extern "C" int ng_defer_reductions(ng_ctx* ctx, void* stream, int on) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (!on && ctx->defer_reduce) {
+    const int rc = ng::flush_reductions(ctx, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  ctx->defer_reduce = on != 0;
+  return NG_OK;
+}
+
+extern "C" int ng_flush_reductions(ng_ctx* ctx, void* stream) {
+  if (!ctx) return NG_ERR_INVALID;
+  return ng::flush_reductions(ctx, (hipStream_t)stream);
+}
+
 extern "C" int ng_reload_env(void) {
   ng::load_switches();
   return NG_OK;
@@ -208,6 +357,11 @@ extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
     (void)hipEventDestroy(r.stop);
   }
   for (auto e : ctx->pool) (void)hipEventDestroy(e);
+  if (ctx->rq) {
+    ng::ReduceQueue* q = (ng::ReduceQueue*)ctx->rq;
+    for (auto& c : q->chunks) (void)hipFree(c.p);
+    delete q;
+  }
   delete ctx;
 }
 

@@ -500,6 +500,7 @@ int fc_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const f
   float* dummy = ws + (size_t)2 * L * FC_F * FC_F;
   float* partial = ws + fc_fused_pack_floats(L);
   float* summed = partial + (size_t)grid * part;
+  if (float* dp = deferred_partials(ctx, (size_t)grid * part)) partial = dp;
   int rc = fc_fused_pack(ctx, st, L, W, Wf, Wb);
   if (rc) return rc;
   FcBwdArgs a{};
@@ -526,10 +527,8 @@ int fc_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const f
     sg.begin[l] = l * FC_F * FC_F; sg.len[l] = FC_F * nout; sg.dst[l] = dW[l];
     sg.begin[L + l] = L * FC_F * FC_F + l * FC_F; sg.len[L + l] = nout; sg.dst[L + l] = db[l];
   }
-  launch_reduce_z_seg(st, partial, grid, fc_part_floats(L), part, sg);
-  NG_HIP(ctx, hipGetLastError());
   (void)summed;
-  return NG_OK;
+  return reduce_seg_or_defer(ctx, st, partial, grid, fc_part_floats(L), part, sg);
 }
 
 }  // namespace ng

@@ -220,6 +220,7 @@ int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   if (!ws) return NG_ERR_NOMEM;
   float* partial = ws;
   float* summed = ws + (size_t)nb * items;
+  if (float* dp = deferred_partials(ctx, (size_t)nb * items)) partial = dp;
   const size_t lds = (size_t)rl * items * 4;
   ProfScope ps(ctx, st, "head_bwd");
 #define NG_HB(L, CM)                                                                                      \
@@ -233,10 +234,9 @@ int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   sg.n = 2;
   sg.begin[0] = 0; sg.len[0] = Fh * C; sg.dst[0] = dWout;
   sg.begin[1] = Fh * C; sg.len[1] = C; sg.dst[1] = dbout;
-  launch_reduce_z_seg(st, partial, nb, items, items, sg);
   (void)summed;
   NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  return reduce_seg_or_defer(ctx, st, partial, nb, items, items, sg);
 }
 
 bool embed_bwd_fast_supported(int F, int C) {
@@ -252,7 +252,8 @@ int embed_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int C, int F, const f
   const int grid = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 2);
   const int64_t rows = cdiv(cdiv(N, grid), rl) * rl;
   const int nb = (int)cdiv(N, rows);
-  float* partial = (float*)workspace(ctx, (size_t)nb * items * 4);
+  float* partial = deferred_partials(ctx, (size_t)nb * items);
+  if (!partial) partial = (float*)workspace(ctx, (size_t)nb * items * 4);
   if (!partial) return NG_ERR_NOMEM;
   const size_t lds = (size_t)rl * items * 4;
   ProfScope ps(ctx, st, "embed_bwd");
@@ -260,9 +261,8 @@ int embed_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int C, int F, const f
     hipLaunchKernelGGL((embed_bwd_fast_kernel<16>), dim3(nb), dim3(256), lds, st, N, C, F, rows, atoms, dh0, partial);
   else
     hipLaunchKernelGGL((embed_bwd_fast_kernel<32>), dim3(nb), dim3(256), lds, st, N, C, F, rows, atoms, dh0, partial);
-  launch_reduce_z(st, partial, nb, items, dWemb);
   NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  return reduce_or_defer(ctx, st, partial, nb, items, dWemb);
 }
 
 }  // namespace ng

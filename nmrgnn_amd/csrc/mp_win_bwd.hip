@@ -889,9 +889,7 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
 #undef NODE
   ProfScope ps(ctx, st, "reduce_partials");
   // partial idx = (n*64 + m)*64 + l  ->  dw[(l*64 + m)*E + n]
-  launch_reduce_z(st, scratch, grid, (int64_t)E * WF * WF, dw, 2, WF, E, WF, (int64_t)E * WF * WF);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  return reduce_or_defer(ctx, st, scratch, grid, (int64_t)E * WF * WF, dw, 2, WF, E, WF, (int64_t)E * WF * WF);
 }
 
 bool mp_win_bwd_supported(int F, int E, int K) {
@@ -961,6 +959,8 @@ int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, co
   float* rec = dP + N * WF;
   float* scr = rec + rec_floats;
   float* dummy = scr + dw_scr;
+  // deferred reductions (reduce.cuh): the dw partials of this layer stay in the reduction arena until the flush
+  if (float* dscr = deferred_partials(ctx, dw_scr)) scr = dscr;
   int rc = h2 ? mpw_pack_bwd_h2(ctx, st, E, w, WfragT, WfragN, guarded ? WfragT32 : nullptr, guarded ? WfragN32 : nullptr, guard)
               : mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // all weight images in one launch
   if (rc) return rc;

@@ -48,6 +48,9 @@ struct ng_ctx {
   // gradient exchange for a C-ABI caller (comm.hip): RCCL communicator of this rank, nullptr = none / world of one
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
+  // deferred second-stage reductions (ng_defer_reductions; reduce.cuh): queue + partial arena, owned by capi.hip
+  bool defer_reduce = false;
+  void* rq = nullptr;
 };
 
 namespace ng {

@@ -21,43 +21,7 @@ __device__ __forceinline__ void block_max_store(float m, float* __restrict__ blo
 // 16 waves split z, so every lane has nz/16 independent, fully coalesced loads in flight (the
 // one-thread-per-element form was latency-bound: 60-120 us for a 12K-element gradient).
 //   w_map = 0: identity;  w_map = 1: MPLayer weight, idx = k*Nout + m with k = ne*F + l -> (l*F+m)*E+ne
-static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __restrict__ partial, int nz,
-                                                        int64_t n_elem, float* __restrict__ out,
-                                                        int w_map, int F, int E, int Nout,
-                                                        int64_t z_stride) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (idx < n_elem)
-    for (int z = w; z < nz; z += 16) s += partial[(int64_t)z * z_stride + idx];
-  red[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && idx < n_elem) {
-    float t = red[0][lane];
-#pragma unroll
-    for (int j = 1; j < 16; ++j) t += red[j][lane];
-    int64_t o = idx;
-    if (w_map == 1) {
-      const int k = (int)(idx / Nout), m = (int)(idx % Nout);
-      const int ne = k / F, l = k % F;
-      o = ((int64_t)l * F + m) * E + ne;
-    } else if (w_map == 2) {   // MPLayer weight from h^T B: idx = k*Nout + l with k = ne*F + m
-      const int k = (int)(idx / Nout), l = (int)(idx % Nout);
-      const int ne = k / F, m = k % F;
-      o = ((int64_t)l * F + m) * E + ne;
-    }
-    out[o] = t;
-  }
-}
-
-static inline void launch_reduce_z(hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out,
-                            int w_map = 0, int F = 0, int E = 0, int Nout = 1, int64_t z_stride = 0) {
-  hipLaunchKernelGGL(reduce_z_kernel, dim3((unsigned)cdiv(n_elem, 64)), dim3(1024), 0, st, partial,
-                     nz, n_elem, out, w_map, F, E, Nout, z_stride ? z_stride : n_elem);
-}
-
-// Same reduction, but the summed vector is cut into segments that land in different tensors (weight and
+// Same reduction with segments: the summed vector is cut into pieces that land in different tensors (weight and
 // bias gradients of several layers): one launch instead of a reduction plus one device copy per tensor.
 constexpr int REDUCE_MAX_SEG = 16;
 struct ReduceSegs {
@@ -67,24 +31,67 @@ struct ReduceSegs {
   float* dst[REDUCE_MAX_SEG];
 };
 
+// One reduction: what reduce_z_kernel / reduce_z_seg_kernel / reduce_batch_kernel all execute for block `blk` of the
+// job (the summation order — and with it every bit of the result — is the same whichever kernel runs it).
+struct ReduceJob {
+  const float* partial;
+  float* out;                    // plain / mapped form (sg == nullptr)
+  int64_t n_elem, z_stride;
+  int nz, w_map, F, E, Nout;
+};
+
+__device__ __forceinline__ void reduce_job_block(const ReduceJob& j, const ReduceSegs* sg, unsigned blk, float (*red)[64]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blk * 64 + lane;
+  float s = 0.f;
+  if (idx < j.n_elem)
+    for (int z = w; z < j.nz; z += 16) s += j.partial[(int64_t)z * j.z_stride + idx];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && idx < j.n_elem) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][lane];
+    if (sg) {
+#pragma unroll
+      for (int k = 0; k < REDUCE_MAX_SEG; ++k)
+        if (k < sg->n && idx >= sg->begin[k] && idx < sg->begin[k] + sg->len[k]) sg->dst[k][idx - sg->begin[k]] = t;
+      return;
+    }
+    int64_t o = idx;
+    if (j.w_map == 1) {
+      const int k = (int)(idx / j.Nout), m = (int)(idx % j.Nout);
+      const int ne = k / j.F, l = k % j.F;
+      o = ((int64_t)l * j.F + m) * j.E + ne;
+    } else if (j.w_map == 2) {   // MPLayer weight from h^T B: idx = k*Nout + l with k = ne*F + m
+      const int k = (int)(idx / j.Nout), l = (int)(idx % j.Nout);
+      const int ne = k / j.F, m = k % j.F;
+      o = ((int64_t)l * j.F + m) * j.E + ne;
+    }
+    j.out[o] = t;
+  }
+}
+
+static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __restrict__ partial, int nz,
+                                                        int64_t n_elem, float* __restrict__ out,
+                                                        int w_map, int F, int E, int Nout,
+                                                        int64_t z_stride) {
+  __shared__ float red[16][64];
+  const ReduceJob j{partial, out, n_elem, z_stride, nz, w_map, F, E, Nout};
+  reduce_job_block(j, nullptr, blockIdx.x, red);
+}
+
+static inline void launch_reduce_z(hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out,
+                            int w_map = 0, int F = 0, int E = 0, int Nout = 1, int64_t z_stride = 0) {
+  hipLaunchKernelGGL(reduce_z_kernel, dim3((unsigned)cdiv(n_elem, 64)), dim3(1024), 0, st, partial,
+                     nz, n_elem, out, w_map, F, E, Nout, z_stride ? z_stride : n_elem);
+}
+
 static __global__ __launch_bounds__(1024) void reduce_z_seg_kernel(const float* __restrict__ partial, int nz,
                                                                    int64_t n_elem, int64_t z_stride, ReduceSegs sg) {
   __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (idx < n_elem)
-    for (int z = w; z < nz; z += 16) s += partial[(int64_t)z * z_stride + idx];
-  red[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && idx < n_elem) {
-    float t = red[0][lane];
-#pragma unroll
-    for (int j = 1; j < 16; ++j) t += red[j][lane];
-#pragma unroll
-    for (int k = 0; k < REDUCE_MAX_SEG; ++k)
-      if (k < sg.n && idx >= sg.begin[k] && idx < sg.begin[k] + sg.len[k]) sg.dst[k][idx - sg.begin[k]] = t;
-  }
+  const ReduceJob j{partial, nullptr, n_elem, z_stride, nz, 0, 0, 0, 1};
+  reduce_job_block(j, &sg, blockIdx.x, red);
 }
 
 static inline void launch_reduce_z_seg(hipStream_t st, const float* partial, int nz, int64_t n_elem,
@@ -92,6 +99,18 @@ static inline void launch_reduce_z_seg(hipStream_t st, const float* partial, int
   hipLaunchKernelGGL(reduce_z_seg_kernel, dim3((unsigned)cdiv(n_elem, 64)), dim3(1024), 0, st, partial, nz,
                      n_elem, z_stride, sg);
 }
+
+// Deferred form (ng_defer_reductions, capi.hip): while deferral is on, a producer takes its partial buffer from the
+// context's reduction arena (deferred_partials: stays valid until the flush, nullptr = deferral off) and hands the
+// reduction to reduce_or_defer / reduce_seg_or_defer, which queue it; ng_flush_reductions runs every queued job in ONE
+// launch (reduce_batch_kernel).  With deferral off both run the reduction at once, as before.  The backward of a
+// training step has seven such reductions of 5-12 us each behind kernels that leave the GPU idle meanwhile.
+float* deferred_partials(ng_ctx* ctx, size_t floats);
+int reduce_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out, int w_map = 0,
+                    int F = 0, int E = 0, int Nout = 1, int64_t z_stride = 0);
+int reduce_seg_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, int64_t z_stride,
+                        const ReduceSegs& sg);
+int flush_reductions(ng_ctx* ctx, hipStream_t st);
 
 // partial[blk][a*B + b] = sum_{rows of blk} X(row, a) * Y(row, b)      (A <= 32, any B)
 // rows are staged 64 at a time in LDS; thread t owns items t, t+256, ... (<= SMALL_TN_ITEMS each);

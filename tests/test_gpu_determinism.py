@@ -144,3 +144,42 @@ def test_backward_inside_a_frozen_window_uses_each_layers_own_weights(gpu_device
             finally:
                 lib.ng_weights_frozen(h, 0)
             assert torch.equal(eng.params.grad, ref.params.grad), (F, rep)
+
+
+@pytest.mark.parametrize("F", [64, 256])
+def test_deferred_weight_gradient_sums_equal_the_eager_ones(gpu_device, F):
+    """Engine.backward queues the second-stage sums of the node-side weight gradients and runs them in one launch
+    (ng_defer_reductions / ng_flush_reductions, ABI 5): every gradient must carry the bits of the eager form, also when
+    the queue is longer than one batch and on the second call (arena reuse)."""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    hp = make_hp(atom_feature_size=F)
+    b = synth.make_batch(48, 200, 16, 10, 0.05, seed=4)
+    eng = Engine(hp, 10, device=gpu_device, seed=11)
+    randomize_biases(eng)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=5)
+    mask = eng.dropout_mask(N * (F // 2), seed=6)
+    dpe = torch.from_numpy(np.random.default_rng(2).standard_normal(N).astype(np.float32)).to(gpu_device)
+    grads = {}
+    for mode in (False, True, True):
+        eng.defer_reductions = mode
+        eng.params.grad.fill_(12345.0)       # a gradient the backward did not (re)write would keep the sentinel
+        eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
+        eng.backward(dpe)
+        g = eng.params.grad.clone()
+        # (the flat buffer pads every tensor to 16 bytes: only the views are gradients)
+        for name, gv in eng.params.grad_views.items():
+            assert torch.isfinite(gv).all() and not bool((gv == 12345.0).any()), name
+        if mode in grads:
+            assert torch.equal(grads[mode], g)
+        grads[mode] = g
+    assert torch.equal(grads[False], grads[True])
+    # C ABI: switching deferral off flushes what is queued
+    lib, h, st = eng.lib, eng.ctx.handle, eng._st()
+    eng._ck(lib.ng_defer_reductions(h, st, 1), "on")
+    eng._ck(lib.ng_flush_reductions(h, st), "empty flush")
+    eng._ck(lib.ng_defer_reductions(h, st, 0), "off")
