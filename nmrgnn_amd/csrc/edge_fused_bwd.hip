@@ -361,8 +361,17 @@ __global__ __launch_bounds__(1024) void edge_bwd_reduce_kernel(const float* __re
   const int idx = blockIdx.x * 64 + lane;
   float s = 0.f;
   if (idx < total) {
-#pragma unroll 4
-    for (int w = wv; w < n_wg; w += 16) s += partial[(int64_t)w * stride + idx];
+    // eight loads in flight per lane, added in workgroup order (same sum as the plain loop)
+    const float* p = partial + idx;
+    int w = wv;
+    for (; w + 112 < n_wg; w += 128) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(w + 16 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; w < n_wg; w += 16) s += p[(int64_t)w * stride];
   }
   red[wv][lane] = s;
   __syncthreads();

@@ -634,7 +634,8 @@ extern "C" int ng_fc_block_bwd(ng_ctx* ctx, void* stream, int64_t N, int F, int 
     const int nb = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 4);
     const int64_t rows = cdiv(cdiv(N, nb), rl) * rl;
     const int nblk = (int)cdiv(N, rows);
-    float* partial = (float*)aux_workspace(ctx, (size_t)nblk * No * 4);
+    float* partial = deferred_partials(ctx, (size_t)nblk * No);
+    if (!partial) partial = (float*)aux_workspace(ctx, (size_t)nblk * No * 4);
     if (!partial) return NG_ERR_NOMEM;
     const float* gsc = nullptr;         // the same dP feeds both products: one scale, from the dP kernel's block maxima
     {
@@ -643,8 +644,9 @@ extern "C" int ng_fc_block_bwd(ng_ctx* ctx, void* stream, int64_t N, int F, int 
       float* bmax = dense_grad_uses_h2(N, F, No) ? gemm_grad_blockmax(ctx, &cap) : nullptr;
       hipLaunchKernelGGL(fc_dp_kernel, dim3(nblk), dim3(256), (size_t)rl * No * 4, st, N, No, rows, act, cur,
                          resid ? x[l + 1] : g, resid ? x[l] : nullptr, dP, partial, bmax);
-      launch_reduce_z(st, partial, nblk, (int64_t)No, db[l]);
       NG_HIP(ctx, hipGetLastError());
+      const int rcr = reduce_or_defer(ctx, st, partial, nblk, (int64_t)No, db[l]);
+      if (rcr) return rcr;
       if (bmax) {
         const int rcs = gemm_grad_scale_from_blocks(ctx, st, nblk, &gsc);
         if (rcs) return rcs;

@@ -228,6 +228,8 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   const DwPlan p = dw_plan(ctx, M, Kin, Nout, db != nullptr);
   float* partial = scratch;
   float* cs_partial = scratch + p.nz * n_elem;
+  // deferred reductions (reduce.cuh): the split-K partials wait in the reduction arena for the flush
+  if (float* dp = deferred_partials(ctx, (size_t)p.nz * n_elem)) partial = dp;
   RangeGuard guard{nullptr, 0};
   if (gemm_h2_dw_ok(M, Kin, Nout)) {
     guard = range_guard_begin(ctx);
@@ -248,8 +250,8 @@ int dense_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act,
   }
   {
     ProfScope ps(ctx, st, "reduce_partials");
-    launch_reduce_z(st, partial, (int)p.nz, n_elem, dW, w_map, F, E, Nout);
-    NG_HIP(ctx, hipGetLastError());
+    const int rc = reduce_or_defer(ctx, st, partial, (int)p.nz, n_elem, dW, w_map, F, E, Nout);
+    if (rc) return rc;
   }
   if (db) {
     NG_REQUIRE(ctx, Nout / 4 <= 256, "dense_dw: Nout <= 1024 for the bias gradient");

@@ -822,14 +822,31 @@ __global__ void mp_records_kernel(int64_t N, int K, int E, const int32_t* __rest
                                   const int32_t* __restrict__ csc_edge, const float* __restrict__ e,
                                   float4* __restrict__ rec) {
   const int64_t nnz = csc_ptr[N];
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
-    const int eid = csc_edge[p];
-    float4 r;
-    r.x = __builtin_bit_cast(float, eid / K);
-    r.y = e[(int64_t)eid * E];
-    r.z = E > 1 ? e[(int64_t)eid * E + 1] : 0.f;
-    r.w = E > 2 ? e[(int64_t)eid * E + 2] : 0.f;
-    rec[p] = r;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // four entries per trip: the four edge ids are requested together, then the twelve gathers (one entry per trip ran
+  // two dependent memory round trips per entry: 36 us for 2.1 M entries)
+  for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < nnz; p0 += 4 * stride) {
+    int eid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) eid[u] = csc_edge[std::min<int64_t>(p0 + u * stride, nnz - 1)];
+    float4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r[u].x = __builtin_bit_cast(float, eid[u] / K);
+      if (E == 3) {
+        // one 12-byte load per entry (global_load_dwordx3): three scattered dword loads fetched the entry's sector three times
+        struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+        const F3 v = *reinterpret_cast<const F3*>(e + (int64_t)eid[u] * 3);
+        r[u].y = v.x; r[u].z = v.y; r[u].w = v.z;
+      } else {
+        r[u].y = e[(int64_t)eid[u] * E];
+        r[u].z = E > 1 ? e[(int64_t)eid[u] * E + 1] : 0.f;
+        r[u].w = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u * stride < nnz) rec[p0 + u * stride] = r[u];
   }
 }
 

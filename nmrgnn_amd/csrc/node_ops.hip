@@ -73,15 +73,26 @@ __global__ __launch_bounds__(256) void embed_fwd_rows_kernel(int64_t N, int C, c
 #pragma unroll
   for (int c = 0; c < 16; ++c) w[c] = c < C ? *reinterpret_cast<const float4*>(Wemb + (int64_t)c * F + c4 * 4) : f4zero();
   const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / C4N);
-  for (int64_t i = (int64_t)blockIdx.x * (256 / C4N) + threadIdx.x / C4N; i < N; i += rows_per_pass) {
-    const float mine = c4 < C ? atoms[i * C + c4] : 0.f;
-    float4 acc = f4zero();
+  // four rows per trip, their one-hot loads requested together: with one row per trip the kernel waited a memory round
+  // trip per row (16 us for 131k rows of 64 features; the 33 MB it writes take 4)
+  for (int64_t i0 = (int64_t)blockIdx.x * (256 / C4N) + threadIdx.x / C4N; i0 < N; i0 += 4 * rows_per_pass) {
+    float mine[4];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float a = __shfl(mine, c, C4N);
-      acc.x = fmaf(a, w[c].x, acc.x); acc.y = fmaf(a, w[c].y, acc.y); acc.z = fmaf(a, w[c].z, acc.z); acc.w = fmaf(a, w[c].w, acc.w);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * rows_per_pass;
+      mine[u] = (c4 < C && i < N) ? atoms[i * C + c4] : 0.f;
     }
-    *reinterpret_cast<float4*>(h0 + i * F + c4 * 4) = acc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * rows_per_pass;
+      float4 acc = f4zero();
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float a = __shfl(mine[u], c, C4N);
+        acc.x = fmaf(a, w[c].x, acc.x); acc.y = fmaf(a, w[c].y, acc.y); acc.z = fmaf(a, w[c].z, acc.z); acc.w = fmaf(a, w[c].w, acc.w);
+      }
+      if (i < N) *reinterpret_cast<float4*>(h0 + i * F + c4 * 4) = acc;
+    }
   }
 }
 
