@@ -50,39 +50,24 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
   __syncthreads();
   const int q = threadIdx.x % LPR;
   const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / LPR);
-  // Two rows per trip, and a row's one-hot values are loaded ONCE by the row's lane group (lane q holds columns q and
-  // q + LPR) and passed round: the per-column loads inside the c loop made every row C dependent memory round trips.
-  for (int64_t i0 = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; i0 < N; i0 += 2 * rows_per_pass) {
-    constexpr int NA = (HC_MAX + LPR - 1) / LPR;     // one-hot columns q, q + LPR, ... held by lane q
-    float4 x[2], m[2];
-    float av[2][NA];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t i = std::min<int64_t>(i0 + u * rows_per_pass, N - 1);
-      x[u] = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
-      m[u] = mask ? *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-      for (int j = 0; j < NA; ++j) av[u][j] = q + j * LPR < C ? atoms[i * C + q + j * LPR] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; i < N; i += rows_per_pass) {
+    float4 x = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
+    if (mask) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q);
+      x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t i = i0 + u * rows_per_pass;
-      if (mask) { x[u].x *= m[u].x; x[u].y *= m[u].y; x[u].z *= m[u].z; x[u].w *= m[u].w; }
-      float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, v = 0.f;
-#pragma unroll
-      for (int j = 0; j < NA; ++j)
-        for (int c = j * LPR; c < C && c < (j + 1) * LPR; ++c) {
-          const float a = __shfl(av[u][j], c - j * LPR, LPR);
-          u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
-          u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
-          v += a * sV[c];
-        }
-      float p = x[u].x * u0 + x[u].y * u1 + x[u].z * u2 + x[u].w * u3;
-      p = sum8(p);
-      if (LPR >= 16) p += __shfl_xor(p, 8, 64);
-      if (LPR == 32) p += __shfl_xor(p, 16, 64);
-      if (q == 0 && i < N) peaks[i] = p + v;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, v = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float a = atoms[i * C + c];
+      u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
+      u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
+      v += a * sV[c];
     }
+    float p = x.x * u0 + x.y * u1 + x.z * u2 + x.w * u3;
+    p = sum8(p);
+    if (LPR >= 16) p += __shfl_xor(p, 8, 64);
+    if (LPR == 32) p += __shfl_xor(p, 16, 64);
+    if (q == 0) peaks[i] = p + v;
   }
 }
 
