@@ -91,6 +91,10 @@ int ng_randn(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, float* out, 
 int ng_dropout_mask(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, float keep, float* out,
                     int64_t n);
 
+/* out = x + alpha*xi with the xi of ng_randn(seed, offset): GaussianNoise (nmrgnn/model.py:213,253) in one launch
+ * instead of ng_randn + ng_add_scaled; the bits are those of the two-call form */
+int ng_add_noise(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, int64_t n, const float* x, float alpha,
+                 float* out);
 /* out = x + alpha*y : applies the GaussianNoise draw, d_eff = d + sigma*xi (nmrgnn/model.py:253) */
 int ng_add_scaled(ng_ctx*, void* stream, int64_t n, const float* x, const float* y, float alpha,
                   float* out);
@@ -309,6 +313,11 @@ int ng_dense_bwd(ng_ctx*, void* stream, int64_t M, int Kin, int Nout, int act, i
 int ng_head_fwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
                 const float* drop_mask, const float* Wout, const float* bout, const float* atoms,
                 const float* peak_std, const float* peak_avg, float* peaks);
+/* the same with the keras Dropout mask (model.py:216-219,266-267) drawn inside the launch: mask_out[N,Fh] receives the
+ * values of ng_dropout_mask(seed, offset, keep) over the N*Fh elements (the backward reads them) */
+int ng_head_fwd_dropout(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g, uint64_t seed, uint64_t offset,
+                        float keep, float* mask_out, const float* Wout, const float* bout, const float* atoms,
+                        const float* peak_std, const float* peak_avg, float* peaks);
 int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
                 const float* drop_mask, const float* Wout, const float* atoms,
                 const float* peak_std, const float* dpeaks, float* dg, float* dWout, float* dbout);

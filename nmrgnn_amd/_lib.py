@@ -43,6 +43,7 @@ SIGNATURES = {
     "ng_randn": (_int, [_vp, _vp, _u64, _u64, _vp, _i64]),
     "ng_dropout_mask": (_int, [_vp, _vp, _u64, _u64, _f, _vp, _i64]),
     "ng_add_scaled": (_int, [_vp, _vp, _i64, _vp, _vp, _f, _vp]),
+    "ng_add_noise": (_int, [_vp, _vp, _u64, _u64, _i64, _vp, _f, _vp]),
     "ng_rbf_expand": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _f, _vp]),
     "ng_edge_mlp_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "ng_dense_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp]),
     "ng_head_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_head_fwd_dropout": (_int, [_vp, _vp, _i64, _int, _int, _vp, _u64, _u64, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_head_bwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_mp_layer_wants_aggregate": (_int, [_int, _int, _int]),
     "ng_fc_block_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),

@@ -14,6 +14,7 @@
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
 #include "reduce.cuh"
+#include "rng.cuh"
 
 namespace ng {
 
@@ -33,7 +34,11 @@ __device__ __forceinline__ float sum8(float v) {
 }
 
 // ---- head forward: LPR lanes per row, one float4 of the Fh features each --------------------------------
-template <int LPR>
+// draw: the keep-mask is drawn here (the values of dropout_mask_kernel(seed, offset, keep) over the [N][Fh] elements: a
+// lane's four columns are one Philox counter) and written to mask_out for the backward, instead of being read
+struct HeadDraw { uint64_t seed, offset; float keep; float* mask_out; };
+
+template <int LPR, bool DRAW>
 __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, const float* __restrict__ g,
                                                             const float* __restrict__ mask,
                                                             const float* __restrict__ Wout,
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
                                                             const float* __restrict__ atoms,
                                                             const float* __restrict__ pstd,
                                                             const float* __restrict__ pavg,
-                                                            float* __restrict__ peaks) {
+                                                            float* __restrict__ peaks, HeadDraw dr) {
   constexpr int Fh = LPR * 4;
   __shared__ float sWs[Fh * HC_MAX];     // std_c * Wout[f][c]
   __shared__ float sV[HC_MAX];           // std_c * b_c + avg_c
@@ -52,7 +57,18 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
   const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / LPR);
   for (int64_t i = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; i < N; i += rows_per_pass) {
     float4 x = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
-    if (mask) {
+    if (DRAW) {
+      uint32_t r[4];
+      philox4x32(dr.seed, dr.offset + (uint64_t)(i * LPR + q), r);
+      const float inv = 1.0f / dr.keep;
+      float4 m = make_float4(u01(r[0]) <= dr.keep ? inv : 0.f, u01(r[1]) <= dr.keep ? inv : 0.f,
+                             u01(r[2]) <= dr.keep ? inv : 0.f, u01(r[3]) <= dr.keep ? inv : 0.f);
+      *reinterpret_cast<float4*>(dr.mask_out + i * Fh + 4 * q) = m;
+      // opaque from here on, like a loaded mask: folded into the select the products below were contracted differently
+      // from the mask-reading form (peaks 1 ulp apart)
+      asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
+      x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+    } else if (mask) {
       const float4 m = *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q);
       x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
     }
@@ -63,7 +79,8 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
       u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
       v += a * sV[c];
     }
-    float p = x.x * u0 + x.y * u1 + x.z * u2 + x.w * u3;
+    // explicit fused chain: left to the compiler the two instantiations contracted this sum differently (1 ulp apart)
+    float p = fmaf(x.w, u3, fmaf(x.z, u2, fmaf(x.y, u1, x.x * u0)));
     p = sum8(p);
     if (LPR >= 16) p += __shfl_xor(p, 8, 64);
     if (LPR == 32) p += __shfl_xor(p, 16, 64);
@@ -190,20 +207,25 @@ bool head_fwd_fast_supported(int Fh, int C) {
 
 int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
                   const float* Wout, const float* bout, const float* atoms, const float* pstd,
-                  const float* pavg, float* peaks) {
+                  const float* pavg, float* peaks, uint64_t seed, uint64_t offset, float keep, float* mask_out) {
   const int lpr = Fh / 4;
   const int64_t rpb = 256 / lpr;
   const int grid = (int)std::min<int64_t>(cdiv(N, rpb), (int64_t)ctx->num_cu * 8);
+  const HeadDraw dr{seed, offset, keep, mask_out};
   ProfScope ps(ctx, st, "head_fwd");
-  if (lpr == 8)
-    hipLaunchKernelGGL((head_fwd_fast_kernel<8>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, atoms,
-                       pstd, pavg, peaks);
-  else if (lpr == 32)     // the reference's default width: fc output 128 (the one-thread-per-atom kernel took 91 us for 2770 atoms)
-    hipLaunchKernelGGL((head_fwd_fast_kernel<32>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, atoms,
-                       pstd, pavg, peaks);
-  else
-    hipLaunchKernelGGL((head_fwd_fast_kernel<16>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout,
-                       atoms, pstd, pavg, peaks);
+#define NG_HF(L)                                                                                                   \
+  do {                                                                                                             \
+    if (mask_out)                                                                                                  \
+      hipLaunchKernelGGL((head_fwd_fast_kernel<L, true>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, \
+                         atoms, pstd, pavg, peaks, dr);                                                            \
+    else                                                                                                           \
+      hipLaunchKernelGGL((head_fwd_fast_kernel<L, false>), dim3(grid), dim3(256), 0, st, N, C, g, mask, Wout, bout, \
+                         atoms, pstd, pavg, peaks, dr);                                                            \
+  } while (0)
+  if (lpr == 8) NG_HF(8);
+  else if (lpr == 32) NG_HF(32);     // the reference's default width: fc output 128 (the one-thread-per-atom kernel took 91 us for 2770 atoms)
+  else NG_HF(16);
+#undef NG_HF
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

@@ -192,7 +192,8 @@ bool head_fast_supported(int Fh, int C);
 bool head_fwd_fast_supported(int Fh, int C);
 int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
                   const float* Wout, const float* bout, const float* atoms, const float* pstd,
-                  const float* pavg, float* peaks);
+                  const float* pavg, float* peaks,
+                  uint64_t seed = 0, uint64_t offset = 0, float keep = 1.f, float* mask_out = nullptr);
 int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
                   const float* Wout, const float* atoms, const float* pstd, const float* dpeaks, float* dg,
                   float* dWout, float* dbout);

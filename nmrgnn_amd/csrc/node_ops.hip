@@ -7,6 +7,7 @@
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
 #include "reduce.cuh"
+#include "rng.cuh"
 
 namespace ng {
 
@@ -596,29 +597,6 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __res
 }
 
 // ------------------------------------------------------------------------------------ RNG
-// Philox4x32-10 counter RNG (Salmon et al. 2011); counter = element index / 4 + offset.
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-  const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
-  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-__device__ __forceinline__ float u01(uint32_t x) {  // (0,1]
-  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
-}
-
 __global__ void randn_kernel(uint64_t seed, uint64_t offset, float* __restrict__ out, int64_t n) {
   const int64_t n4 = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
@@ -656,6 +634,24 @@ __global__ void add_scaled_kernel(int64_t n, const float* __restrict__ x,
     out[i] = x[i] + alpha * y[i];
 }
 
+// out = x + alpha * xi with the xi of randn_kernel(seed, offset) — GaussianNoise in one launch (model.py:253); same
+// expressions as randn_kernel followed by add_scaled_kernel, so the bits are those of the two-launch form
+__global__ void add_noise_kernel(uint64_t seed, uint64_t offset, int64_t n, const float* __restrict__ x, float alpha,
+                                 float* __restrict__ out) {
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32(seed, offset + (uint64_t)q, r);
+    float z[4];
+    const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), t0 = 6.28318530717958648f * u01(r[1]);
+    const float r1 = sqrtf(-2.0f * logf(u01(r[2]))), t1 = 6.28318530717958648f * u01(r[3]);
+    z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1); z[3] = r1 * sinf(t1);
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) out[q * 4 + k] = x[q * 4 + k] + alpha * z[k];
+  }
+}
+
 static inline dim3 ew_grid(int64_t work_items) {
   return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(work_items, 256), 256 * 8)));
 }
@@ -682,6 +678,16 @@ extern "C" int ng_dropout_mask(ng_ctx* ctx, void* stream, uint64_t seed, uint64_
   if (n == 0) return NG_OK;
   hipLaunchKernelGGL(dropout_mask_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      seed, offset, keep, out, n);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_add_noise(ng_ctx* ctx, void* stream, uint64_t seed, uint64_t offset, int64_t n, const float* x,
+                            float alpha, float* out) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (n == 0) return NG_OK;
+  hipLaunchKernelGGL(add_noise_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed, offset, n, x,
+                     alpha, out);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -849,6 +855,23 @@ extern "C" int ng_head_fwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, 
                      peak_avg, peaks);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
+}
+
+extern "C" int ng_head_fwd_dropout(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, const float* g, uint64_t seed,
+                                   uint64_t offset, float keep, float* mask_out, const float* Wout, const float* bout,
+                                   const float* atoms, const float* peak_std, const float* peak_avg, float* peaks) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, C >= 1 && C <= MAX_C, "head: number of elements <= 32");
+  NG_REQUIRE(ctx, keep > 0.f && keep <= 1.f, "dropout keep probability in (0,1]");
+  NG_REQUIRE(ctx, mask_out, "head_fwd_dropout: mask_out [N,Fh] required (the backward reads it)");
+  if (N == 0) return NG_OK;
+  if (head_fwd_fast_supported(Fh, C) && Fh % 4 == 0)
+    return head_fwd_fast(ctx, (hipStream_t)stream, N, Fh, C, g, nullptr, Wout, bout, atoms, peak_std, peak_avg, peaks,
+                         seed, offset, keep, mask_out);
+  // other shapes: the draw and the head as two launches
+  const int rc = ng_dropout_mask(ctx, stream, seed, offset, keep, mask_out, N * Fh);
+  if (rc) return rc;
+  return ng_head_fwd(ctx, stream, N, Fh, C, g, mask_out, Wout, bout, atoms, peak_std, peak_avg, peaks);
 }
 
 extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, const float* g,

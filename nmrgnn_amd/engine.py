@@ -148,12 +148,13 @@ class Engine:
         d_src = batch.edges.reshape(-1)
         d_eff = d_src
         if training and self.sigma > 0:
-            if noise is None:
-                noise = self.randn(ne, seed, 0)
-            noise = noise.reshape(-1)
             d_eff = self._new(ne)
-            self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
-                     "ng_add_scaled")
+            if noise is None:     # the draw and d + sigma * xi in one launch (the bits of randn + add_scaled)
+                self._ck(lib.ng_add_noise(h, st, seed, 0, ne, ptr(d_src), self.sigma, ptr(d_eff)), "ng_add_noise")
+            else:
+                noise = noise.reshape(-1)
+                self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
+                         "ng_add_scaled")
         z_save = self._new(self.Le - 1, ne, H) if tape else None
         # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
         # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
@@ -214,15 +215,19 @@ class Engine:
         self._ck(lib.ng_fc_block_fwd(h, st, N, F, self.Lf, self.fc_act, ptr(fx[0]), ptr_array(Wfc),
                                      ptr_array(Bfc), ptr_array(fx[1:]), ptr(g)), "ng_fc_block_fwd")
         mask = None
-        if training and self.use_dropout:
-            mask = dropout_mask
-            if mask is None:
-                mask = self.dropout_mask(N * Fh, seed, 1 << 40)
-            mask = mask.reshape(N, Fh).contiguous()
         peaks = self._new(N)
-        self._ck(lib.ng_head_fwd(h, st, N, Fh, self.C, ptr(g), ptr(mask), ptr(P["out/kernel"]),
-                                 ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
-                                 ptr(self.peak_avg), ptr(peaks)), "ng_head_fwd")
+        if training and self.use_dropout and dropout_mask is None:
+            # the keep-mask is drawn inside the head launch and kept for the backward (the values of ng_dropout_mask)
+            mask = self._new(N, Fh)
+            self._ck(lib.ng_head_fwd_dropout(h, st, N, Fh, self.C, ptr(g), seed, 1 << 40, 1.0 - DROPOUT_RATE, ptr(mask),
+                                             ptr(P["out/kernel"]), ptr(P["out/bias"]), ptr(batch.atoms),
+                                             ptr(self.peak_std), ptr(self.peak_avg), ptr(peaks)), "ng_head_fwd_dropout")
+        else:
+            if training and self.use_dropout:
+                mask = dropout_mask.reshape(N, Fh).contiguous()
+            self._ck(lib.ng_head_fwd(h, st, N, Fh, self.C, ptr(g), ptr(mask), ptr(P["out/kernel"]),
+                                     ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
+                                     ptr(self.peak_avg), ptr(peaks)), "ng_head_fwd")
         if tape:
             tp = Tape()
             tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e

@@ -183,3 +183,37 @@ def test_deferred_weight_gradient_sums_equal_the_eager_ones(gpu_device, F):
     eng._ck(lib.ng_defer_reductions(h, st, 1), "on")
     eng._ck(lib.ng_flush_reductions(h, st), "empty flush")
     eng._ck(lib.ng_defer_reductions(h, st, 0), "off")
+
+
+def test_fused_draws_carry_the_bits_of_the_two_launch_forms(gpu_device):
+    """ng_add_noise == ng_randn + ng_add_scaled and ng_head_fwd_dropout == ng_dropout_mask + ng_head_fwd, bit for bit
+    (the training forward draws inside the consuming launch; explicit draws stay available for the parity tests)."""
+    import torch
+    from nmrgnn_amd._lib import ptr
+    from nmrgnn_amd.engine import Engine
+    eng = Engine(make_hp(atom_feature_size=64), 10, device=gpu_device, seed=3)
+    lib, h, st = eng.lib, eng.ctx.handle, eng._st()
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 4096, 100003):
+        d = torch.from_numpy(rng.uniform(0.05, 0.5, n).astype(np.float32)).to(gpu_device)
+        xi = eng.randn(n, seed=77, offset=5)
+        a = torch.empty(n, device=gpu_device); b = torch.empty(n, device=gpu_device)
+        eng._ck(lib.ng_add_scaled(h, st, n, ptr(d), ptr(xi), 0.025, ptr(a)), "add_scaled")
+        eng._ck(lib.ng_add_noise(h, st, 77, 5, n, ptr(d), 0.025, ptr(b)), "add_noise")
+        assert torch.equal(a, b)
+    C = 10
+    for N, Fh in ((1, 32), (1000, 32), (777, 64), (2770, 128), (33, 16)):      # Fh = 16: no fast head kernel, two launches inside
+        g = torch.from_numpy(rng.standard_normal((N, Fh)).astype(np.float32)).to(gpu_device)
+        Wo = torch.from_numpy(rng.standard_normal((Fh, C)).astype(np.float32)).to(gpu_device)
+        bo = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(gpu_device)
+        at = torch.zeros(N, C, device=gpu_device); at[torch.arange(N), torch.from_numpy(rng.integers(0, C, N)).to(gpu_device)] = 1.0
+        sd = torch.from_numpy(rng.uniform(0.5, 2.0, C).astype(np.float32)).to(gpu_device)
+        av = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(gpu_device)
+        m_ref = eng.dropout_mask(N * Fh, seed=91, offset=1 << 40, keep=0.8).reshape(N, Fh)
+        p_ref = torch.empty(N, device=gpu_device); p = torch.empty(N, device=gpu_device)
+        m = torch.full((N, Fh), -1.0, device=gpu_device)
+        eng._ck(lib.ng_head_fwd(h, st, N, Fh, C, ptr(g), ptr(m_ref), ptr(Wo), ptr(bo), ptr(at), ptr(sd), ptr(av), ptr(p_ref)), "head")
+        eng._ck(lib.ng_head_fwd_dropout(h, st, N, Fh, C, ptr(g), 91, 1 << 40, 0.8, ptr(m), ptr(Wo), ptr(bo), ptr(at), ptr(sd),
+                                        ptr(av), ptr(p)), "head_dropout")
+        assert torch.equal(m, m_ref), (N, Fh, int((m != m_ref).sum()), m[:2], m_ref[:2])
+        assert torch.equal(p, p_ref), (N, Fh, float((p - p_ref).abs().max()))
