@@ -184,6 +184,42 @@ __device__ __forceinline__ void h2_epilogue(const f32x16& acc, u32x4 (&bfo)[2][2
   }
 }
 
+// The same half layer with the caller's elementwise work handed in per step (fill(step), compile-time step): one wave
+// has to put its own VALU work into the shadow of its own MFMAs — up to five plain VALU instructions issue per
+// 32x32x16 MFMA for free (tools/ubench/mfma_fill.hip), while VALU work outside an MFMA sequence is not overlapped by the
+// partner wave either (the two waves of a SIMD run in lockstep between the layer barriers).
+template <class F>
+__device__ __forceinline__ void h2_hidden_chunk_f(const char* slot, const u32x4 (&bf)[4][2][2], f32x16& acc0, f32x16& acc1,
+                                                  const float* __restrict__ sb, int bo0, int lane, F&& fill) {
+  const u32x4* fr = reinterpret_cast<const u32x4*>(slot) + lane;
+  u32x4 a0[2][2], a1[2][2];
+  h2_load_a(fr, 0, a0[0], a1[0]);
+  acc0 = h2_bias(sb, bo0, lane >> 5);
+  acc1 = h2_bias(sb, bo0 + 1, lane >> 5);
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    if (step < 7) h2_load_a(fr, step + 1, a0[(step + 1) & 1], a1[(step + 1) & 1]);
+    mma3_2a(a0[step & 1], a1[step & 1], bf[step >> 1][step & 1], acc0, acc1);
+    fill(step);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// one quarter (registers 4q .. 4q+3) of h2_epilogue for the tape forms without a transposition tile (SAVE 0 / 2)
+template <int SAVE, bool SP>
+__device__ __forceinline__ void h2_epilogue_q(const f32x16& acc, u32x4 (&bfo)[2][2], int q, float* __restrict__ zp, int qstride) {
+  typedef float nt4 __attribute__((ext_vector_type(4)));
+  const float z0 = SP ? h2_softplus(acc[4 * q + 0]) : acc[4 * q + 0], z1 = SP ? h2_softplus(acc[4 * q + 1]) : acc[4 * q + 1];
+  const float z2 = SP ? h2_softplus(acc[4 * q + 2]) : acc[4 * q + 2], z3 = SP ? h2_softplus(acc[4 * q + 3]) : acc[4 * q + 3];
+  if (SAVE == 2) __builtin_nontemporal_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
+  const int s = q >> 1, j = 2 * (q & 1);
+  unsigned h, l;
+  split2_pair(z0, z1, h, l);
+  bfo[s][0][j] = h; bfo[s][1][j] = l;
+  split2_pair(z2, z3, h, l);
+  bfo[s][0][j + 1] = h; bfo[s][1][j + 1] = l;
+}
+
 #define H2_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <int SAVE>
@@ -244,27 +280,83 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     const bool valid = gr < a.n_edges;
     const float ds = valid ? ds_n : 0.f;
     const float mask = ds > 0.f ? 1.f : 0.f;
-    // ---- RBF straight into B fragments; masked edges: d = 1e19 -> exp2(-inf) = exact 0
-    {
-      const float dm = ds > 0.f ? de_n : 1.0e19f;
-      const float c2 = a.neg_inv_gap_log2e;
+    const float dm = ds > 0.f ? de_n : 1.0e19f;      // masked edges: d = 1e19 -> exp2(-inf) = exact 0
+    const float c2 = a.neg_inv_gap_log2e;
+    // one RBF unit = the four dwords' worth of B fragment bf[bi][s][.][2 tq .. 2 tq + 1] (four centres of this lane)
+    auto rbf_unit = [&](int bi, int s, int tq) {
+      const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * bi + 16 * s + 8 * tq + 4 * hf);
+      float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
+      u0 = __builtin_amdgcn_exp2f(u0 * u0 * c2); u1 = __builtin_amdgcn_exp2f(u1 * u1 * c2);
+      u2 = __builtin_amdgcn_exp2f(u2 * u2 * c2); u3 = __builtin_amdgcn_exp2f(u3 * u3 * c2);
+      unsigned h, l;
+      split2_pair(u0, u1, h, l);
+      bf[bi][s][0][2 * tq] = h; bf[bi][s][1][2 * tq] = l;
+      split2_pair(u2, u3, h, l);
+      bf[bi][s][0][2 * tq + 1] = h; bf[bi][s][1][2 * tq + 1] = l;
+    };
+    // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
+    const int64_t wrow0 = tile * H2_TM + 32 * wave;
+    const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
+    const bool full = rows_left >= 32;
+    if constexpr (SAVE == 2) {
+      // ---- pipelined schedule (blocked tape: the training forward; the inference form spilled 56 B/lane with it).  The first chunk of a layer is 48 MFMAs with no
+      // elementwise work of its own: it takes the RBF of the blocks it has not reached yet (layer 0) or the epilogue of
+      // the previous layer's blocks 2 and 3 (their pieces are first needed at its step 4 / 6); the second chunk carries
+      // the softplus of blocks 0 and 1 as before.
+      f32x16 acc[4];
+      const int bstride = full ? 1024 : 32, qstride = full ? 256 : 8;
+      // tape position of this lane in layer 0; layer l adds l * n_edges * 128 floats (rows past the end go to the dummy row)
+      const bool todummy = !full && l31 >= rows_left;
+      float* zp0 = nullptr;
+      if (SAVE == 2)
+        zp0 = full ? a.z_save + (tile * 8 + wave) * 4096 + lane * 4 : a.z_save + (wrow0 + l31) * FH + 4 * hf;
+      const int64_t lstride = a.n_edges * FH;
+      auto zpl = [&](int layer) -> float* { return todummy ? a.dummy + 4 * hf : zp0 + layer * lstride; };
+      // B fragments of the first two steps up front, the rest inside layer 0's first chunk
+      rbf_unit(0, 0, 0); rbf_unit(0, 0, 1); rbf_unit(0, 1, 0); rbf_unit(0, 1, 1);
+      {   // distances of this workgroup's next tile
+        const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, a.n_edges - 1);
+        ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
+      }
 #pragma unroll
-      for (int bi = 0; bi < 4; ++bi)
+      for (int layer = 0; layer < 3; ++layer) {
+        H2_STEP_BEGIN();
+        if (layer == 0) {
+          h2_hidden_chunk_f(ring + use_s * SLOT, bf, acc[0], acc[1], sBias, 0, lane, [&](int step) {
+            if (step < 6) { rbf_unit((step + 2) >> 1, (step + 2) & 1, 0); rbf_unit((step + 2) >> 1, (step + 2) & 1, 1); }
+          });
+        } else {
+          float* zp = zpl(layer - 1);        // the previous layer's blocks 2 / 3: tape rows and next-layer pieces
+          h2_hidden_chunk_f(ring + use_s * SLOT, bf, acc[0], acc[1], sBias + layer * FH, 0, lane, [&](int step) {
+            if (step < 4) h2_epilogue_q<SAVE, true>(acc[2], bf[2], step, zp + 2 * bstride, qstride);
+            if (step >= 2 && step < 6) h2_epilogue_q<SAVE, true>(acc[3], bf[3], step - 2, zp + 3 * bstride, qstride);
+          });
+        }
+        // blocks 2 / 3 of THIS layer (the previous layer's acc[2] / acc[3] were consumed inside the chunk above)
+        h2_hidden_chunk_f(ring + use_s * SLOT + H2_CHUNK, bf, acc[2], acc[3], sBias + layer * FH, 2, lane, [&](int step) {
+          acc[0][2 * step] = h2_softplus(acc[0][2 * step]); acc[0][2 * step + 1] = h2_softplus(acc[0][2 * step + 1]);
+          acc[1][2 * step] = h2_softplus(acc[1][2 * step]); acc[1][2 * step + 1] = h2_softplus(acc[1][2 * step + 1]);
+        });
+        H2_STEP_END();
+        float* zp = zpl(layer);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int q = 0; q < 4; ++q) h2_epilogue_q<SAVE, false>(acc[0], bf[0], q, zp, qstride);
 #pragma unroll
-          for (int tq = 0; tq < 2; ++tq) {
-            const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * bi + 16 * s + 8 * tq + 4 * hf);
-            float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
-            u0 = __builtin_amdgcn_exp2f(u0 * u0 * c2); u1 = __builtin_amdgcn_exp2f(u1 * u1 * c2);
-            u2 = __builtin_amdgcn_exp2f(u2 * u2 * c2); u3 = __builtin_amdgcn_exp2f(u3 * u3 * c2);
-            unsigned h, l;
-            split2_pair(u0, u1, h, l);
-            bf[bi][s][0][2 * tq] = h; bf[bi][s][1][2 * tq] = l;
-            split2_pair(u2, u3, h, l);
-            bf[bi][s][0][2 * tq + 1] = h; bf[bi][s][1][2 * tq + 1] = l;
-          }
-    }
+        for (int q = 0; q < 4; ++q) h2_epilogue_q<SAVE, false>(acc[1], bf[1], q, zp + bstride, qstride);
+      }
+      {   // the last hidden layer's blocks 2 / 3 have no MFMAs left to hide under (the output layer needs all pieces)
+        float* zp = zpl(2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h2_epilogue_q<SAVE, true>(acc[2], bf[2], q, zp + 2 * bstride, qstride);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h2_epilogue_q<SAVE, true>(acc[3], bf[3], q, zp + 3 * bstride, qstride);
+      }
+    } else {
+    // ---- RBF straight into B fragments
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { rbf_unit(bi, s, 0); rbf_unit(bi, s, 1); }
     {   // distances of this workgroup's next tile
       const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, a.n_edges - 1);
       ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
@@ -281,25 +373,14 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
       }
       h2_hidden_chunk<true>(ring + use_s * SLOT + (WL ? H2_CHUNK : 0), bf, acc[2], acc[3], sBias + layer * FH, 2, lane, acc[0], acc[1]);
       H2_STEP_END();
-      // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
-      const int64_t wrow0 = tile * H2_TM + 32 * wave;
-      const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
       float* zl = SAVE ? a.z_save + (int64_t)layer * a.n_edges * FH : nullptr;
       float* zw = SAVE ? zl + wrow0 * FH : nullptr;
-      const bool full = rows_left >= 32;
-      float* zp = nullptr;
-      int bstride = 0, qstride = 0;
-      if (SAVE == 2) {
-        zp = full ? zl + (tile * 8 + wave) * 4096 + lane * 4
-                  : (l31 < rows_left ? zl + (wrow0 + l31) * FH + 4 * hf : a.dummy + 4 * hf);
-        bstride = full ? 1024 : 32;
-        qstride = full ? 256 : 8;
-      }
       float* tb = sT + wave * (32 * H2_TLD);
-      h2_epilogue<SAVE, false>(acc[0], bf[0], tb, zw, a.dummy, rows_left, lane, zp, qstride);
-      h2_epilogue<SAVE, false>(acc[1], bf[1], tb, zw + 32, a.dummy, rows_left, lane, zp + bstride, qstride);
-      h2_epilogue<SAVE, true>(acc[2], bf[2], tb, zw + 64, a.dummy, rows_left, lane, zp + 2 * bstride, qstride);
-      h2_epilogue<SAVE, true>(acc[3], bf[3], tb, zw + 96, a.dummy, rows_left, lane, zp + 3 * bstride, qstride);
+      h2_epilogue<SAVE, false>(acc[0], bf[0], tb, zw, a.dummy, rows_left, lane, nullptr, 0);
+      h2_epilogue<SAVE, false>(acc[1], bf[1], tb, zw + 32, a.dummy, rows_left, lane, nullptr, 0);
+      h2_epilogue<SAVE, true>(acc[2], bf[2], tb, zw + 64, a.dummy, rows_left, lane, nullptr, 0);
+      h2_epilogue<SAVE, true>(acc[3], bf[3], tb, zw + 96, a.dummy, rows_left, lane, nullptr, 0);
+    }
     }
     // ---- output layer: rows 0..E-1 of one 32-row block
     {
