@@ -187,7 +187,8 @@ __device__ __forceinline__ void h2_epilogue(const f32x16& acc, u32x4 (&bfo)[2][2
 // The same half layer with the caller's elementwise work handed in per step (fill(step), compile-time step): one wave
 // has to put its own VALU work into the shadow of its own MFMAs — up to five plain VALU instructions issue per
 // 32x32x16 MFMA for free (tools/ubench/mfma_fill.hip), while VALU work outside an MFMA sequence is not overlapped by the
-// partner wave either (the two waves of a SIMD run in lockstep between the layer barriers).
+// partner wave either (the two waves of a SIMD run in lockstep between the layer barriers).  The order inside a step is
+// the compiler's: explicit sched_group_barrier patterns (one MFMA, then 4-10 VALU, six times) measured 2-3 % slower.
 template <class F>
 __device__ __forceinline__ void h2_hidden_chunk_f(const char* slot, const u32x4 (&bf)[4][2][2], f32x16& acc0, f32x16& acc1,
                                                   const float* __restrict__ sb, int bo0, int lane, F&& fill) {
