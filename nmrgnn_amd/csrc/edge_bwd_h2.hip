@@ -129,6 +129,18 @@ __device__ __forceinline__ void hx_img_write(char* __restrict__ img, int row, in
   }
 }
 
+// one quarter of hx_img_write: columns col0 + 8q .. + 3 of one row
+template <int ROWB>
+__device__ __forceinline__ void hx_img_write_q(char* __restrict__ img, int row, int col0, int q, float v0, float v1,
+                                               float v2, float v3) {
+  unsigned h0, l0, h1, l1;
+  split2_pair(v0, v1, h0, l0);
+  split2_pair(v2, v3, h1, l1);
+  char* p = img + row * ROWB + (col0 + 8 * q) * 2;
+  *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(p + FTM * ROWB) = u32x2{l0, l1};
+}
+
 // one MFMA operand (8 consecutive edges of this lane's column) = two transposing reads of 4 edges each; `step` is
 // the byte distance between the two quads' first rows
 __device__ __forceinline__ u32x4 hx_tr_frag(const char* p, int step) {
@@ -193,8 +205,13 @@ __device__ __forceinline__ void hx_wload(u32x4 (&w)[2], __amdgpu_buffer_rsrc_t w
 // Returned lane layout: edge 32 zrt + (l&31), columns 32 zk + 8q + 4 (l>>5) + j  in register 4q + j.
 // w0 holds the W^T fragments of step 0 (requested by the caller before the preceding GEMM); steps ks+1 .. ks+3 are
 // in flight while step ks multiplies.
+// fill(ks): elementwise work of the caller that does not depend on this product, handed in per k-step so that it
+// issues in the shadow of the step's three MFMAs (an image build after the GEMM is VALU / LDS-store time nothing overlaps:
+// the partner wave of the SIMD runs its own copy of the same code).
+template <class F>
 __device__ __forceinline__ void hx_dz_gemm(float (&out)[16], const char* __restrict__ imgG, int prow_g,
-                                           __amdgpu_buffer_rsrc_t wrs, const u32x4 (&w0)[2], int L, int zk, int lane) {
+                                           __amdgpu_buffer_rsrc_t wrs, const u32x4 (&w0)[2], int L, int zk, int lane,
+                                           F&& fill) {
   const int half = lane >> 5;
   const char* gb = imgG + prow_g * HX_ROWG + 16 * half;
   const int wvo = lane * 16;
@@ -218,6 +235,7 @@ __device__ __forceinline__ void hx_dz_gemm(float (&out)[16], const char* __restr
       for (int p = 0; p < 2; ++p) b[(ks + 1) & 1][p] = *reinterpret_cast<const u32x4*>(gb + 32 * (ks + 1) + p * HX_PIECE_G);
     }
     acc0 = mma3(wa[ks & 3], b[ks & 1], acc0);
+    fill(ks);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
@@ -443,14 +461,19 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       // the wave whose epilogue comes NEXT gets the matrix pipe first (the arbiter otherwise favours the partner,
       // which then runs both of its GEMMs back to back and both epilogues end up side by side)
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
-      hx_dz_gemm(g, GA, prg, wrs, w0, 1, zk, lane);
+      // the Z1 pieces (IZb: nobody reads it in this phase) are written inside the product, a quarter row every other k-step
+      hx_dz_gemm(g, GA, prg, wrs, w0, 1, zk, lane, [&](int ks) {
+        if ((ks & 1) == 0) {
+          const int q = ks >> 1;
+          hx_img_write_q<HX_ROWZ>(IZb, prz, col0, q, z1r[4 * q], z1r[4 * q + 1], z1r[4 * q + 2], z1r[4 * q + 3]);
+        }
+      });
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
       HX_T(2);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z2r[r], z2r[r + 1]);
       hx_img_write<HX_ROWG>(GB, prg, col0, g);       // G2
     }
-    hx_img_write<HX_ROWZ>(IZb, prz, col0, z1r);      // Z1 pieces
     hx_wload(w0, wrs, lane * 16, ((0 * 4 + zk) * 8) * 2 * 1024, 0);
     HX_T(3);
     if (zrt != 0) hx_dw_gemm(accW[2], accB, 4, IZ, GA, kslab, nsl0, lane);
@@ -463,7 +486,20 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
     {
       float g[16];
       if (zrt != 0) __builtin_amdgcn_s_setprio(2);
-      hx_dz_gemm(g, GB, prg, wrs, w0, 0, zk, lane);
+      // R = m * rbf(d_eff) -> IZ (free since the barrier above) inside the product, a quarter row every other k-step
+      // (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
+      const float dm = on ? dn : 1.0e19f;
+      hx_dz_gemm(g, GB, prg, wrs, w0, 0, zk, lane, [&](int ks) {
+        if ((ks & 1) == 0) {
+          const int q = ks >> 1;
+          const float4 mu = *reinterpret_cast<const float4*>(sCen + col0 + 8 * q);
+          const float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
+          hx_img_write_q<HX_ROWZ>(IZ, prz, col0, q, __builtin_amdgcn_exp2f(u0 * u0 * a.neg_inv_gap_log2e),
+                                  __builtin_amdgcn_exp2f(u1 * u1 * a.neg_inv_gap_log2e),
+                                  __builtin_amdgcn_exp2f(u2 * u2 * a.neg_inv_gap_log2e),
+                                  __builtin_amdgcn_exp2f(u3 * u3 * a.neg_inv_gap_log2e));
+        }
+      });
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
       // next tile's Z3 / d / dE (registers dead since the head).  Issued BEHIND the last W^T fragment loads of the tile:
       // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
@@ -472,20 +508,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
 #pragma unroll
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z1r[r], z1r[r + 1]);
       hx_img_write<HX_ROWG>(GA, prg, col0, g);       // G1
-    }
-    {   // R = m * rbf(d_eff)  ->  IZ, free since the barrier above  (masked rows: d = 1e19 -> exp2(-inf) = exact 0, as in the forward)
-      float rr[16];
-      const float dm = on ? dn : 1.0e19f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 mu = *reinterpret_cast<const float4*>(sCen + col0 + 8 * q);
-        const float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
-        rr[4 * q + 0] = __builtin_amdgcn_exp2f(u0 * u0 * a.neg_inv_gap_log2e);
-        rr[4 * q + 1] = __builtin_amdgcn_exp2f(u1 * u1 * a.neg_inv_gap_log2e);
-        rr[4 * q + 2] = __builtin_amdgcn_exp2f(u2 * u2 * a.neg_inv_gap_log2e);
-        rr[4 * q + 3] = __builtin_amdgcn_exp2f(u3 * u3 * a.neg_inv_gap_log2e);
-      }
-      hx_img_write<HX_ROWZ>(IZ, prz, col0, rr);
     }
     HX_T(8);
     if (zrt != 0) hx_dw_gemm(accW[1], accB, 2, IZb, GB, kslab, nsl0, lane);
