@@ -285,7 +285,11 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     const float c2 = a.neg_inv_gap_log2e;
     // one RBF unit = the four dwords' worth of B fragment bf[bi][s][.][2 tq .. 2 tq + 1] (four centres of this lane)
     auto rbf_unit = [&](int bi, int s, int tq) {
-      const float4 mu = *reinterpret_cast<const float4*>(sCen + 32 * bi + 16 * s + 8 * tq + 4 * hf);
+      // (opaque offset: the centres are constants of the launch — left visible, the sixteen loads were hoisted out of the
+      // tile loop and their 64 registers spilled in the inference form)
+      int off = 32 * bi + 16 * s + 8 * tq + 4 * hf;
+      asm volatile("" : "+v"(off));
+      const float4 mu = *reinterpret_cast<const float4*>(sCen + off);
       float u0 = dm - mu.x, u1 = dm - mu.y, u2 = dm - mu.z, u3 = dm - mu.w;
       u0 = __builtin_amdgcn_exp2f(u0 * u0 * c2); u1 = __builtin_amdgcn_exp2f(u1 * u1 * c2);
       u2 = __builtin_amdgcn_exp2f(u2 * u2 * c2); u3 = __builtin_amdgcn_exp2f(u3 * u3 * c2);
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     const int64_t wrow0 = tile * H2_TM + 32 * wave;
     const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
     const bool full = rows_left >= 32;
-    if constexpr (SAVE == 2) {
+    if constexpr (SAVE != 1) {
       // ---- pipelined schedule (blocked tape: the training forward; the inference form spilled 56 B/lane with it).  The first chunk of a layer is 48 MFMAs with no
       // elementwise work of its own: it takes the RBF of the blocks it has not reached yet (layer 0) or the epilogue of
       // the previous layer's blocks 2 and 3 (their pieces are first needed at its step 4 / 6); the second chunk carries
@@ -414,7 +418,8 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
       if (valid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ne = r + 4 * hf;
+          int ne = r + 4 * hf;
+          asm volatile("" : "+v"(ne));      // (not a tile-loop invariant to be kept in — and spilled from — a register)
           if (ne < a.E) {
             const float v = mask * fmaf(acc[r], H2_WINV, sBo[ne]);
             bad |= not_finite(v);
