@@ -30,11 +30,26 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{lo, hi}, f16x2_cvt));
 }
 
-// (x0, x1) -> packed fp16 pieces; piece of x0 in the low half, of x1 in the high half
+// -1 as an fp16 value the optimizer cannot see through (an SGPR; the empty asm emits no instruction)
+__device__ __forceinline__ _Float16 h2_minus_one() {
+  int b = 0xBC00;
+  asm volatile("" : "+s"(b));
+  return __builtin_bit_cast(_Float16, (short)b);
+}
+
+// (x0, x1) -> packed fp16 pieces; piece of x0 in the low half, of x1 in the high half.
+// The residual x - (float)h is taken as fma((float)h, (float)(-1 as fp16), x): with BOTH multiplicands extended from fp16
+// the compiler selects v_fma_mix_f32 (fp16 sources by op_sel, fp32 addend) — one instruction per element instead of
+// v_cvt_f32_f16 + v_sub_f32; the difference is exact in fp32, so the single rounding changes nothing (same bits).  Four
+// instructions per pair instead of six.  v_fma_mix_f32 issues beside the 16-bit MFMA like any plain VALU instruction
+// (tools/ubench/mfma_fill.hip `fmamix`: 34.1 ... 36.1 cycles per MFMA with 1 ... 5 of them per gap), unlike the packed fp32
+// ops its VOP3P encoding shares.  (A visible -1.0f is folded back into a subtraction, an opaque FLOAT -1 makes the
+// compiler convert and use v_pk_fma_f32: round 2.)
 __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
   h = cvt_pk_f16(x0, x1);
   const f16x2_cvt hv = __builtin_bit_cast(f16x2_cvt, h);
-  const float r0 = x0 - (float)hv[0], r1 = x1 - (float)hv[1];     // exact (v_cvt_f32_f16 x2 + v_pk_add_f32)
+  const float m1 = (float)h2_minus_one();
+  const float r0 = __builtin_fmaf((float)hv[0], m1, x0), r1 = __builtin_fmaf((float)hv[1], m1, x1);
   l = cvt_pk_f16(r0, r1);
 }
 
