@@ -114,17 +114,15 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t N, int C, in
   for (int c = 0; c < CM; ++c) { acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f; db[c] = 0.f; }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
-  for (int64_t i = r0 + r; i < r1; i += RL) {
-    float4 x = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
-    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (mask) m = *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q);
+  // two rows per trip: both rows' loads (features, mask, dpeaks, one-hot row) are requested before either row is
+  // worked on (one row per trip ran a memory round trip per row); the sums keep their row order
+  auto row_body = [&](int64_t i, float4 x, const float4& m, float dp, const float (&av)[CM]) {
     x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
-    const float dp = dpeaks[i];
     float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
       if (c < C) {
-        const float a = atoms[i * C + c];
+        const float a = av[c];
         u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
         u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
         const float d = dp * a * sStd[c];            // dfull[i][c]
@@ -134,6 +132,27 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t N, int C, in
     }
     *reinterpret_cast<float4*>(dg + i * Fh + 4 * q) = make_float4(m.x * dp * u0, m.y * dp * u1, m.z * dp * u2,
                                                                   m.w * dp * u3);
+  };
+  for (int64_t i = r0 + r; i < r1; i += 2 * RL) {
+    const int64_t i2 = i + RL;
+    const bool two = i2 < r1;
+    const int64_t j2 = two ? i2 : i;
+    const float4 xa = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
+    const float4 xb = *reinterpret_cast<const float4*>(g + j2 * Fh + 4 * q);
+    float4 ma = make_float4(1.f, 1.f, 1.f, 1.f), mb = ma;
+    if (mask) {
+      ma = *reinterpret_cast<const float4*>(mask + i * Fh + 4 * q);
+      mb = *reinterpret_cast<const float4*>(mask + j2 * Fh + 4 * q);
+    }
+    const float dpa = dpeaks[i], dpb = dpeaks[j2];
+    float aa[CM], ab[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+      aa[c] = c < C ? atoms[i * C + c] : 0.f;
+      ab[c] = c < C ? atoms[j2 * C + c] : 0.f;
+    }
+    row_body(i, xa, ma, dpa, aa);
+    if (two) row_body(i2, xb, mb, dpb, ab);
   }
   // sum over the row lanes through LDS, one partial per workgroup: layout [f*C + c] then [Fh*C + c]
   const int items = Fh * C + C;
@@ -169,14 +188,26 @@ __global__ __launch_bounds__(256) void embed_bwd_fast_kernel(int64_t N, int C, i
   for (int c = 0; c < CM; ++c) acc[c] = f4zero();
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = std::min<int64_t>(r0 + rows_per_block, N);
-  for (int64_t i = r0 + r; i < r1; i += RL) {
+  // two rows per trip, both rows' loads requested before either is used (the sums keep their row order)
+  for (int64_t i = r0 + r; i < r1; i += 2 * RL) {
+    const int64_t i2 = i + RL;
+    const bool two = i2 < r1;
+    const int64_t j2 = two ? i2 : i;
     const float4 d = *reinterpret_cast<const float4*>(dh0 + i * F + 4 * q);
+    const float4 d2 = *reinterpret_cast<const float4*>(dh0 + j2 * F + 4 * q);
+    float a1[CM], a2[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
-      if (c < C) {
-        const float a = atoms[i * C + c];
-        acc[c].x += a * d.x; acc[c].y += a * d.y; acc[c].z += a * d.z; acc[c].w += a * d.w;
-      }
+      a1[c] = c < C ? atoms[i * C + c] : 0.f;
+      a2[c] = (c < C && two) ? atoms[j2 * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+      if (c < C) { acc[c].x += a1[c] * d.x; acc[c].y += a1[c] * d.y; acc[c].z += a1[c] * d.z; acc[c].w += a1[c] * d.w; }
+    if (two) {
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) { acc[c].x += a2[c] * d2.x; acc[c].y += a2[c] * d2.y; acc[c].z += a2[c] * d2.z; acc[c].w += a2[c] * d2.w; }
     }
   }
   const int items = C * F;
