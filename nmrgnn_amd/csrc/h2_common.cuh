@@ -25,7 +25,7 @@ typedef float f32x2_cvt __attribute__((ext_vector_type(2)));
 // LLVM's hazard recognizer does not apply the MFMA-related wait states (XDL write -> VALU, SrcC read -> VALU write, ...)
 // to instructions hidden inside an asm statement; when the scheduler interleaved asm conversions with an MFMA chain
 // (round 2, bf16 version of these kernels) ~16 % of the edges came out different from run to run by up to 6e-6
-// (tools/dbg_det.py, tests/test_gpu_determinism.py).
+// (tests/test_gpu_determinism.py).
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{lo, hi}, f16x2_cvt));
 }
