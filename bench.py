@@ -483,7 +483,12 @@ def main():
         "metric": "atoms/s (fwd+bwd) on 256-atom/16-neighbor synthetic graphs",
         "value": value, "unit": "atoms/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None,
+        # the arithmetic type of the multiplier, not a precision claim: fp32 operands, each carried as two fp16 pieces
+        # (22-bit significand), three piece products per multiply on the fp16 matrix pipe, fp32 accumulate; the step on
+        # f32-input MFMA only is `fp32_mfma_only` below
+        "dtype": ("f32 (f32-input MFMA)" if os.environ.get("NG_EDGE_MATH", "") == "fp32"
+                  else "f32 (2xf16-piece MFMA, f32 accumulate)"), "data": "synthetic",
         "config": {"workload": (f"configs[2]/[3]: training step (fwd+loss+bwd+all-reduce+Adam) on "
                                 + (f"{args.total_graphs} graphs in total" if args.scaling == "strong"
                                    else f"{args.graphs} graphs per GPU")
@@ -491,7 +496,9 @@ def main():
                                   f"layers, noise+dropout on"),
                    "atoms_total": atoms_total, "atoms_this_rank": atoms_local, "edges_this_rank": gb.n_edges,
                    "parallelism": f"graph-parallel dp{world}", "params": eng.params.count(),
-                   "backend": backend, "world_size": world, "collective_library": collective_library(backend)},
+                   "backend": backend, "world_size": world, "collective_library": collective_library(backend),
+                   # dmabuf IPC between the ranks' processes: what RCCL's intra-node transport needs here
+                   "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
         "ms_per_step_hipevent_median": float(np.median(ev_ms)),
         "ms_per_step_hipevent_min": float(np.min(ev_ms)),
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},

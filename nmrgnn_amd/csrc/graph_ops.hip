@@ -23,13 +23,15 @@ constexpr int GL_SCAN_ITEMS = 4;                       // per thread
 constexpr int GL_SCAN_TILE = GL_BLOCK * GL_SCAN_ITEMS;  // 1024 counts per scan block
 
 // one thread per entry: histogram of live targets; the compute-side list (padded slots -> the atom itself)
-__global__ __launch_bounds__(GL_BLOCK) void gl_count_kernel(int64_t n_entries, int K, const int32_t* __restrict__ nlist,
+// An entry whose target lies outside [0, N) is treated like a padded slot (dropped from the incoming lists, compute-side
+// index = the atom itself): with validate=False nothing else stands between a bad index and an out-of-bounds atomic.
+__global__ __launch_bounds__(GL_BLOCK) void gl_count_kernel(int64_t n_entries, int64_t N, int K, const int32_t* __restrict__ nlist,
                                                             const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
                                                             int32_t* __restrict__ count) {
   const int64_t eid = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
   if (eid >= n_entries) return;
   const int32_t t = nlist[eid];
-  const bool live = edges == nullptr || edges[eid] > 0.f;
+  const bool live = (edges == nullptr || edges[eid] > 0.f) && t >= 0 && t < N;
   if (nlist_c) nlist_c[eid] = live ? t : (int32_t)(eid / K);
   if (live) atomicAdd(&count[t], 1);
 }
@@ -95,13 +97,15 @@ __global__ __launch_bounds__(GL_BLOCK) void gl_scan_apply_kernel(int64_t n, cons
 }
 
 // unordered fill: entry eid goes to the next free slot of its target
-__global__ __launch_bounds__(GL_BLOCK) void gl_fill_kernel(int64_t n_entries, const int32_t* __restrict__ nlist,
+__global__ __launch_bounds__(GL_BLOCK) void gl_fill_kernel(int64_t n_entries, int64_t N, const int32_t* __restrict__ nlist,
                                                            const float* __restrict__ edges, int32_t* __restrict__ cursor,
                                                            int32_t* __restrict__ tmp) {
   const int64_t eid = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
   if (eid >= n_entries) return;
   if (edges != nullptr && !(edges[eid] > 0.f)) return;
-  const int pos = atomicAdd(&cursor[nlist[eid]], 1);
+  const int32_t t = nlist[eid];
+  if (t < 0 || t >= N) return;
+  const int pos = atomicAdd(&cursor[t], 1);
   tmp[pos] = (int32_t)eid;
 }
 
@@ -205,14 +209,14 @@ extern "C" int ng_build_incoming_lists(ng_ctx* ctx, void* stream, int64_t N, int
   ProfScope ps(ctx, st, "incoming_lists");
   NG_HIP(ctx, hipMemsetAsync(count, 0, (size_t)N * sizeof(int32_t), st));
   if (n_entries > 0)
-    hipLaunchKernelGGL(gl_count_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, K, nlist, edges,
+    hipLaunchKernelGGL(gl_count_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, N, K, nlist, edges,
                        nlist_c, count);
   hipLaunchKernelGGL(gl_scan_local_kernel, dim3(nb), dim3(GL_BLOCK), 0, st, N, count, bsum);
   hipLaunchKernelGGL(gl_scan_sums_kernel, dim3(1), dim3(GL_BLOCK), 0, st, nb, bsum);
   hipLaunchKernelGGL(gl_scan_apply_kernel, dim3((unsigned)cdiv(N, GL_BLOCK)), dim3(GL_BLOCK), 0, st, N, count, bsum, csc_ptr,
                      cursor);
   if (n_entries > 0)
-    hipLaunchKernelGGL(gl_fill_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, nlist, edges,
+    hipLaunchKernelGGL(gl_fill_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, N, nlist, edges,
                        cursor, tmp);
   hipLaunchKernelGGL(gl_sort_kernel, dim3((unsigned)cdiv(N, GL_BLOCK)), dim3(GL_BLOCK), 0, st, N, cursor, csc_ptr, tmp, csc_edge);
   NG_HIP(ctx, hipGetLastError());

@@ -494,6 +494,10 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
 //   count:  deg[row]                               -> the caller's exclusive scan gives row_ptr
 //   fill :  col (batch-global), dist*scale, inv_degree = 1/#(local neighbour index > 0)  (library.py:115-116)
 constexpr int CUT_TILE = 1024;
+// ONE explicit fused-multiply-add chain for the squared distance (the expression of knn.hip's knn_dist2): the count and
+// the fill pass — and the one-thread and 16-lane forms — must agree bit for bit on `d2 < cutoff2`, because rows are sized
+// by the count and then filled; left to -ffp-contract two instantiations may round differently by an ulp.
+__device__ __forceinline__ float cut_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float scale, const float* __restrict__ pos,
@@ -508,8 +512,8 @@ __global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float
   if (i < n) { qx = fp[3 * i]; qy = fp[3 * i + 1]; qz = fp[3 * i + 2]; }
   const int64_t row = (int64_t)frame * n + i;
   int cnt = 0, cnt_pos = 0;
-  int64_t out = 0;
-  if (FILL && i < n) out = row_ptr[row];
+  int64_t out = 0, lim = 0;          // a row never writes past its own extent, whatever the count pass saw
+  if (FILL && i < n) { out = row_ptr[row]; lim = row_ptr[row + 1]; }
   for (int t0 = 0; t0 < n; t0 += CUT_TILE) {
     const int m = min(CUT_TILE, n - t0);
     __syncthreads();
@@ -520,10 +524,10 @@ __global__ __launch_bounds__(256) void cutoff_kernel(int n, float cutoff2, float
     if (i < n) {
       for (int t = 0; t < m; ++t) {
         const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float d2 = cut_dist2(dx, dy, dz);
         const int j = t0 + t;
         if (d2 < cutoff2 && j != i) {
-          if (FILL) {
+          if (FILL && out + cnt < lim) {
             col[out + cnt] = frame * n + j;
             dist[out + cnt] = sqrtf(d2) * scale;
             if (row_of) row_of[out + cnt] = (int32_t)row;
@@ -557,8 +561,8 @@ __global__ __launch_bounds__(256) void cutoff_s16_kernel(int n, float cutoff2, f
   const float qx = fp[3 * ic], qy = fp[3 * ic + 1], qz = fp[3 * ic + 2];
   const int64_t row = (int64_t)frame * n + i;
   int cnt = 0, cnt_pos = 0;
-  int64_t out = 0;
-  if (FILL && i < n) out = row_ptr[row];
+  int64_t out = 0, lim = 0;          // a row never writes past its own extent, whatever the count pass saw
+  if (FILL && i < n) { out = row_ptr[row]; lim = row_ptr[row + 1]; }
   for (int t0 = 0; t0 < n; t0 += CUT_TILE) {
     const int m = min(CUT_TILE, n - t0);
     __syncthreads();
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(256) void cutoff_s16_kernel(int n, float cutoff2, f
         d2[u] = 0.f;
         if (t < m && i < n) {
           const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
-          d2[u] = dx * dx + dy * dy + dz * dz;
+          d2[u] = cut_dist2(dx, dy, dz);
           hit[u] = d2[u] < cutoff2 && t0 + t != i;
         }
       }
@@ -592,8 +596,8 @@ __global__ __launch_bounds__(256) void cutoff_s16_kernel(int n, float cutoff2, f
         const int j = t0 + c0 + 16 * u + s;
         const unsigned long long b = __ballot(hit[u]);
         const unsigned mine = (unsigned)(b >> (16 * grp)) & 0xFFFFu;
-        if (FILL && hit[u]) {
-          const int p = cnt + __popc(mine & ((1u << s) - 1u));
+        const int p = cnt + __popc(mine & ((1u << s) - 1u));
+        if (FILL && hit[u] && out + p < lim) {
           col[out + p] = frame * n + j;
           dist[out + p] = sqrtf(d2[u]) * scale;
           if (row_of) row_of[out + p] = (int32_t)row;

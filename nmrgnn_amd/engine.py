@@ -200,7 +200,9 @@ class Engine:
         Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
         Bfc = [P[f"fc/{t}/bias"] for t in range(self.Lf)]
         # molecule-sized inference: FC block + head in ONE launch (csrc/frame_fused.hip)
-        if not tape and N <= FUSED_TAIL_MAX_ATOMS and lib.ng_fc_head_ok(N, F, self.Lf, self.C, self.fc_act):
+        # (not for a training-mode forward without a tape: the fused tail has no dropout, the layered path applies it)
+        if not tape and not (training and self.use_dropout) and N <= FUSED_TAIL_MAX_ATOMS \
+                and lib.ng_fc_head_ok(N, F, self.Lf, self.C, self.fc_act):
             peaks = self._new(N)
             self._ck(lib.ng_fc_head_fwd(h, st, N, F, self.Lf, self.C, self.fc_act, ptr(hs[-1]), ptr_array(Wfc), ptr_array(Bfc),
                                         ptr(P["out/kernel"]), ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),

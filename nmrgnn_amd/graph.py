@@ -23,6 +23,17 @@ import numpy as np
 import torch
 
 
+def _norm_device(device):
+    """torch.device with an explicit index for cuda ('cuda' / torch.device('cuda') name the current device): the
+    library's per-device context is looked up by index"""
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def _to_dev(x, dtype, device):
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=dtype).contiguous()
@@ -36,9 +47,7 @@ class GraphBatch:
 
     def __init__(self, atoms, nlist, edges, inv_degree, graph_ptr=None, device=None,
                  validate=True, nlist_c=None):
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        self.device = torch.device(device)
+        self.device = _norm_device(device)
         self.atoms = _to_dev(atoms, torch.float32, self.device)
         self.nlist = _to_dev(nlist, torch.int32, self.device)
         self.edges = _to_dev(edges, torch.float32, self.device)
@@ -78,9 +87,7 @@ class GraphBatch:
         atom, batch-global) and ``dist`` (distance > 0).  ``inv_degree`` defaults to the reference's rule
         1 / #(graph-local neighbour index > 0), 0 when that count is 0 (nmrgnn/library.py:115-116)."""
         self = cls.__new__(cls)
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        self.device = torch.device(device)
+        self.device = _norm_device(device)
         self.is_csr = True
         self.atoms = _to_dev(atoms, torch.float32, self.device)
         if self.atoms.dim() != 2:
@@ -223,9 +230,7 @@ def frames_to_batch(atoms, frames, neighbor_number=16, scale=0.1, device=None):
     import ctypes as C
     from . import _lib
     from ._lib import ptr
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    device = torch.device(device)
+    device = _norm_device(device)
     pos = _to_dev(np.asarray(frames, dtype=np.float32) if not isinstance(frames, torch.Tensor) else frames,
                   torch.float32, device)
     if pos.dim() == 2:
@@ -256,9 +261,7 @@ def frames_to_batch_cutoff(atoms, frames, cutoff=4.0, scale=0.1, device=None):
     import ctypes as C
     from . import _lib
     from ._lib import ptr
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    device = torch.device(device)
+    device = _norm_device(device)
     pos = _to_dev(np.asarray(frames, dtype=np.float32) if not isinstance(frames, torch.Tensor) else frames,
                   torch.float32, device)
     if pos.dim() == 2:
@@ -274,8 +277,10 @@ def frames_to_batch_cutoff(atoms, frames, cutoff=4.0, scale=0.1, device=None):
         ctx.check(ctx.lib.ng_cutoff_count(ctx.handle, st, G, n, float(cutoff), ptr(pos), ptr(deg)), "ng_cutoff_count")
         row_ptr = torch.empty(G * n + 1, dtype=torch.int32, device=device)
         ctx.check(ctx.lib.ng_exclusive_scan_i32(ctx.handle, st, G * n, ptr(deg), ptr(row_ptr)), "ng_exclusive_scan_i32")
-        nnz = int(row_ptr[-1])                      # the one host synchronisation: the list length sizes the buffers
-        if nnz < 0:
+        # the one host synchronisation: the list length sizes the buffers.  Summed in int64 — the device scan is int32
+        # and a total of 2^32 or more would wrap back to a plausible positive number
+        nnz = int(deg.sum(dtype=torch.int64))
+        if nnz >= 2 ** 31:
             raise ValueError("cutoff graph: more than 2^31 edges in one batch")
         col = torch.empty(nnz, dtype=torch.int32, device=device)
         dist = torch.empty(nnz, dtype=torch.float32, device=device)
