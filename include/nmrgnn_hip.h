@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 5
+#define NG_ABI_VERSION 6
 
 enum {
   NG_OK = 0,
@@ -137,6 +137,35 @@ int ng_edge_mlp_bwd_tape(ng_ctx*, void* stream, int64_t n_edges, int H, int E, i
                          const float* d_src, const float* d_eff, const float* centers, float gap,
                          const float* const* W, const float* z_save, const float* de,
                          float* const* dW, float* const* db, int tape_layout);
+
+/* ---- the edge path over the LIVE slots of a padded list (ABI 6) -----------------------------------------------
+ * A padded slot (edges == 0) yields e == 0 and contributes to no gradient: the mask multiplies the RBF and the MLP
+ * output (nmrgnn/model.py:251,257,261).  The fused edge kernels can therefore skip such slots entirely: results are the
+ * ones of ng_edge_mlp_fwd / _bwd (e bit for bit; weight gradients up to the summation order over edges).
+ *   ng_build_live_edges: a stable partition of the n_slots = N*K slots, once per batch, no host synchronisation:
+ *     perm  [n_slots]  the live slots (edges > 0) in ascending order, then the dead ones
+ *     pos   [n_slots]  row of slot g in the compacted order, -1 for a dead slot
+ *     d_c   [n_slots]  d_c[r] = edges[perm[r]] for r < n_live: the compacted distances
+ *     n_live[1]        device scalar
+ *   ng_add_noise_live: GaussianNoise into the compacted order, out_c[pos[g]] = x[g] + alpha * xi_g with the xi_g of
+ *     ng_add_noise(seed, offset) (y == NULL) or xi_g = y[g] (explicit draws); dead slots are skipped.
+ *   ng_edge_mlp_fwd_live / _bwd_live: d_src_c / d_eff_c are the COMPACTED distances (n_live rows; d_eff_c = d_src_c
+ *     for inference); e_out and de keep the caller's [n_slots, E] layout (dead slots of e_out are written 0);
+ *     z_save [Le-1, n_slots, H]: layer stride as for n_slots rows, the first n_live rows of every layer used.
+ *   ng_edge_live_supported: 1 when this shape runs the fused edge path (the only one with a live view). */
+int ng_build_live_edges(ng_ctx*, void* stream, int64_t n_slots, const float* edges, int32_t* perm, int32_t* pos,
+                        float* d_c, int32_t* n_live);
+int ng_add_noise_live(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, int64_t n, const float* x, const float* y,
+                      float alpha, const int32_t* pos, float* out_c);
+int ng_edge_live_supported(int H, int E, int Le, int act);
+int ng_edge_mlp_fwd_live(ng_ctx*, void* stream, int64_t n_slots, int H, int E, int Le, int act,
+                         const float* d_src_c, const float* d_eff_c, const int32_t* perm, const int32_t* n_live,
+                         const float* centers, float gap, const float* const* W, const float* const* b,
+                         float* e_out, float* z_save);
+int ng_edge_mlp_bwd_live(ng_ctx*, void* stream, int64_t n_slots, int H, int E, int Le, int act,
+                         const float* d_src_c, const float* d_eff_c, const int32_t* perm, const int32_t* n_live,
+                         const float* centers, float gap, const float* const* W, const float* z_save,
+                         const float* de, float* const* dW, float* const* db, int tape_layout);
 
 /* ---- node path ----------------------------------------------------------------------------- */
 /* embed_layer, nmrgnn/model.py:241,262: h0 = atoms[N,C] @ Wemb[C,F] */

@@ -52,6 +52,13 @@ SIGNATURES = {
                                C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "ng_edge_mlp_bwd_tape": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                     C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _int]),
+    "ng_build_live_edges": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ng_add_noise_live": (_int, [_vp, _vp, _u64, _u64, _i64, _vp, _vp, _f, _vp, _vp]),
+    "ng_edge_live_supported": (_int, [_int, _int, _int, _int]),
+    "ng_edge_mlp_fwd_live": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _f,
+                                    C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
+    "ng_edge_mlp_bwd_live": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _f,
+                                    C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _int]),
     "ng_embed_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "ng_embed_bwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "ng_mp_aggregate": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
@@ -125,7 +132,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 5:
+        if lib.ng_abi_version() != 6:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

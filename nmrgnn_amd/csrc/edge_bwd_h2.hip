@@ -95,6 +95,12 @@ struct EdgeBwdH2Args {
   int tape_blocked;     // z_save layout: 1 = blocked inside full 32-edge groups (edge_fused.h), 0 = row-major
   unsigned long long* stamps;
   RangeGuard guard;     // raised when a partial comes out non-finite (an operand left the fp16 range)
+  // live-edge view (ng_internal.h: LiveEdges; kernel template LIVE): the rows of this launch are the compacted live
+  // slots [row_base, row_base + n_edges) clipped to *n_live; d_eff and the tape are compacted (this segment's part), `de`
+  // is the caller's full [n_slots][E] array, row r reads de[perm[r]]; d_src is not read (every row is live)
+  const int32_t* perm;     // first row of THIS segment
+  const int32_t* n_live;
+  int64_t row_base;
 };
 
 // W^T fragments of the dZ GEMMs: lane (row k = 32 zk + (l&31), k-slot t) = piece_p( 2^8 W[k][n = 16 ks + 8 (l>>5) + t] )
@@ -281,6 +287,7 @@ __device__ __forceinline__ void hx_sprime2(float& x0, float& x1, float z0, float
 #define HX_T(k)
 #endif
 
+template <bool LIVE>
 __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_hx[];
   // images: Z-type x at smem + x * HX_IMG_Z, G-type x at smem + 2 * HX_IMG_Z + x * HX_IMG_G (roles alternate per tile)
@@ -302,8 +309,10 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   const int prz = hx_prow_z(row), prg = hx_prow_g(row); // where that row lives in the images
   const int E = a.E;
   const float gscale = a.scale[0], ginv = a.scale[1];   // gradients run scaled by a power of two (header)
+  // rows of this launch (LIVE: the segment's share of the compacted live rows, a device scalar)
+  const int64_t n_edges = LIVE ? std::max<int64_t>(0, std::min<int64_t>(a.n_edges, (int64_t)*a.n_live - a.row_base)) : a.n_edges;
   // tape offsets of this wave's block for the tile starting at ROW0 (see hx_load_z)
-#define HX_ZFULL(ROW0) (a.tape_blocked && (ROW0) + 32 * zrt + 32 <= a.n_edges)
+#define HX_ZFULL(ROW0) (a.tape_blocked && (ROW0) + 32 * zrt + 32 <= n_edges)
 #define HX_ZOFF(ROW0, GI) (HX_ZFULL(ROW0) ? (int)(((ROW0) / 32 + zrt) * 16384 + (zk * 256 + lane) * 16) : (GI) * (FH * 4) + col0 * 4)
 #define HX_ZQ(ROW0) (HX_ZFULL(ROW0) ? 1024 : 32)
 
@@ -328,40 +337,58 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   float accWo[4] = {0.f, 0.f, 0.f, 0.f};
   float accbo[4] = {0.f, 0.f, 0.f, 0.f};     // sum of this lane's row of dE over the tiles (8 lanes hold each row)
 
-  const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
+  const int64_t ntiles = (n_edges + FTM - 1) / FTM;
   // one buffer resource per array (offsets are 32-bit: n_edges * 512 B < 4 GB, checked by the host)
-  const unsigned zbytes = (unsigned)(a.n_edges * FH * 4);
+  const unsigned zbytes = (unsigned)(n_edges * FH * 4);
   const __amdgpu_buffer_rsrc_t rsZ1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save), 0, zbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsZ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + a.z_layer_stride), 0, zbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsZ3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z_save + 2 * a.z_layer_stride), 0, zbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_src), 0, (unsigned)(a.n_edges * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsDn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_eff), 0, (unsigned)(a.n_edges * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsDe = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.de), 0, (unsigned)(a.n_edges * a.E * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_src), 0, (unsigned)(n_edges * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d_eff), 0, (unsigned)(n_edges * 4), 0x00020000);
+  // LIVE: de is the caller's whole [n_slots][E] array, addressed by slot (n_slots * E * 4 < 2^32: checked by the host)
+  const __amdgpu_buffer_rsrc_t rsDe = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.de), 0, LIVE ? 0xFFFFFFFFu : (unsigned)(n_edges * a.E * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsPm = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.perm), 0, LIVE ? (unsigned)(n_edges * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wt_img), 0, 2 * 4 * 8 * 2 * 1024, 0x00020000);
   __syncthreads();
 
   // per-tile inputs of this lane's row, requested one tile ahead
-  float z3r[16], z2r[16], pf_ds, pf_dn, pf_de[4];
+  float z3r[16], z2r[16], pf_ds = 1.f, pf_dn, pf_de[4];
+  // LIVE: the slot of this lane's row, requested TWO tiles ahead (by the prefetch of the tile before): as an address of
+  // the de loads it must be in a register when they are issued — a load that waits for another load inside the prefetch
+  // would stall in front of the GEMM the prefetch hides under
+  int pf_slot = 0;
+  auto load_slot = [&](int64_t row0) {
+    const int gi = (int)std::max<int64_t>(std::min<int64_t>(row0 + row, n_edges - 1), 0);
+    pf_slot = (int)__builtin_amdgcn_raw_buffer_load_b32(rsPm, gi * 4, 0, 0);
+  };
   // Nothing here may USE a loaded value (no select, no conversion): a use inside this block makes the compiler
   // wait for the HBM loads right behind their issue, in front of the GEMM they are meant to hide under.  Indices are
   // clamped, the masks are applied at the point of use in the next iteration.
-  auto prefetch = [&](int64_t row0) {
-    const int64_t gr = std::min<int64_t>(row0 + row, a.n_edges - 1);
+  auto prefetch = [&](int64_t row0, int64_t row0_after) {
+    const int64_t gr = std::min<int64_t>(row0 + row, n_edges - 1);
     const int gi = (int)gr;
     hx_load_z(z3r, rsZ3, HX_ZOFF(row0, gi), HX_ZQ(row0));
-    pf_ds = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDs, gi * 4, 0, 0));
+    if (!LIVE) pf_ds = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDs, gi * 4, 0, 0));
     pf_dn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDn, gi * 4, 0, 0));
+    const int ge = LIVE ? pf_slot : gi;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
-      pf_de[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDe, (gi * E + std::min(n, E - 1)) * 4, 0, 0));
+      pf_de[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDe, (ge * E + std::min(n, E - 1)) * 4, 0, 0));
+    if (LIVE) load_slot(row0_after);
   };
   // Z2 of the next tile: its registers are free only after phase B's epilogue
   auto prefetch_z2 = [&](int64_t row0) {
-    const int gi = (int)std::min<int64_t>(row0 + row, a.n_edges - 1);
+    const int gi = (int)std::min<int64_t>(row0 + row, n_edges - 1);
     hx_load_z(z2r, rsZ2, HX_ZOFF(row0, gi), HX_ZQ(row0));
   };
-  if ((int64_t)blockIdx.x < ntiles) { prefetch((int64_t)blockIdx.x * FTM); prefetch_z2((int64_t)blockIdx.x * FTM); }
+  // first row of the tile `steps` grid strides after `tile`, clamped to the last tile
+  auto row0_of = [&](int64_t tile, int steps) { return std::min<int64_t>(tile + (int64_t)steps * gridDim.x, ntiles - 1) * FTM; };
+  if ((int64_t)blockIdx.x < ntiles) {
+    if (LIVE) load_slot((int64_t)blockIdx.x * FTM);      // (the one place the slot load is waited for: once per launch)
+    prefetch((int64_t)blockIdx.x * FTM, row0_of(blockIdx.x, 1));
+    prefetch_z2((int64_t)blockIdx.x * FTM);
+  }
 
   // ---- the head of a tile ("phase A": mask, dE, fp32 Z3 staging, dWo / dbo on the VALU, G3, the Z2 image) in three
   // steps separated by barriers.  For every tile but a workgroup's first it runs INSIDE phase D of the tile before
@@ -372,7 +399,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   float dEm[4];
   // step 1: this lane's row of the tile whose inputs sit in pf_* / z3r; `live` = 0 on the pass past the last tile
   auto head1 = [&](int64_t row0, bool live, char* Zn, bool& on_o, float& dn_o) {
-    on_o = live && pf_ds > 0.f && row0 + row < a.n_edges;
+    on_o = live && pf_ds > 0.f && row0 + row < n_edges;
     dn_o = pf_dn;
 #pragma unroll
     for (int n = 0; n < 4; ++n) dEm[n] = (on_o && n < E) ? gscale * pf_de[n] : 0.f;
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   // phase with that GEMM waited an HBM round trip for L2 hits.
   float z1r[16];
   auto load_z1 = [&](int64_t row0) {
-    const int gi = (int)std::min<int64_t>(row0 + row, a.n_edges - 1);
+    const int gi = (int)std::min<int64_t>(row0 + row, n_edges - 1);
     hx_load_z(z1r, rsZ1, HX_ZOFF(row0, gi), HX_ZQ(row0));
   };
   if ((int64_t)blockIdx.x < ntiles) {      // the first tile's head stands alone
@@ -503,7 +530,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
       if (zrt != 0) __builtin_amdgcn_s_setprio(0);
       // next tile's Z3 / d / dE (registers dead since the head).  Issued BEHIND the last W^T fragment loads of the tile:
       // memory returns in order, a fragment load queued behind these HBM loads would wait for all of them.
-      prefetch(row0n);
+      prefetch(row0n, row0_of(tile, 2));
       HX_T(7);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) hx_sprime2(g[r], g[r + 1], z1r[r], z1r[r + 1]);
@@ -679,7 +706,8 @@ size_t edge_bwd_h2_ws_bytes() { return HX_WT_BYTES + (size_t)(HX_SCALE_BLOCKS + 
 // wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_h2_segments(n_edges) * grid][part_stride]
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard) {
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard,
+                       LiveEdges live) {
   float* blockmax = reinterpret_cast<float*>(wt_img + HX_WT_BYTES);
   float* scale = blockmax + HX_SCALE_BLOCKS;
   {
@@ -696,7 +724,9 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     EdgeBwdH2Args a;
     a.n_edges = std::min<int64_t>(HX_SEG_EDGES, n_edges - e0); a.d_src = d_src + e0; a.d_eff = d_eff + e0; a.centers = centers;
     a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
-    a.wt_img = wt_img; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH; a.de = de + e0 * E;
+    a.wt_img = wt_img; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH;
+    a.de = live.perm ? de : de + e0 * E;
+    a.perm = live.perm ? live.perm + e0 : nullptr; a.n_live = live.n_live; a.row_base = e0;
     a.partial = partial + (size_t)sg * grid * part_stride; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;
     a.stamps = nullptr;
     a.guard = guard;
@@ -706,7 +736,10 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     a.stamps = dbg;
 #endif
     ProfScope ps(ctx, st, "edge_bwd_h2");
-    hipLaunchKernelGGL(edge_bwd_h2_kernel, dim3(grid), dim3(HX_THREADS), HX_LDS_BYTES, st, a);
+    if (live.perm)
+      hipLaunchKernelGGL(edge_bwd_h2_kernel<true>, dim3(grid), dim3(HX_THREADS), HX_LDS_BYTES, st, a);
+    else
+      hipLaunchKernelGGL(edge_bwd_h2_kernel<false>, dim3(grid), dim3(HX_THREADS), HX_LDS_BYTES, st, a);
     NG_HIP(ctx, hipGetLastError());
     if (sg + 1 < nseg) continue;
 #ifdef HX_STAMP

@@ -17,7 +17,8 @@ int edge_fused_pack(ng_ctx* ctx, hipStream_t st, const float* const* W, float* W
 namespace ng {
 int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
-                   const float* z_save, const float* de, float* const* dW, float* const* db, int tape_layout = -1);
+                   const float* z_save, const float* de, float* const* dW, float* const* db, int tape_layout = -1,
+                   LiveEdges live = LiveEdges());
 }  // namespace ng
 
 // Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also drains vmcnt(0), which
@@ -37,7 +38,7 @@ namespace ng {
 bool edge_split_enabled();
 int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
-                float* z_save);
+                float* z_save, LiveEdges live = LiveEdges());
 bool edge_bwd_h2_supported(int E, int64_t n_edges);
 int edge_bwd_h2_segments(int64_t n_edges);
 // Layout of the saved-activation tape z_save[Le-1][n_edges][128] between the edge forward and backward:
@@ -50,5 +51,6 @@ size_t edge_bwd_h2_ws_bytes();
 // layout of edge_fused_bwd.hip
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
-                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard);
+                       char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard,
+                       LiveEdges live = LiveEdges());
 }  // namespace ng

@@ -69,6 +69,10 @@ struct EdgeFwdArgs {
   float* dummy;           // 128 floats: where rows past the end store
   int tape_blocked;       // z_save layout (edge_fused.h: edge_tape_blocked): 1 = the split-operand kernels' blocked form
   RangeGuard guard;       // word != nullptr: run only if the guard carries this epoch (fallback of edge_fwd_h2)
+  // live-edge view (ng_internal.h: LiveEdges): rows = compacted live slots, n_edges = slot count, row count = *n_live
+  const int32_t* perm;
+  const int32_t* n_live;
+  int64_t z_layer_stride; // floats between the layers of the tape
 };
 
 __device__ __forceinline__ void load_wfrag(float (&wf)[64], const float* __restrict__ Wpk, int layer,
@@ -208,7 +212,14 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
   }
   __syncthreads();
 
-  const int64_t ntiles = (a.n_edges + TM - 1) / TM;
+  const int64_t n_edges = a.perm ? (int64_t)*a.n_live : a.n_edges;
+  const int64_t ntiles = (n_edges + TM - 1) / TM;
+  if (a.perm) {     // dead slots carry e == 0
+    for (int64_t i = n_edges + (int64_t)blockIdx.x * NTHR + tid; i < a.n_edges; i += (int64_t)gridDim.x * NTHR) {
+      const int64_t g = a.perm[i];
+      for (int n = 0; n < E; ++n) a.e_out[g * E + n] = 0.f;
+    }
+  }
   float wf[64];
   load_wfrag(wf, a.Wpk, 0, slab, lane);
 
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
   // the point of use they exposed a full HBM latency at the head of every tile
   float ds_n, de_n;
   {
-    const int64_t g0 = std::min<int64_t>((int64_t)blockIdx.x * TM + (tid & (TM - 1)), a.n_edges - 1);
+    const int64_t g0 = std::max<int64_t>(std::min<int64_t>((int64_t)blockIdx.x * TM + (tid & (TM - 1)), n_edges - 1), 0);
     ds_n = a.d_src[g0]; de_n = a.d_eff[g0];
   }
 #pragma unroll 1
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
     {
       const int r = tid & (TM - 1), qt = tid / TM;
       const int64_t gr = row0 + r;
-      const float ds = gr < a.n_edges ? ds_n : 0.f;
+      const float ds = gr < n_edges ? ds_n : 0.f;
       const float de = de_n;
       const float m = ds > 0.f ? 1.f : 0.f;
       if (qt == 0) sMask[r] = m;
@@ -253,19 +264,19 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
     // ---- hidden layer 0: X0 -> X1
     hidden_layer(wf, X0, X1, sBias, slab, rbase, lane, a.Wpk, 1);
     {   // issued here they are younger than layer 1's weight slab and a full layer older than layer 2's
-      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * TM + (tid & (TM - 1)), a.n_edges - 1);
+      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * TM + (tid & (TM - 1)), n_edges - 1);
       ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
     }
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X1, a.z_save, a.dummy, row0, a.n_edges, wave, lane, a.tape_blocked);
+    if (SAVE) save_tile(X1, a.z_save, a.dummy, row0, n_edges, wave, lane, a.tape_blocked);
     // ---- hidden layer 1: X1 -> X0
     hidden_layer(wf, X1, X0, sBias + FH, slab, rbase, lane, a.Wpk, 2);
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X0, a.z_save + a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane, a.tape_blocked);
+    if (SAVE) save_tile(X0, a.z_save + a.z_layer_stride, a.dummy, row0, n_edges, wave, lane, a.tape_blocked);
     // ---- hidden layer 2: X0 -> X1   (reloads layer 0's slab for the next tile)
     hidden_layer(wf, X0, X1, sBias + 2 * FH, slab, rbase, lane, a.Wpk, 0);
     NG_LDS_BARRIER();
-    if (SAVE) save_tile(X1, a.z_save + 2 * a.n_edges * FH, a.dummy, row0, a.n_edges, wave, lane, a.tape_blocked);
+    if (SAVE) save_tile(X1, a.z_save + 2 * a.z_layer_stride, a.dummy, row0, n_edges, wave, lane, a.tape_blocked);
     // ---- output layer: wave w -> rows 16w..16w+15, 4 lanes per row (k = 16i + 4*(lane&3) + s)
     {
       const int r = 16 * wave + (lane >> 2), qq = lane & 3;
@@ -288,10 +299,11 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
         acc[n] += __shfl_xor(acc[n], 2, 64);
       }
       const int64_t gr = row0 + r;
-      if (qq == 0 && gr < a.n_edges) {
+      if (qq == 0 && gr < n_edges) {
         const float m = sMask[r];
+        const int64_t go = a.perm ? (int64_t)a.perm[gr] : gr;     // (a dependent load: this kernel is the strict-fp32 / fallback form)
 #pragma unroll
-        for (int n = 0; n < E; ++n) a.e_out[gr * E + n] = m * (acc[n] + a.bo[n]);
+        for (int n = 0; n < E; ++n) a.e_out[go * E + n] = m * (acc[n] + a.bo[n]);
       }
     }
     // (the barrier after the next tile's RBF phase orders these X1 / sMask reads before they are
@@ -311,9 +323,9 @@ bool edge_fused_supported(int H, int E, int Le) { return H == FH && Le == 4 && E
 
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
-                   const float* const* b, float* e_out, float* z_save) {
-  if (edge_split_enabled()) return edge_h2_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save);
-  return edge_fused_fwd_f32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save, false, nullptr);
+                   const float* const* b, float* e_out, float* z_save, LiveEdges live) {
+  if (edge_split_enabled()) return edge_h2_fwd(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save, live);
+  return edge_fused_fwd_f32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save, false, nullptr, live);
 }
 
 // f32-input MFMA forward.  guard != nullptr: the range fallback of edge_h2_fwd — same launches, but the kernel's
@@ -322,7 +334,8 @@ int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
 // split-operand image the first kernel is still reading.
 int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                        const float* d_eff, const float* centers, float gap, const float* const* W,
-                       const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard) {
+                       const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard,
+                       LiveEdges live) {
   // scratch: fragment-ordered copy of the three hidden weight matrices
   const size_t pk_floats = (size_t)3 * FH * FH;
   // (frozen weights: the fragment copy is kept like every other packed image — one launch less per call)
@@ -342,6 +355,7 @@ int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.Wo = W[3]; a.bo = b[3];
   a.e_out = e_out; a.z_save = z_save; a.dummy = Wpk + pk_floats;
+  a.perm = live.perm; a.n_live = live.n_live; a.z_layer_stride = n_edges * FH;
   // 64-edge tiles, two 256-thread workgroups per CU
   const int TMr = 64;
   const int64_t ntiles = cdiv(n_edges, TMr);

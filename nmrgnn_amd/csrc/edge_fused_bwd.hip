@@ -41,6 +41,11 @@ struct EdgeBwdArgs {
   int tape_blocked;     // z_save layout (edge_fused.h), 1 = blocked inside full 32-edge groups
   int zero_rows;        // fallback of a multi-segment split-operand launch: partial rows grid .. zero_rows-1 are cleared
   RangeGuard guard;     // word != nullptr: run only if the guard carries this epoch (fallback of edge_bwd_h2)
+  // live-edge view (ng_internal.h: LiveEdges): rows = compacted live slots (n_edges = slot count, rows = *n_live), d_eff
+  // and the tape compacted, de[perm[row]] in the caller's slot layout; d_src is not read
+  const int32_t* perm;
+  const int32_t* n_live;
+  int64_t z_layer_stride;
 };
 
 // partial layout (floats): dW[3][128*128] | db[3][128] | dWo[128*E] | dbo[E]
@@ -203,10 +208,11 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   for (int n = 0; n < E; ++n) accWo[n] = 0.f;
   float accbo = 0.f;
 
-  const int64_t ntiles = (a.n_edges + FTM - 1) / FTM;
+  const int64_t n_edges = a.perm ? (int64_t)*a.n_live : a.n_edges;
+  const int64_t ntiles = (n_edges + FTM - 1) / FTM;
   const float* Z1g = a.z_save;
-  const float* Z2g = a.z_save + a.n_edges * FH;
-  const float* Z3g = a.z_save + 2 * a.n_edges * FH;
+  const float* Z2g = a.z_save + a.z_layer_stride;
+  const float* Z3g = a.z_save + 2 * a.z_layer_stride;
   __syncthreads();
 
   // per-tile inputs are fetched one tile ahead (during phase D of the previous tile) so that phase A
@@ -214,18 +220,25 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   float4 pzA[4], pzB[4];
   float pf_ds = 0.f, pf_dn = 0.f, pf_de = 0.f, pf_dm = 0.f;
   auto prefetch = [&](int64_t row0) {
-    tile_to_regs(pzA, Z3g, row0, a.n_edges, tid, a.tape_blocked);
+    tile_to_regs(pzA, Z3g, row0, n_edges, tid, a.tape_blocked);
     pf_ds = 0.f; pf_dn = 0.f; pf_de = 0.f; pf_dm = 0.f;
     if (tid < FTM) {
       const int64_t gr = row0 + tid;
-      if (gr < a.n_edges) { pf_ds = a.d_src[gr]; pf_dn = a.d_eff[gr]; }
+      if (gr < n_edges) { pf_ds = a.perm ? 1.f : a.d_src[gr]; pf_dn = a.d_eff[gr]; }
     }
     if (tid < FTM * E) {
       // mask source and gradient are requested TOGETHER (clamped index, masked at use): reading de only
       // after d_src had arrived put a full HBM latency (5-8k cycles per tile) into this prefetch
-      const int64_t gr = std::min<int64_t>(row0 + tid / E, a.n_edges - 1);
-      pf_dm = row0 + tid / E < a.n_edges ? a.d_src[gr] : 0.f;
-      pf_de = a.de[std::min<int64_t>(row0 * E + tid, a.n_edges * E - 1)];
+      const int64_t gr = std::min<int64_t>(row0 + tid / E, n_edges - 1);
+      if (a.perm) {
+        // live view: every row is live; its gradient sits at the row's SLOT (one dependent load per tile — this kernel
+        // is the strict-fp32 / range-fallback form, the split-operand kernel requests the slot two tiles ahead)
+        pf_dm = row0 + tid / E < n_edges ? 1.f : 0.f;
+        pf_de = a.de[(int64_t)a.perm[gr] * E + tid % E];
+      } else {
+        pf_dm = row0 + tid / E < n_edges ? a.d_src[gr] : 0.f;
+        pf_de = a.de[std::min<int64_t>(row0 * E + tid, n_edges * E - 1)];
+      }
     }
   };
   if ((int64_t)blockIdx.x < ntiles) prefetch((int64_t)blockIdx.x * FTM);
@@ -242,9 +255,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
     regs_to_lds(pzA, bufA, tid);
     // Z2 is requested here and lands in bufB at the end of this phase (~6k cycles of cover): holding it in
     // registers across the previous tile's last GEMM cost 16 VGPRs at the kernel's pressure peak
-    tile_to_regs(pzB, Z2g, row0, a.n_edges, tid, a.tape_blocked);
+    tile_to_regs(pzB, Z2g, row0, n_edges, tid, a.tape_blocked);
     NG_LDS_BARRIER();
-    tile_to_regs(pzA, Z1g, row0, a.n_edges, tid, a.tape_blocked);   // lands in bufC at the end of phase B
+    tile_to_regs(pzA, Z1g, row0, n_edges, tid, a.tape_blocked);   // lands in bufC at the end of phase B
     // G3 = (dE Wo^T) * s'(Z3) -> bufC
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -391,7 +404,8 @@ __global__ __launch_bounds__(1024) void edge_bwd_reduce_kernel(const float* __re
 
 int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
-                   const float* z_save, const float* de, float* const* dW, float* const* db, int tape_layout) {
+                   const float* z_save, const float* de, float* const* dW, float* const* db, int tape_layout,
+                   LiveEdges live) {
   const int64_t ntiles = cdiv(n_edges, FTM);
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
@@ -410,6 +424,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   a.WpkT = WpkT; a.Wo = W[3]; a.z_save = z_save; a.de = de;
   a.partial = partial; a.part_stride = stride;
   a.tape_blocked = 0; a.zero_rows = 0; a.guard = RangeGuard{nullptr, 0};
+  a.perm = live.perm; a.n_live = live.n_live; a.z_layer_stride = n_edges * FH;
   const size_t lds = (size_t)(3 * FTM * FLD + FH * FMAX_E + FTM * FMAX_E + 2 * FTM + FH) * 4;
   // default: split-operand kernel on the 16-bit matrix pipe (edge_bwd_h2.hip); NG_EDGE_MATH=fp32 (both directions) or
   // NG_EDGE_BWD_MATH=fp32 (this one only) select the f32-input MFMA kernel below
@@ -423,7 +438,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
     const RangeGuard guard = range_guard_begin(ctx);
     if (!guard.word) return NG_ERR_NOMEM;
     int rc3 = edge_bwd_h2_launch(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, z_save, de,
-                     (char*)(partial + (size_t)nseg * grid * stride), partial, stride, grid, blocked ? 1 : 0, guard);
+                     (char*)(partial + (size_t)nseg * grid * stride), partial, stride, grid, blocked ? 1 : 0, guard, live);
     if (rc3) return rc3;
     n_part = nseg * grid;
     // range fallback: the f32-input kernel below, executed only if the split-operand kernel raised the guard; it

@@ -88,6 +88,11 @@ struct EdgeH2Args {
   float* z_save;          // [3][n_edges][128] or nullptr
   float* dummy;           // 128 floats
   RangeGuard guard;       // raised when an output comes out non-finite (an operand left the fp16 range)
+  // live-edge view (ng_internal.h: LiveEdges): rows = compacted live slots, row r writes e_out[perm[r]]; n_edges above is
+  // then the SLOT count (upper bound of the rows, and the length of perm), the row count is *n_live
+  const int32_t* perm;
+  const int32_t* n_live;
+  int64_t z_layer_stride; // floats between the layers of the tape
 };
 
 // one chunk = 32 wave-instructions of 1 KB; wave w moves KB w, w+8, w+16, w+24 (scalar resource + scalar offset + one
@@ -247,11 +252,22 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   }
   if (tid < 32) sBo[tid] = tid < a.E ? a.bo[tid] : 0.f;
 
-  const int64_t ntiles = (a.n_edges + H2_TM - 1) / H2_TM;
+  // rows of this launch: every slot, or the compacted live ones (device scalar: no host round trip per batch)
+  const int64_t n_edges = a.perm ? (int64_t)__builtin_amdgcn_readfirstlane(*a.n_live) : a.n_edges;
+  const int64_t ntiles = (n_edges + H2_TM - 1) / H2_TM;
   float ds_n, de_n;
+  int pg_n = 0;           // slot of this lane's row (live view), requested a tile ahead like the distances
   {
-    const int64_t g0 = std::min<int64_t>((int64_t)blockIdx.x * H2_TM + 32 * wave + l31, a.n_edges - 1);
+    const int64_t g0 = std::max<int64_t>(std::min<int64_t>((int64_t)blockIdx.x * H2_TM + 32 * wave + l31, n_edges - 1), 0);
     ds_n = a.d_src[g0]; de_n = a.d_eff[g0];
+    if (a.perm) pg_n = a.perm[g0];
+  }
+  if (a.perm) {
+    // the dead slots (perm[n_live ..]) carry e == 0 (model.py:261: the mask multiplies the MLP output); nobody else writes them
+    for (int64_t i = n_edges + (int64_t)blockIdx.x * 512 + tid; i < a.n_edges; i += (int64_t)gridDim.x * 512) {
+      const int64_t g = a.perm[i];
+      for (int c = 0; c < a.E; ++c) a.e_out[g * a.E + c] = 0.f;
+    }
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, H2_NCHUNK * H2_CHUNK, 0x00020000);
@@ -278,7 +294,8 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t gr = tile * H2_TM + 32 * wave + l31;
-    const bool valid = gr < a.n_edges;
+    const bool valid = gr < n_edges;
+    const int gout = a.perm ? pg_n : (int)gr;      // slot this row's e goes to (slot counts fit 31 bits)
     const float ds = valid ? ds_n : 0.f;
     const float mask = ds > 0.f ? 1.f : 0.f;
     const float dm = ds > 0.f ? de_n : 1.0e19f;      // masked edges: d = 1e19 -> exp2(-inf) = exact 0
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     };
     // rows of this wave: tile*256 + 32*wave + (0..31); rows_left <= 0 when the wave lies past the end
     const int64_t wrow0 = tile * H2_TM + 32 * wave;
-    const int rows_left = (int)std::min<int64_t>(32, a.n_edges - wrow0);
+    const int rows_left = (int)std::min<int64_t>(32, n_edges - wrow0);
     const bool full = rows_left >= 32;
     if constexpr (SAVE != 1) {
       // ---- pipelined schedule (blocked tape: the training forward; the inference form spilled 56 B/lane with it).  The first chunk of a layer is 48 MFMAs with no
@@ -315,13 +332,14 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
       float* zp0 = nullptr;
       if (SAVE == 2)
         zp0 = full ? a.z_save + (tile * 8 + wave) * 4096 + lane * 4 : a.z_save + (wrow0 + l31) * FH + 4 * hf;
-      const int64_t lstride = a.n_edges * FH;
+      const int64_t lstride = a.z_layer_stride;
       auto zpl = [&](int layer) -> float* { return todummy ? a.dummy + 4 * hf : zp0 + layer * lstride; };
       // B fragments of the first two steps up front, the rest inside layer 0's first chunk
       rbf_unit(0, 0, 0); rbf_unit(0, 0, 1); rbf_unit(0, 1, 0); rbf_unit(0, 1, 1);
       {   // distances of this workgroup's next tile
-        const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, a.n_edges - 1);
+        const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, n_edges - 1);
         ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
+        if (a.perm) pg_n = a.perm[gn];
       }
 #pragma unroll
       for (int layer = 0; layer < 3; ++layer) {
@@ -363,8 +381,9 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) { rbf_unit(bi, s, 0); rbf_unit(bi, s, 1); }
     {   // distances of this workgroup's next tile
-      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, a.n_edges - 1);
+      const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, n_edges - 1);
       ds_n = a.d_src[gn]; de_n = a.d_eff[gn];
+      if (a.perm) pg_n = a.perm[gn];
     }
     // ---- three hidden layers, two chunks each
 #pragma unroll
@@ -378,7 +397,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
       }
       h2_hidden_chunk<true>(ring + use_s * SLOT + (WL ? H2_CHUNK : 0), bf, acc[2], acc[3], sBias + layer * FH, 2, lane, acc[0], acc[1]);
       H2_STEP_END();
-      float* zl = SAVE ? a.z_save + (int64_t)layer * a.n_edges * FH : nullptr;
+      float* zl = SAVE ? a.z_save + (int64_t)layer * a.z_layer_stride : nullptr;
       float* zw = SAVE ? zl + wrow0 * FH : nullptr;
       float* tb = sT + wave * (32 * H2_TLD);
       h2_epilogue<SAVE, false>(acc[0], bf[0], tb, zw, a.dummy, rows_left, lane, nullptr, 0);
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
           if (ne < a.E) {
             const float v = mask * fmaf(acc[r], H2_WINV, sBo[ne]);
             bad |= not_finite(v);
-            a.e_out[gr * a.E + ne] = v;
+            a.e_out[(int64_t)gout * a.E + ne] = v;
           }
         }
       }
@@ -438,7 +457,7 @@ bool edge_split_enabled() { return !sw().edge_math_fp32; }
 
 int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                 const float* centers, float gap, const float* const* W, const float* const* b, float* e_out,
-                float* z_save) {
+                float* z_save, LiveEdges live) {
   const size_t img_bytes = (size_t)H2_NCHUNK * H2_CHUNK;
   bool have = false;
   char* img = (char*)cached_image(ctx, W[0], 6, img_bytes + FH * 4, &have);
@@ -455,6 +474,7 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   a.img = img;
   a.bh[0] = b[0]; a.bh[1] = b[1]; a.bh[2] = b[2];
   a.bo = b[3]; a.E = E; a.e_out = e_out; a.z_save = z_save;
+  a.perm = live.perm; a.n_live = live.n_live; a.z_layer_stride = n_edges * FH;
   a.dummy = (float*)(img + img_bytes);
   a.guard = range_guard_begin(ctx);
   if (!a.guard.word) return NG_ERR_NOMEM;
@@ -471,7 +491,7 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   NG_HIP(ctx, hipGetLastError());
   // the same call on f32-input MFMA, executed only if the kernel above raised the guard (operands beyond the fp16 range)
   return edge_fused_fwd_f32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save,
-                            z_save && edge_tape_blocked(E, n_edges), &a.guard);
+                            z_save && edge_tape_blocked(E, n_edges), &a.guard, live);
 }
 
 }  // namespace ng

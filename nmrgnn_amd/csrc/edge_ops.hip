@@ -368,6 +368,43 @@ extern "C" int ng_edge_mlp_fwd(ng_ctx* ctx, void* stream, int64_t n_edges, int H
                               gap, W, b, e_out, z_save);
 }
 
+// ---- the same calls over the live-edge view of a padded list (ng_build_live_edges) --------------------------------
+extern "C" int ng_edge_live_supported(int H, int E, int Le, int act) { return use_fused(H, E, Le, act) ? 1 : 0; }
+
+static int check_live(ng_ctx* ctx, int64_t n_slots, int H, int E, int Le, int act, const int32_t* perm, const int32_t* n_live) {
+  NG_REQUIRE(ctx, perm && n_live, "edge_mlp live view: perm and n_live required");
+  NG_REQUIRE(ctx, use_fused(H, E, Le, act), "edge_mlp live view: only the fused edge path has it (ng_edge_live_supported)");
+  // slots are addressed through 32-bit byte offsets of the de array
+  NG_REQUIRE(ctx, n_slots > 0 && n_slots * (int64_t)E * 4 < ((int64_t)1 << 31), "edge_mlp live view: n_slots * E * 4 must stay below 2^31");
+  return NG_OK;
+}
+
+extern "C" int ng_edge_mlp_fwd_live(ng_ctx* ctx, void* stream, int64_t n_slots, int H, int E, int Le, int act,
+                                    const float* d_src_c, const float* d_eff_c, const int32_t* perm, const int32_t* n_live,
+                                    const float* centers, float gap, const float* const* W, const float* const* b,
+                                    float* e_out, float* z_save) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (int rc = check_edge_shape(ctx, H, E, Le, act)) return rc;
+  NG_REQUIRE(ctx, gap > 0.f, "edge_mlp: rbf gap > 0");
+  if (n_slots == 0) return NG_OK;
+  if (int rc = check_live(ctx, n_slots, H, E, Le, act, perm, n_live)) return rc;
+  return edge_fused_fwd(ctx, (hipStream_t)stream, n_slots, E, d_src_c, d_eff_c, centers, gap, W, b, e_out, z_save,
+                        LiveEdges{perm, n_live});
+}
+
+extern "C" int ng_edge_mlp_bwd_live(ng_ctx* ctx, void* stream, int64_t n_slots, int H, int E, int Le, int act,
+                                    const float* d_src_c, const float* d_eff_c, const int32_t* perm, const int32_t* n_live,
+                                    const float* centers, float gap, const float* const* W, const float* z_save,
+                                    const float* de, float* const* dW, float* const* db, int tape_layout) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (int rc = check_edge_shape(ctx, H, E, Le, act)) return rc;
+  NG_REQUIRE(ctx, z_save, "edge_mlp_bwd: saved activations required");
+  NG_REQUIRE(ctx, n_slots > 0, "edge_mlp_bwd live view: n_slots > 0");
+  if (int rc = check_live(ctx, n_slots, H, E, Le, act, perm, n_live)) return rc;
+  return edge_fused_bwd(ctx, (hipStream_t)stream, n_slots, E, d_src_c, d_eff_c, centers, gap, W, z_save, de, dW, db,
+                        tape_layout, LiveEdges{perm, n_live});
+}
+
 extern "C" int ng_edge_tape_layout(int H, int E, int Le, int act, int64_t n_edges) {
   return use_fused(H, E, Le, act) && edge_tape_blocked(E, n_edges) ? 1 : 0;
 }

@@ -156,9 +156,107 @@ __global__ __launch_bounds__(1024) void gl_scan_small_kernel(int n, const int32_
   if (threadIdx.x == 0) out[n] = carry;
 }
 
+// ---- live-edge partition (round 4): a STABLE partition of the slots of a padded list into live (edges > 0) and dead,
+// the row order of the compacted edge kernels.  Three launches: live count per block of 1024 slots, exclusive scan of
+// the block counts (+ the total = n_live), fill.  Integer work only; the order is the slot order by construction.
+__global__ __launch_bounds__(GL_BLOCK) void gl_live_count_kernel(int64_t n, const float* __restrict__ edges, int32_t* __restrict__ bcnt) {
+  __shared__ int32_t s[GL_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * GL_SCAN_TILE + (int64_t)threadIdx.x * GL_SCAN_ITEMS;
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < GL_SCAN_ITEMS; ++k) c += (base + k < n && edges[base + k] > 0.f) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t t = 0;
+    for (int w = 0; w < GL_BLOCK / 64; ++w) t += s[w];
+    bcnt[blockIdx.x] = t;
+  }
+}
+
+// one block: exclusive scan of the block counts in place, total -> *total
+__global__ __launch_bounds__(GL_BLOCK) void gl_live_scan_kernel(int nblocks, int32_t* __restrict__ bcnt, int32_t* __restrict__ total) {
+  __shared__ int32_t s[GL_BLOCK];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nblocks; b0 += GL_BLOCK) {
+    const int i = b0 + threadIdx.x;
+    const int32_t v = i < nblocks ? bcnt[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < GL_BLOCK; off <<= 1) {
+      const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nblocks) bcnt[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == GL_BLOCK - 1) carry += s[GL_BLOCK - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// slot g: live -> perm[rank] = g, pos[g] = rank, d_c[rank] = edges[g];  dead -> perm[n_live + (g - live slots before g)] = g,
+// pos[g] = -1
+__global__ __launch_bounds__(GL_BLOCK) void gl_live_fill_kernel(int64_t n, const float* __restrict__ edges, const int32_t* __restrict__ boff,
+                                                                const int32_t* __restrict__ total, int32_t* __restrict__ perm,
+                                                                int32_t* __restrict__ pos, float* __restrict__ d_c) {
+  __shared__ int32_t s[GL_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * GL_SCAN_TILE + (int64_t)threadIdx.x * GL_SCAN_ITEMS;
+  float d[GL_SCAN_ITEMS];
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < GL_SCAN_ITEMS; ++k) { d[k] = base + k < n ? edges[base + k] : 0.f; c += d[k] > 0.f ? 1 : 0; }
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < GL_BLOCK; off <<= 1) {
+    const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int32_t rank = boff[blockIdx.x] + s[threadIdx.x] - c;      // live slots before this thread's first slot
+  const int32_t n_live = *total;
+#pragma unroll
+  for (int k = 0; k < GL_SCAN_ITEMS; ++k) {
+    const int64_t g = base + k;
+    if (g >= n) break;
+    if (d[k] > 0.f) {
+      perm[rank] = (int32_t)g; pos[g] = rank; d_c[rank] = d[k];
+      ++rank;
+    } else {
+      perm[n_live + (g - rank)] = (int32_t)g; pos[g] = -1;
+    }
+  }
+}
+
 }  // namespace ng
 
 using namespace ng;
+
+extern "C" int ng_build_live_edges(ng_ctx* ctx, void* stream, int64_t n_slots, const float* edges, int32_t* perm, int32_t* pos,
+                                   float* d_c, int32_t* n_live) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, n_slots >= 0 && n_slots < ((int64_t)1 << 31) - GL_SCAN_TILE, "live edges: slot count out of range");
+  NG_REQUIRE(ctx, n_live && (n_slots == 0 || (edges && perm && pos && d_c)), "live edges: arguments");
+  hipStream_t st = (hipStream_t)stream;
+  DeviceGuard dg(ctx->device);
+  if (n_slots == 0) { NG_HIP(ctx, hipMemsetAsync(n_live, 0, sizeof(int32_t), st)); return NG_OK; }
+  const int nb = (int)cdiv(n_slots, GL_SCAN_TILE);
+  int32_t* bcnt = (int32_t*)aux_workspace(ctx, (size_t)(nb + 16) * sizeof(int32_t));
+  if (!bcnt) return NG_ERR_HIP;
+  ProfScope ps(ctx, st, "live_edges");
+  hipLaunchKernelGGL(gl_live_count_kernel, dim3(nb), dim3(GL_BLOCK), 0, st, n_slots, edges, bcnt);
+  hipLaunchKernelGGL(gl_live_scan_kernel, dim3(1), dim3(GL_BLOCK), 0, st, nb, bcnt, n_live);
+  hipLaunchKernelGGL(gl_live_fill_kernel, dim3(nb), dim3(GL_BLOCK), 0, st, n_slots, edges, bcnt, n_live, perm, pos, d_c);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
 
 // out[0..n] = exclusive prefix sums of in[0..n-1] (out[n] = total): row_ptr from a degree vector, on the device
 extern "C" int ng_exclusive_scan_i32(ng_ctx* ctx, void* stream, int64_t n, const int32_t* in, int32_t* out) {

@@ -29,6 +29,17 @@ __device__ __forceinline__ bool range_guard_raised(RangeGuard g) {
 }
 __device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) < INFINITY); }
 
+// ---- live-edge view of a padded edge list (round 4: ng_build_live_edges / ng_edge_mlp_*_live) -----------------------
+// A padded slot (edges == 0) yields e == 0 and contributes nothing to any gradient (nmrgnn/model.py:251,257,261), yet
+// the fused edge kernels ran all four layers on it.  With a view the kernels walk the n_live COMPACTED rows only: row r
+// is slot perm[r]; d_src / d_eff are the compacted arrays (every row live), the tape is compacted too (layer stride =
+// the slot count, the host-side upper bound), e_out / de keep the caller's [n_slots][E] layout and are reached through
+// perm.  n_live is a device scalar: no host synchronisation per batch.  perm == nullptr: no view, every slot is a row.
+struct LiveEdges {
+  const int32_t* perm = nullptr;     // [n_slots]: the live slots in ascending order, then the dead ones
+  const int32_t* n_live = nullptr;   // device scalar, number of live slots
+};
+
 // Y = act(rowscale[m] * (X @ W) + b) (+ R);  S (optional) receives the activation output.
 int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,
               const float* W, const float* b, const float* rowscale, const float* R, float* Y,
@@ -72,10 +83,11 @@ bool dense_grad_uses_h2(int64_t M, int Kin, int Nout);
 bool edge_fused_supported(int H, int E, int Le);
 int edge_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                    const float* d_eff, const float* centers, float gap, const float* const* W,
-                   const float* const* b, float* e_out, float* z_save);
+                   const float* const* b, float* e_out, float* z_save, LiveEdges live = LiveEdges());
 int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src,
                        const float* d_eff, const float* centers, float gap, const float* const* W,
-                       const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard);
+                       const float* const* b, float* e_out, float* z_save, bool tape_blocked, const RangeGuard* guard,
+                       LiveEdges live = LiveEdges());
 
 // elementwise helpers (node_ops.hip)
 int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp);

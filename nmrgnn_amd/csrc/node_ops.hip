@@ -652,6 +652,33 @@ __global__ void add_noise_kernel(uint64_t seed, uint64_t offset, int64_t n, cons
   }
 }
 
+// GaussianNoise over the live-edge view (round 4): out_c[pos[g]] = x[g] + alpha * xi_g for every live slot g (pos[g] >= 0),
+// xi_g the draw add_noise_kernel gives slot g (same counters, same expressions: same bits), or y[g] when the caller
+// supplies the draws.  Dead slots get nothing: the compacted edge kernels never see them.
+__global__ void add_noise_live_kernel(uint64_t seed, uint64_t offset, int64_t n, const float* __restrict__ x,
+                                      const float* __restrict__ y, float alpha, const int32_t* __restrict__ pos,
+                                      float* __restrict__ out_c) {
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    float z[4];
+    if (y) {
+      for (int k = 0; k < 4; ++k) z[k] = q * 4 + k < n ? y[q * 4 + k] : 0.f;
+    } else {
+      uint32_t r[4];
+      philox4x32(seed, offset + (uint64_t)q, r);
+      const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), t0 = 6.28318530717958648f * u01(r[1]);
+      const float r1 = sqrtf(-2.0f * logf(u01(r[2]))), t1 = 6.28318530717958648f * u01(r[3]);
+      z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1); z[3] = r1 * sinf(t1);
+    }
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) {
+        const int32_t p = pos[q * 4 + k];
+        if (p >= 0) out_c[p] = x[q * 4 + k] + alpha * z[k];
+      }
+  }
+}
+
 static inline dim3 ew_grid(int64_t work_items) {
   return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(work_items, 256), 256 * 8)));
 }
@@ -688,6 +715,17 @@ extern "C" int ng_add_noise(ng_ctx* ctx, void* stream, uint64_t seed, uint64_t o
   if (n == 0) return NG_OK;
   hipLaunchKernelGGL(add_noise_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed, offset, n, x,
                      alpha, out);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_add_noise_live(ng_ctx* ctx, void* stream, uint64_t seed, uint64_t offset, int64_t n, const float* x,
+                                 const float* y, float alpha, const int32_t* pos, float* out_c) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (n == 0) return NG_OK;
+  NG_REQUIRE(ctx, x && pos && out_c, "add_noise_live: arguments");
+  hipLaunchKernelGGL(add_noise_live_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed, offset, n, x, y,
+                     alpha, pos, out_c);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

@@ -7,6 +7,7 @@ There is no CPU fallback — constructing an Engine without the library / a GPU 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -35,7 +36,7 @@ def rbf_grid(low, high, count):
 class Tape:
     """activations kept between forward(training=True) and backward()"""
     __slots__ = ("batch", "d_eff", "z_save", "z_layout", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
-                 "peaks")
+                 "peaks", "live")
 
 
 class Engine:
@@ -83,6 +84,9 @@ class Engine:
         self._rng_calls = 0
         self._frozen = False
         self.defer_reductions = True      # backward(): queue the weight-gradient sums, one launch (ng_defer_reductions)
+        # padded slots (edges == 0) are skipped by the fused edge kernels (include/nmrgnn_hip.h: ng_edge_mlp_fwd_live);
+        # NG_EDGE_LIVE=0 runs every slot as rounds 1-3 did (A/B measurements, tests)
+        self.use_live_edges = os.environ.get("NG_EDGE_LIVE", "1") != "0"
         Engine._ids += 1
         self._id = Engine._ids          # owner tag of the frozen-weight cache
 
@@ -147,7 +151,16 @@ class Engine:
         self._ck(lib.ng_ctx_set_graph_span(h, batch.max_graph_atoms), "ng_ctx_set_graph_span")
         d_src = batch.edges.reshape(-1)
         d_eff = d_src
-        if training and self.sigma > 0:
+        # live-edge view: the fused edge kernels walk the compacted live slots only (same e bit for bit)
+        live = batch.live_edges() if (self.use_live_edges and lib.ng_edge_live_supported(H, E, self.Le, self.fc_act)) else None
+        if live is not None:
+            perm, pos, d_c, n_live = live
+            d_src = d_eff = d_c
+            if training and self.sigma > 0:
+                d_eff = self._new(ne)       # compacted: the first n_live entries are used
+                self._ck(lib.ng_add_noise_live(h, st, seed, 0, ne, ptr(batch.edges), ptr(None if noise is None else noise.reshape(-1)),
+                                               self.sigma, ptr(pos), ptr(d_eff)), "ng_add_noise_live")
+        elif training and self.sigma > 0:
             d_eff = self._new(ne)
             if noise is None:     # the draw and d + sigma * xi in one launch (the bits of randn + add_scaled)
                 self._ck(lib.ng_add_noise(h, st, seed, 0, ne, ptr(d_src), self.sigma, ptr(d_eff)), "ng_add_noise")
@@ -162,9 +175,14 @@ class Engine:
         e = self._new(ne, E)
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff),
-                                     ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
-                                     ptr(e), ptr(z_save)), "ng_edge_mlp_fwd")
+        if live is not None:
+            self._ck(lib.ng_edge_mlp_fwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff), ptr(perm),
+                                              ptr(n_live), ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
+                                              ptr(e), ptr(z_save)), "ng_edge_mlp_fwd_live")
+        else:
+            self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff),
+                                         ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
+                                         ptr(e), ptr(z_save)), "ng_edge_mlp_fwd")
         h0 = self._new(N, F)
         self._ck(lib.ng_embed_fwd(h, st, N, self.C, F, ptr(batch.atoms), ptr(P["embed/kernel"]),
                                   ptr(h0)), "ng_embed_fwd")
@@ -234,6 +252,7 @@ class Engine:
             tp = Tape()
             tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e
             tp.z_layout = z_layout
+            tp.live = live
             tp.h, tp.A, tp.S, tp.fx, tp.fs, tp.g, tp.drop_mask, tp.peaks = hs, As, Ss, fx, fs, g, mask, peaks
             self.tape = tp
         return peaks
@@ -311,9 +330,15 @@ class Engine:
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, ne, H, E, self.Le, self.fc_act, ptr(b.edges), ptr(tp.d_eff),
-                                          ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
-                                          ptr(de), ptr_array(dW), ptr_array(dB), tp.z_layout), "ng_edge_mlp_bwd")
+        if tp.live is not None:
+            perm, _, d_c, n_live = tp.live
+            self._ck(lib.ng_edge_mlp_bwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_c), ptr(tp.d_eff), ptr(perm),
+                                              ptr(n_live), ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
+                                              ptr(de), ptr_array(dW), ptr_array(dB), tp.z_layout), "ng_edge_mlp_bwd_live")
+        else:
+            self._ck(lib.ng_edge_mlp_bwd_tape(h, st, ne, H, E, self.Le, self.fc_act, ptr(b.edges), ptr(tp.d_eff),
+                                              ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
+                                              ptr(de), ptr_array(dW), ptr_array(dB), tp.z_layout), "ng_edge_mlp_bwd")
         self.tape = None
 
     # ------------------------------------------------------------------ loss / optimiser

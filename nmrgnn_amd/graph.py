@@ -70,6 +70,7 @@ class GraphBatch:
         self.graph_ptr = torch.as_tensor(self.graph_ptr_host, device=self.device)
         self.G = len(self.graph_ptr_host) - 1
         self._csc = None
+        self._live = None
         # compute-side copy of the lists: padded slots (edges == 0, weight exactly 0 after the edge mask)
         # point at the atom itself instead of row 0, so that the row range a tile of atoms references
         # stays local and the window-resident MP kernels (csrc/mp_win.hip) can keep it in LDS
@@ -134,6 +135,7 @@ class GraphBatch:
             raise ValueError("inv_degree must be [N]")
         self.nlist_c = self.nlist
         self._csc = None
+        self._live = None
         return self
 
     def to_csr(self):
@@ -191,6 +193,29 @@ class GraphBatch:
         ptr = torch.zeros(self.N + 1, dtype=torch.int64)
         ptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=self.N), 0)
         self._csc = (ptr.to(torch.int32).contiguous(), eid[order].to(torch.int32).contiguous())
+
+    def live_edges(self):
+        """(perm, pos, d_c, n_live) of the padded lists (include/nmrgnn_hip.h: ng_build_live_edges) — the row order of
+        the compacted edge kernels; built once per batch on the device, no host synchronisation.  None for a CSR batch
+        (every entry is live) and for lists known to carry no padded slot."""
+        if self.is_csr or self.nlist_c is self.nlist or self.device.type != "cuda" or self.n_edges == 0:
+            return None
+        if self._live is None:
+            import ctypes as C
+            from . import _lib
+            from ._lib import ptr
+            ctx = _lib.get_context(self.device.index)
+            ne = self.n_edges
+            perm = torch.empty(ne, dtype=torch.int32, device=self.device)
+            pos = torch.empty(ne, dtype=torch.int32, device=self.device)
+            d_c = torch.empty(ne, dtype=torch.float32, device=self.device)
+            n_live = torch.empty(1, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                ctx.check(ctx.lib.ng_build_live_edges(ctx.handle, st, ne, ptr(self.edges), ptr(perm), ptr(pos), ptr(d_c),
+                                                      ptr(n_live)), "ng_build_live_edges")
+            self._live = (perm, pos, d_c, n_live)
+        return self._live
 
     def csc(self):
         """incoming-edge lists for the backward scatter; built once per batch.  ``csc_edge`` is allocated for every
