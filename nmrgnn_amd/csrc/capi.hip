@@ -122,8 +122,11 @@ void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* v
     DeviceGuard dg(ctx->device);
     if (w.buf) { (void)hipDeviceSynchronize(); (void)hipFree(w.buf); w.buf = nullptr; w.bytes = 0; }
     if (hipMalloc(&w.buf, bytes) != hipSuccess) { w.buf = nullptr; return nullptr; }
+    (void)hipMemset(w.buf, 0, bytes);      // (flag words inside an image start out equal to no version)
     w.bytes = bytes;
     w.ver = 0;
+    w.has_job = false;                     // a registered job points into the old buffer
+    ctx->wjobs_dirty = true;
   }
   *valid = w.ver == ctx->wver;
   w.ver = ctx->wver;
@@ -288,6 +291,8 @@ extern "C" int ng_weights_frozen(ng_ctx* ctx, int owner) {
   if (owner != 0 && owner != ctx->wowner) {   // another model takes the cache over: nothing in it is its own
     ctx->wver++;
     ctx->wowner = owner;
+    for (auto& kv : ctx->wimg) kv.second.has_job = false;     // (its weights may be gone: nothing of it is refreshed)
+    ctx->wjobs_dirty = true;
   }
   ctx->wcache = owner != 0;
   return NG_OK;
@@ -352,6 +357,7 @@ extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   if (ctx->small) (void)hipFree(ctx->small);
   for (auto& kv : ctx->wimg)
     if (kv.second.buf) (void)hipFree(kv.second.buf);
+  if (ctx->wjobs_dev) (void)hipFree(ctx->wjobs_dev);
   for (auto& r : ctx->recs) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);

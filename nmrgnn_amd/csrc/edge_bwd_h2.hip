@@ -37,6 +37,7 @@
 
 #include "edge_fused.h"
 #include "h2_common.cuh"
+#include "pack_bodies.cuh"
 
 namespace ng {
 
@@ -103,22 +104,9 @@ struct EdgeBwdH2Args {
   int64_t row_base;
 };
 
-// W^T fragments of the dZ GEMMs: lane (row k = 32 zk + (l&31), k-slot t) = piece_p( 2^8 W[k][n = 16 ks + 8 (l>>5) + t] )
-__global__ void h2_pack_wt_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
-                                  unsigned* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (L, zk, ks, lane)
-  if (idx >= 2 * 4 * 8 * 64) return;
-  const int lane = idx & 63, ks = (idx >> 6) & 7, zk = (idx >> 9) & 3, L = idx >> 11;
-  const float* W = L == 0 ? W2 : W3;
-  const int k = 32 * zk + (lane & 31), n0 = 16 * ks + 8 * (lane >> 5);
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    split2_pair(HX_WSCALE * W[k * FH + n0 + 2 * j], HX_WSCALE * W[k * FH + n0 + 2 * j + 1], h[j], l[j]);
-  unsigned* dst = img + (size_t)(((L * 4 + zk) * 8 + ks) * 2) * 256 + lane * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
-}
+// W^T fragments of the dZ GEMMs (packed by pack_bodies.cuh: PK_EDGE_WT): lane (row k = 32 zk + (l&31), k-slot t) =
+// piece_p( 2^8 W[k][n = 16 ks + 8 (l>>5) + t] )
+static_assert(HX_WSCALE == pk::WSCALE && FH == pk::FHd, "pack_bodies.cuh");
 
 // 16 values of one row (columns col0 + 8q + j, v[4q + j]) -> the two piece planes of an image
 template <int ROWB>
@@ -710,9 +698,19 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
                        LiveEdges live) {
   float* blockmax = reinterpret_cast<float*>(wt_img + HX_WT_BYTES);
   float* scale = blockmax + HX_SCALE_BLOCKS;
+  // the W^T image: cached while the weights are frozen / refreshed behind Adam, else in the caller's scratch
+  bool have_wt = false;
+  char* wimg = (char*)cached_image(ctx, W[1], 13, HX_WT_BYTES, &have_wt);
+  const bool cached_wt = wimg != nullptr;
+  if (!wimg) wimg = wt_img;
   {
     ProfScope ps(ctx, st, "edge_bwd_h2_prep");
-    hipLaunchKernelGGL(h2_pack_wt_kernel, dim3(16), dim3(256), 0, st, W[1], W[2], (unsigned*)wt_img);
+    if (!have_wt) {
+      PackJob j;
+      j.kind = PK_EDGE_WT; j.blocks = 16; j.src[0] = W[1]; j.src[1] = W[2]; j.dst[0] = wimg;
+      if (int rc = pack_launch(ctx, st, j)) return rc;
+      if (cached_wt) cache_set_job(ctx, W[1], 13, j);
+    }
     const int nb = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
     hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb), dim3(256), 0, st, de, n_edges * E, blockmax);
     hipLaunchKernelGGL(hx_scale_kernel, dim3(1), dim3(128), 0, st, blockmax, nb, W[1], W[2], W[3], E, scale);
@@ -724,7 +722,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     EdgeBwdH2Args a;
     a.n_edges = std::min<int64_t>(HX_SEG_EDGES, n_edges - e0); a.d_src = d_src + e0; a.d_eff = d_eff + e0; a.centers = centers;
     a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
-    a.wt_img = wt_img; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH;
+    a.wt_img = wimg; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH;
     a.de = live.perm ? de : de + e0 * E;
     a.perm = live.perm ? live.perm + e0 : nullptr; a.n_live = live.n_live; a.row_base = e0;
     a.partial = partial + (size_t)sg * grid * part_stride; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;

@@ -11,6 +11,7 @@ constexpr int FMAX_E = 8;
 
 // Wpk / WpkT: fragment-ordered copies of the three hidden weight matrices (see edge_fused.hip)
 int edge_fused_pack(ng_ctx* ctx, hipStream_t st, const float* const* W, float* Wpk, float* WpkT);
+PackJob edge_fused_pack_job(const float* const* W, float* Wpk, float* WpkT);
 
 }  // namespace ng
 

@@ -20,6 +20,7 @@
 
 #include "mfma_gemm.cuh"
 #include "edge_fused.h"
+#include "pack_bodies.cuh"
 
 namespace ng {
 
@@ -34,24 +35,8 @@ __device__ __forceinline__ float softplus_fast(float x) {
 
 // Wpk[layer][w][t][lane][s] = W[layer][k = 8t + 4*(lane>>5) + s][n = 32w + (lane&31)]   (forward)
 // WpkT[layer][w][t][lane][s] = W[layer][k = 32w + (lane&31)][n = 8t + 4*(lane>>5) + s]  (dX = dP W^T)
-__global__ void pack_weights_kernel(int n_layers, const float* __restrict__ W0,
-                                    const float* __restrict__ W1, const float* __restrict__ W2,
-                                    float* __restrict__ Wpk, float* __restrict__ WpkT) {
-  const int per_layer = FH * FH;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_layers * per_layer;
-       idx += gridDim.x * blockDim.x) {
-    const int layer = idx / per_layer;
-    int r = idx % per_layer;
-    const int s = r & 3; r >>= 2;
-    const int lane = r & 63; r >>= 6;
-    const int t = r & 15; r >>= 4;
-    const int w = r;
-    const float* Wl = layer == 0 ? W0 : (layer == 1 ? W1 : W2);
-    const int ka = 8 * t + 4 * (lane >> 5) + s, na = 32 * w + (lane & 31);
-    Wpk[idx] = Wl[ka * FH + na];
-    if (WpkT) WpkT[idx] = Wl[na * FH + ka];
-  }
-}
+// (packed by pack_bodies.cuh: PK_EDGE_F32)
+static_assert(FH == pk::FHd, "pack_bodies.cuh");
 
 struct EdgeFwdArgs {
   int64_t n_edges;
@@ -312,11 +297,15 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
   }
 }
 
+PackJob edge_fused_pack_job(const float* const* W, float* Wpk, float* WpkT) {
+  PackJob j;
+  j.kind = PK_EDGE_F32; j.blocks = 48;
+  j.src[0] = W[0]; j.src[1] = W[1]; j.src[2] = W[2]; j.dst[0] = Wpk; j.dst[1] = WpkT;
+  return j;
+}
+
 int edge_fused_pack(ng_ctx* ctx, hipStream_t st, const float* const* W, float* Wpk, float* WpkT) {
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(48), dim3(256), 0, st, 3, W[0], W[1], W[2], Wpk,
-                     WpkT);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  return pack_launch(ctx, st, edge_fused_pack_job(W, Wpk, WpkT));
 }
 
 bool edge_fused_supported(int H, int E, int Le) { return H == FH && Le == 4 && E >= 1 && E <= FMAX_E; }
@@ -341,10 +330,14 @@ int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
   // (frozen weights: the fragment copy is kept like every other packed image — one launch less per call)
   bool have = false;
   float* Wpk = (float*)cached_image(ctx, W[0], 11, (pk_floats + FH) * 4, &have);
+  const bool cached = Wpk != nullptr;
   if (!Wpk) Wpk = (float*)(guard ? aux_workspace(ctx, (pk_floats + FH) * 4) : workspace(ctx, (pk_floats + FH) * 4));
   if (!Wpk) return NG_ERR_NOMEM;
-  int rc = have ? NG_OK : edge_fused_pack(ctx, st, W, Wpk, nullptr);
-  if (rc) return rc;
+  if (!have) {
+    const PackJob j = edge_fused_pack_job(W, Wpk, nullptr);
+    if (int rc = pack_launch(ctx, st, j)) return rc;
+    if (cached) cache_set_job(ctx, W[0], 11, j);
+  }
   EdgeFwdArgs a;
   a.tape_blocked = tape_blocked ? 1 : 0;
   a.guard = guard ? *guard : RangeGuard{nullptr, 0};

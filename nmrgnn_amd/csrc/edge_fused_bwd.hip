@@ -411,13 +411,20 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
   const int stride = (bwd_part_floats(E) + 3) / 4 * 4;
   const size_t pk_floats = (size_t)3 * FH * FH;
   const int nseg = edge_bwd_h2_segments(n_edges);      // launches of the split-operand kernel (1 below 8.4 M edges)
-  float* ws = (float*)workspace(ctx, (pk_floats * 2 + (size_t)nseg * grid * stride) * 4 + edge_bwd_h2_ws_bytes());
+  // W^T fragments of the f32-input kernel (the strict-fp32 path, or the range fallback of the split-operand kernel): a
+  // cached image while the weights are frozen / refreshed behind Adam (pack_bodies.cuh), else packed into the scratch
+  bool haveT = false;
+  float* WpkT = (float*)cached_image(ctx, W[0], 12, pk_floats * 4, &haveT);
+  const bool cachedT = WpkT != nullptr;
+  float* ws = (float*)workspace(ctx, (pk_floats + (size_t)nseg * grid * stride) * 4 + edge_bwd_h2_ws_bytes());
   if (!ws) return NG_ERR_NOMEM;
-  float* Wpk = ws;
-  float* WpkT = ws + pk_floats;
-  float* partial = ws + 2 * pk_floats;
-  int rc = edge_fused_pack(ctx, st, W, Wpk, WpkT);
-  if (rc) return rc;
+  if (!cachedT) WpkT = ws;
+  float* partial = ws + pk_floats;
+  if (!haveT) {
+    const PackJob j = edge_fused_pack_job(W, nullptr, WpkT);
+    if (int rc = pack_launch(ctx, st, j)) return rc;
+    if (cachedT) cache_set_job(ctx, W[0], 12, j);
+  }
   EdgeBwdArgs a;
   a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;
   a.neg_inv_gap = (float)(-1.0 / (double)gap);

@@ -29,6 +29,7 @@
 
 #include "edge_fused.h"
 #include "h2_common.cuh"
+#include "pack_bodies.cuh"
 
 namespace ng {
 
@@ -44,35 +45,11 @@ constexpr float H2_WSCALE = (float)(1 << H2_WS), H2_WINV = 1.0f / (float)(1 << H
 // feature (within a 32-block) held in k-slot t (0..7) of k-step s by lane half hf  ==  accumulator register 8s+t
 __host__ __device__ inline int h2_feat(int t, int s, int hf) { return (t & 3) + 16 * s + 8 * (t >> 2) + 4 * hf; }
 
-// Weight image: chunk c (0..5): layer c>>1, output blocks 2*(c&1) + {0,1};  chunk 6: output layer (rows >= E zero).
+// Weight image (packed by pack_bodies.cuh: PK_EDGE_H2): chunk c (0..5): layer c>>1, output blocks 2*(c&1) + {0,1};  chunk 6:
+// output layer (rows >= E zero).
 //   fragment ((bo_l*4 + bi)*2 + s)*2 + p, 1 KB each, lane-linear 16 B per lane:
 //   lane (row i = l&31, k-slot t) = piece_p( 2^WS W[k = 32 bi + h2_feat(t, s, l>>5)][n = 32 bo + i] )
-__global__ void h2_pack_kernel(const float* __restrict__ W0, const float* __restrict__ W1,
-                               const float* __restrict__ W2, const float* __restrict__ Wo, int E,
-                               unsigned* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (chunk, bo_l, bi, s, lane)
-  if (idx >= H2_NCHUNK * 16 * 64) return;
-  const int lane = idx & 63, s = (idx >> 6) & 1, bi = (idx >> 7) & 3, bo_l = (idx >> 9) & 1, c = idx >> 10;
-  const int i = lane & 31, hf = lane >> 5;
-  float v[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int k = 32 * bi + h2_feat(t, s, hf);
-    if (c < 6) {
-      const float* W = (c >> 1) == 0 ? W0 : ((c >> 1) == 1 ? W1 : W2);
-      v[t] = H2_WSCALE * W[k * FH + 32 * (2 * (c & 1) + bo_l) + i];
-    } else {
-      v[t] = (bo_l == 0 && i < E) ? H2_WSCALE * Wo[k * E + i] : 0.f;
-    }
-  }
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) split2_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
-  const int frag = ((bo_l * 4 + bi) * 2 + s) * 2;
-  unsigned* dst = img + (size_t)c * (H2_CHUNK / 4) + (size_t)frag * 256 + lane * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
-}
+static_assert(H2_NCHUNK == pk::H2_NCHUNKd && H2_CHUNK == pk::H2_CHUNKd && H2_WSCALE == pk::WSCALE && FH == pk::FHd, "pack_bodies.cuh");
 
 struct EdgeH2Args {
   int64_t n_edges;
@@ -461,12 +438,15 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   const size_t img_bytes = (size_t)H2_NCHUNK * H2_CHUNK;
   bool have = false;
   char* img = (char*)cached_image(ctx, W[0], 6, img_bytes + FH * 4, &have);
+  const bool cached = img != nullptr;
   if (!img) img = (char*)workspace(ctx, img_bytes + FH * 4);
   if (!img) return NG_ERR_NOMEM;
   if (!have) {
-    hipLaunchKernelGGL(h2_pack_kernel, dim3(cdiv(H2_NCHUNK * 16 * 64, 256)), dim3(256), 0, st, W[0], W[1], W[2], W[3], E,
-                       (unsigned*)img);
-    NG_HIP(ctx, hipGetLastError());
+    PackJob j;
+    j.kind = PK_EDGE_H2; j.blocks = (int)cdiv(H2_NCHUNK * 16 * 64, PKB); j.i0 = E;
+    j.src[0] = W[0]; j.src[1] = W[1]; j.src[2] = W[2]; j.src[3] = W[3]; j.dst[0] = img;
+    if (int rc = pack_launch(ctx, st, j)) return rc;
+    if (cached) cache_set_job(ctx, W[0], 6, j);
   }
   EdgeH2Args a;
   a.n_edges = n_edges; a.d_src = d_src; a.d_eff = d_eff; a.centers = centers;

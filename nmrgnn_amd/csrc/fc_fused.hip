@@ -16,6 +16,7 @@
 
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
+#include "pack_bodies.cuh"
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "reduce.cuh"
 
@@ -39,27 +40,8 @@ struct FcPtrs {
 
 // forward fragments:  Wf[((l*4 + ct)*4 + T)*64 + lane][u] = W_l[k = 16T + 4(lane>>4) + u][n = 16ct + (lane&15)]
 // backward fragments: Wb[((l*4 + kt)*4 + T)*64 + lane][u] = W_l[k = 16kt + (lane&15)][n = 16T + 4(lane>>4) + u]
-// (columns n >= n_out of the last layer are zero)
-__global__ void fc_pack_kernel(int L, FcPtrs p, float* __restrict__ Wf, float* __restrict__ Wb) {
-  const int per_layer = FC_F * FC_F;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L * per_layer; idx += gridDim.x * blockDim.x) {
-    const int l = idx / per_layer;
-    int r = idx % per_layer;
-    const int u = r & 3; r >>= 2;
-    const int lane = r & 63; r >>= 6;
-    const int T = r & 3; r >>= 2;
-    const int ct = r;
-    const int nout = l == L - 1 ? FC_H : FC_F;
-    {
-      const int k = 16 * T + 4 * (lane >> 4) + u, n = 16 * ct + (lane & 15);
-      Wf[idx] = n < nout ? p.W[l][k * nout + n] : 0.f;
-    }
-    {
-      const int k = 16 * ct + (lane & 15), n = 16 * T + 4 * (lane >> 4) + u;
-      Wb[idx] = n < nout ? p.W[l][k * nout + n] : 0.f;
-    }
-  }
-}
+// (columns n >= n_out of the last layer are zero; packed by pack_bodies.cuh: PK_FC)
+static_assert(FC_F == pk::FC_Fd && FC_H == pk::FC_Hd && FC_MAXL == 6, "pack_bodies.cuh");
 
 struct FcFwdArgs {
   int64_t N;
@@ -449,25 +431,39 @@ bool fc_fused_supported(int F, int L) {
 
 size_t fc_fused_pack_floats(int L) { return (size_t)2 * L * FC_F * FC_F + 64; }
 
-int fc_fused_pack(ng_ctx* ctx, hipStream_t st, int L, const float* const* W, float* Wf, float* Wb) {
-  FcPtrs p{};
-  for (int l = 0; l < L; ++l) p.W[l] = W[l];
-  hipLaunchKernelGGL(fc_pack_kernel, dim3(32), dim3(256), 0, st, L, p, Wf, Wb);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+// the block's packed weights (forward + backward fragments + a dummy row): the cached image of the weights when the cache is
+// on (shared by the forward and the backward of a step, refreshed behind Adam), else `scratch`
+static float* fc_packed(ng_ctx* ctx, hipStream_t st, int L, const float* const* W, float* scratch, int* rc) {
+  bool have = false;
+  float* ws = (float*)cached_image(ctx, W[0], 5, fc_fused_pack_floats(L) * 4, &have);
+  const bool cached = ws != nullptr;
+  if (!ws) ws = scratch;
+  *rc = NG_OK;
+  if (!ws) return nullptr;      // not cacheable and the caller brought no scratch: it calls again with one
+  if (!have) {
+    PackJob j;
+    j.kind = PK_FC; j.blocks = 32; j.i0 = L;
+    for (int l = 0; l < L; ++l) j.src[l] = W[l];
+    j.dst[0] = ws; j.dst[1] = ws + (size_t)L * FC_F * FC_F;
+    *rc = pack_launch(ctx, st, j);
+    if (*rc == NG_OK && cached) cache_set_job(ctx, W[0], 5, j);
+  }
+  return ws;
 }
 
 int fc_fused_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const float* x, const float* const* W,
                  const float* const* b, float* const* y, float* g) {
   if (N == 0) return NG_OK;
-  bool have = false;
-  float* ws = (float*)cached_image(ctx, W[0], 5, fc_fused_pack_floats(L) * 4, &have);
-  if (!ws) ws = (float*)workspace(ctx, fc_fused_pack_floats(L) * 4);
-  if (!ws) return NG_ERR_NOMEM;
-  float* Wf = ws;
-  float* Wb = ws + (size_t)L * FC_F * FC_F;
-  int rc = have ? NG_OK : fc_fused_pack(ctx, st, L, W, Wf, Wb);
+  float* scratch = ctx->wcache ? nullptr : (float*)workspace(ctx, fc_fused_pack_floats(L) * 4);
+  int rc = NG_OK;
+  float* ws = fc_packed(ctx, st, L, W, scratch, &rc);
+  if (!ws) {      // (cache on, but this source is not cacheable)
+    scratch = (float*)workspace(ctx, fc_fused_pack_floats(L) * 4);
+    if (!scratch) return NG_ERR_NOMEM;
+    ws = fc_packed(ctx, st, L, W, scratch, &rc);
+  }
   if (rc) return rc;
+  float* Wf = ws;
   FcFwdArgs a{};
   a.N = N; a.act = act; a.x = x; a.Wf = Wf; a.g = g; a.dummy = ws + (size_t)2 * L * FC_F * FC_F;
   for (int l = 0; l < L; ++l) {
@@ -495,14 +491,14 @@ int fc_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const f
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu);
   float* ws = (float*)workspace(ctx, (fc_fused_pack_floats(L) + (size_t)(grid + 1) * part) * 4);
   if (!ws) return NG_ERR_NOMEM;
-  float* Wf = ws;
-  float* Wb = ws + (size_t)L * FC_F * FC_F;
-  float* dummy = ws + (size_t)2 * L * FC_F * FC_F;
   float* partial = ws + fc_fused_pack_floats(L);
   float* summed = partial + (size_t)grid * part;
   if (float* dp = deferred_partials(ctx, (size_t)grid * part)) partial = dp;
-  int rc = fc_fused_pack(ctx, st, L, W, Wf, Wb);
+  int rc = NG_OK;
+  float* pkd = fc_packed(ctx, st, L, W, ws, &rc);
   if (rc) return rc;
+  float* Wb = pkd + (size_t)L * FC_F * FC_F;
+  float* dummy = pkd + (size_t)2 * L * FC_F * FC_F;
   FcBwdArgs a{};
   a.N = N; a.act = act; a.g = g; a.dg = dg; a.Wb = Wb; a.dx = dx; a.partial = partial; a.part_stride = part;
   a.dummy = dummy;

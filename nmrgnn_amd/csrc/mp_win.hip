@@ -34,6 +34,7 @@
 #include "ng_internal.h"
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "h2_common.cuh"
+#include "pack_bodies.cuh"
 
 namespace ng {
 
@@ -46,143 +47,36 @@ constexpr int WTHREADS = 512;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// ---- weight fragments for v_mfma_f32_16x16x4_f32 (A operand: row i = lane & 15, k = lane >> 4) ----
-// out[((ct*NT + T)*64 + lane)*4 + u] = Wsrc(k = 16T + 4(lane>>4) + u, o = 16ct + (lane&15))
-// mode 0 (forward):       Wsrc(k = n*64 + l, o = m) = w[l][m][n]
-// mode 1 (back to nodes): Wsrc(k = n*64 + m, o = l) = w[l][m][n]
-// mode 2 (dA = dP Wp^T):  Wsrc(k = m, o = n*64 + l) = w[l][m][n]
-// blockIdx.y selects the job: the backward packs its two images (modes 2 and 1) in one launch
-__device__ __forceinline__ void mpw_pack_f32_body(int E, int mode, const float* __restrict__ w, float* __restrict__ out) {
-  const int KF = E * WF;
-  const int kdim = mode == 2 ? WF : KF;
-  const int odim = mode == 2 ? KF : WF;
-  const int NT = kdim / 16;
-  const int total = kdim * odim;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    int r = idx;
-    const int u = r & 3; r >>= 2;
-    const int lane = r & 63; r >>= 6;
-    const int T = r % NT, ct = r / NT;
-    const int k = 16 * T + 4 * (lane >> 4) + u;
-    const int o = 16 * ct + (lane & 15);
-    float v;
-    if (mode == 0) {
-      v = w[((k % WF) * WF + o) * E + k / WF];
-    } else if (mode == 1) {
-      v = w[(o * WF + (k % WF)) * E + k / WF];
-    } else {
-      v = w[((o % WF) * WF + k) * E + o / WF];
-    }
-    out[idx] = v;
-  }
-}
-
-__global__ void mpw_pack_kernel(int E, int mode0, const float* __restrict__ w, float* __restrict__ out0, int mode1,
-                                float* __restrict__ out1) {
-  mpw_pack_f32_body(E, blockIdx.y == 0 ? mode0 : mode1, w, blockIdx.y == 0 ? out0 : out1);
-}
-
-// a weight whose fp16 pieces (of 2^8 w) leave the fp16 range: the piece kernels hand the call to the fp32-input ones
-// (RangeGuard, ng_internal.h)
-__device__ __forceinline__ bool mpw_out_of_range(float w256) { return !(fabsf(w256) < 65504.0f); }
-
-// ---- weight fragments for v_mfma_f32_16x16x32_f16 with two-piece operands (forward, h2_common.cuh) ----
-// out[(((ct*NT2 + T)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of 2^8 Wsrc(k = 32T + 8(lane>>4) + t,
-// o = 16ct + (lane&15)),  Wsrc(k = n*64 + l, o = m) = w[l][m][n]  (mode 0 above)
-// blockIdx.y == 1 (when launched so): the fp32 fragment image (mode 0 above) for the fallback launch.  A weight out of
-// the piece range raises the guard and, for an image kept over calls (ng_weights_frozen), the image's own flag word.
-__global__ void mpw_pack_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ out, float* __restrict__ out_f32,
-                                   RangeGuard guard, unsigned* __restrict__ wflag) {
-  if (blockIdx.y == 1) { mpw_pack_f32_body(E, 0, w, out_f32); return; }
-  const int KF = E * WF, NT2 = KF / 32;
-  bool bad = false;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 4 * NT2 * 64; idx += gridDim.x * blockDim.x) {   // (ct, T, lane)
-    const int lane = idx & 63, T = (idx >> 6) % NT2, ct = (idx >> 6) / NT2;
-    const int o = 16 * ct + (lane & 15);
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k0 = 32 * T + 8 * (lane >> 4) + 2 * j, k1 = k0 + 1;
-      const float v0 = 256.0f * w[((k0 % WF) * WF + o) * E + k0 / WF], v1 = 256.0f * w[((k1 % WF) * WF + o) * E + k1 / WF];
-      bad |= mpw_out_of_range(v0) || mpw_out_of_range(v1);
-      split2_pair(v0, v1, h[j], l[j]);
-    }
-    unsigned* d = out + ((size_t)((ct * NT2 + T) * 2) * 64 + lane) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
-  }
-  if (bad && guard.word) {
-    range_guard_raise(guard, true);
-    if (wflag) *wflag = 1u;
-  }
-}
+// ---- weight images (packed by pack_bodies.cuh) ----
+// f32 fragments for v_mfma_f32_16x16x4_f32 (A operand: row i = lane & 15, k = lane >> 4):
+//   out[((ct*NT + T)*64 + lane)*4 + u] = Wsrc(k = 16T + 4(lane>>4) + u, o = 16ct + (lane&15))
+//   mode 0 (forward):       Wsrc(k = n*64 + l, o = m) = w[l][m][n]
+//   mode 1 (back to nodes): Wsrc(k = n*64 + m, o = l) = w[l][m][n]
+//   mode 2 (dA = dP Wp^T):  Wsrc(k = m, o = n*64 + l) = w[l][m][n]
+// fp16 piece fragments for v_mfma_f32_16x16x32_f16 (two-piece operands, h2_common.cuh), the same three index maps:
+//   out[(((ct*NT2 + T)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of 2^8 Wsrc(k = 32T + 8(lane>>4) + t,
+//   o = 16ct + (lane&15))
+// A weight whose pieces (of 2^8 w) leave the fp16 range raises the call's guard and stores the image version into the
+// image's flag word: the window kernels then take their fp32-input body (RangeGuard, ng_internal.h).
+static_assert(WF == pk::WFd, "pack_bodies.cuh");
 
 int mpw_pack(ng_ctx* ctx, hipStream_t st, int E, int mode, const float* w, float* out) {
-  hipLaunchKernelGGL(mpw_pack_kernel, dim3(24, 1), dim3(256), 0, st, E, mode, w, out, 0, (float*)nullptr);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  PackJob j;
+  j.kind = PK_MPW_F32; j.blocks = 24; j.i0 = E; j.i1 = mode; j.src[0] = w; j.dst[0] = out;
+  return pack_launch(ctx, st, j);
 }
 
-// backward images in ONE launch: blockIdx.y = 0 -> the dA = dP Wp^T image as fp16 piece fragments for
-// v_mfma_f32_16x16x32_f16 (mp_win_bwd_edge_kernel<E, true>):
-//   outT[(((ctile*2 + Ts)*2 + p)*64 + lane)*4 + j] = fp16 pair (t = 2j, 2j+1) of piece p of
-//   2^8 Wsrc2(k = 32 Ts + 8 (lane>>4) + t, o = 16 ctile + (lane&15)),  Wsrc2(k = m, o = n*64 + l) = w[l][m][n];
-// blockIdx.y = 1 -> the dh = B Wn image in the same fp16 piece form (mp_win_bwd_node_kernel<E, true>)
-__global__ void mpw_pack_bwd_h2_kernel(int E, const float* __restrict__ w, unsigned* __restrict__ outT, float* __restrict__ outN,
-                                       float* __restrict__ f32T, float* __restrict__ f32N, RangeGuard guard) {
-  const int KF = E * WF;
-  // blockIdx.y = 2, 3 (when launched so): the fp32 fragment images (modes 2 and 1) for the fallback launches
-  if (blockIdx.y >= 2) { mpw_pack_f32_body(E, blockIdx.y == 2 ? 2 : 1, w, blockIdx.y == 2 ? f32T : f32N); return; }
-  bool bad = false;
-  if (blockIdx.y == 0) {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (KF / 16) * 2 * 64; idx += gridDim.x * blockDim.x) {
-      const int lane = idx & 63, Ts = (idx >> 6) & 1, ctile = idx >> 7;
-      const int o = 16 * ctile + (lane & 15);
-      unsigned h[4], l[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k0 = 32 * Ts + 8 * (lane >> 4) + 2 * j;
-        const float v0 = 256.0f * w[((o % WF) * WF + k0) * E + o / WF], v1 = 256.0f * w[((o % WF) * WF + k0 + 1) * E + o / WF];
-        bad |= mpw_out_of_range(v0) || mpw_out_of_range(v1);
-        split2_pair(v0, v1, h[j], l[j]);
-      }
-      unsigned* d = outT + ((size_t)((ctile * 2 + Ts) * 2) * 64 + lane) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
-    }
-  } else {
-    // dh = B Wn image, same fragment form: Wsrc1(k = n*64 + m, o = l) = w[l][m][n], contraction over k (KF/32 steps)
-    const int NT2 = KF / 32;
-    unsigned* outNu = reinterpret_cast<unsigned*>(outN);
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 4 * NT2 * 64; idx += gridDim.x * blockDim.x) {
-      const int lane = idx & 63, T = (idx >> 6) % NT2, ct = (idx >> 6) / NT2;
-      const int o = 16 * ct + (lane & 15);
-      unsigned h[4], l[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k0 = 32 * T + 8 * (lane >> 4) + 2 * j, k1 = k0 + 1;
-        split2_pair(256.0f * w[(o * WF + (k0 % WF)) * E + k0 / WF], 256.0f * w[(o * WF + (k1 % WF)) * E + k1 / WF], h[j], l[j]);
-      }
-      unsigned* d = outNu + ((size_t)((ct * NT2 + T) * 2) * 64 + lane) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[j] = h[j]; d[256 + j] = l[j]; }
-    }
-  }
-  if (bad && guard.word) range_guard_raise(guard, true);       // the first image sees every weight
-}
-
-int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN, float* f32T, float* f32N,
-                    RangeGuard guard) {
-  hipLaunchKernelGGL(mpw_pack_bwd_h2_kernel, dim3(24, f32T ? 4 : 2), dim3(256), 0, st, E, w, (unsigned*)outT, outN, f32T, f32N,
-                     guard);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+// every backward image of a layer in one launch: T / N piece fragments (+ the two f32 images of a guarded call)
+PackJob mpw_bwd_job(int E, const float* w, float* outT, float* outN, float* f32T, float* f32N, unsigned* flag, RangeGuard guard) {
+  PackJob j;
+  j.kind = PK_MPW_BWD; j.blocks = f32T ? 96 : 48; j.i0 = E; j.src[0] = w;
+  j.dst[0] = outT; j.dst[1] = outN; j.dst[2] = f32T; j.dst[3] = f32N; j.flag = flag; j.guard = guard;
+  return j;
 }
 
 int mpw_pack2(ng_ctx* ctx, hipStream_t st, int E, const float* w, int mode_a, float* out_a, int mode_b, float* out_b) {
-  hipLaunchKernelGGL(mpw_pack_kernel, dim3(24, 2), dim3(256), 0, st, E, mode_a, w, out_a, mode_b, out_b);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  if (int rc = mpw_pack(ctx, st, E, mode_a, w, out_a)) return rc;
+  return mpw_pack(ctx, st, E, mode_b, w, out_b);
 }
 
 // ---- shared device pieces ---------------------------------------------------------------------------
@@ -540,7 +434,8 @@ struct MpWinFwdArgs {
   int act;
   float* dummy;            // 64 floats: where the lanes of rows >= N store
   RangeGuard guard;        // word == nullptr: unguarded (NG_GEMM_MATH=fp32)
-  const unsigned* wflag;   // flag word of a weight image kept over calls (weights out of the piece range), or nullptr
+  const unsigned* wflag;   // flag word of a weight image kept over calls, or nullptr: == wflag_ver when its weights left the piece range
+  unsigned wflag_ver;
   const float* Wfrag32;    // fp32 fragments (mpw_pack mode 0) a guarded call switches to when its weights leave the range
 #ifdef MPW_STAMP
   unsigned long long* stamps;
@@ -725,7 +620,7 @@ __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
 // in the one kernel; the choice is uniform over the launch and costs no second launch.
 template <int E, bool K4, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a) {
-  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag != 0u))) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) {
     a.Wfrag = a.Wfrag32;
     mp_win_fwd_body<E, K4, false>(a);
   } else {
@@ -1172,29 +1067,31 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
     guard = range_guard_begin(ctx);
     if (!guard.word) return NG_ERR_NOMEM;
   }
-  // image: KF*64 floats (fp32 fragments / two fp16 pieces) + 64 floats of dummy row + the flag word; different cache kinds
+  // image: KF*64 floats (fp32 fragments / two fp16 pieces) + 64 floats of dummy row + the flag word; a guarded call keeps
+  // the f32 image of the same weights behind it (one cached buffer, one pack job)
   const size_t img_floats = (size_t)KF * WF + 64 + 16;
-  bool have = false, have32 = false;
-  float* Wfrag = (float*)cached_image(ctx, w, h2 ? 7 : 4, img_floats * 4, &have);
-  float* Wf32 = guarded && Wfrag ? (float*)cached_image(ctx, w, 4, img_floats * 4, &have32) : nullptr;
-  if (Wfrag && guarded && !Wf32) return NG_ERR_NOMEM;
+  const size_t tot_floats = guarded ? 2 * img_floats : img_floats;
+  bool have = false;
+  float* Wfrag = (float*)cached_image(ctx, w, h2 ? 7 : 4, tot_floats * 4, &have);
   const bool cached = Wfrag != nullptr;
   if (!cached) {
-    Wfrag = (float*)workspace(ctx, 2 * img_floats * 4);
+    Wfrag = (float*)workspace(ctx, tot_floats * 4);
     if (!Wfrag) return NG_ERR_NOMEM;
-    Wf32 = guarded ? Wfrag + img_floats : nullptr;
-    have = have32 = false;
+    have = false;
   }
+  float* Wf32 = guarded ? Wfrag + img_floats : nullptr;
   unsigned* wflag = cached && guarded ? reinterpret_cast<unsigned*>(Wfrag + KF * WF + 64) : nullptr;
-  int rc = NG_OK;
-  if (h2 && !(have && (have32 || !guarded))) {
-    if (wflag) NG_HIP(ctx, hipMemsetAsync(wflag, 0, 4, st));
-    hipLaunchKernelGGL(mpw_pack_h2_kernel, dim3(24, guarded ? 2 : 1), dim3(256), 0, st, E, w, (unsigned*)Wfrag, Wf32, guard, wflag);
-    NG_HIP(ctx, hipGetLastError());
-  } else if (!h2 && !have) {
-    rc = mpw_pack(ctx, st, E, 0, w, Wfrag);
+  if (!have) {
+    PackJob j;
+    if (h2) {
+      j.kind = PK_MPW_FWD; j.blocks = guarded ? 48 : 24; j.i0 = E; j.src[0] = w; j.dst[0] = Wfrag; j.dst[1] = Wf32;
+      j.flag = wflag; j.guard = guard;
+    } else {
+      j.kind = PK_MPW_F32; j.blocks = 24; j.i0 = E; j.i1 = 0; j.src[0] = w; j.dst[0] = Wfrag;
+    }
+    if (int rc = pack_launch(ctx, st, j)) return rc;
+    if (cached) cache_set_job(ctx, w, h2 ? 7 : 4, j);
   }
-  if (rc) return rc;
   MpWinFwdArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
   // contiguous runs of tiles per workgroup, a multiple of 8 tiles (256 atoms) so that runs start on
@@ -1205,7 +1102,7 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
   a.out = h_out; a.S_save = s_save; a.act = act; a.dummy = Wfrag + KF * WF;
   const int grid = (int)cdiv(a.ntiles, per);
   const size_t lds = mp_win_lds_bytes(K, E);
-  a.guard = guard; a.wflag = wflag;
+  a.guard = guard; a.wflag = wflag; a.wflag_ver = pack_flag_version(ctx);
 #define CALL(EE, HH)                                                                                      \
   if (K % 4 == 0)                                                                                         \
     hipLaunchKernelGGL((mp_win_fwd_kernel<EE, true, HH>), dim3(grid), dim3(WTHREADS), lds, st, a);        \

@@ -24,6 +24,7 @@
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "reduce.cuh"
 #include "h2_common.cuh"
+#include "pack_bodies.cuh"
 
 namespace ng {
 
@@ -109,6 +110,8 @@ struct MpWinEdgeArgs {
   int accumulate;
   RangeGuard guard;        // word == nullptr: unguarded
   const float* WfragT32;   // fp32 fragments (mpw_pack mode 2) for a guarded call whose weights leave the piece range
+  const unsigned* wflag;   // flag word of an image kept over calls (== wflag_ver: its weights left the piece range), or nullptr
+  unsigned wflag_ver;
 };
 
 // one rotation step of the edge-gradient dot: this lane's chunk of dA[i][n][:] against the row of the slot
@@ -392,7 +395,7 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
 // no second launch on the timeline (an empty one costs ~4.6 us on this part, profiles/r03b).
 template <int E, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeArgs a) {
-  if (H2 && a.guard.word && range_guard_raised(a.guard)) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) {
     a.WfragT = a.WfragT32;
     mp_win_bwd_edge_body<E, false>(a);
   } else {
@@ -420,6 +423,8 @@ struct MpWinNodeArgs {
   float* dummy;
   RangeGuard guard;         // word == nullptr: unguarded
   const float* WfragN32;    // fp32 fragments (mpw_pack mode 1) for a guarded call whose weights leave the piece range
+  const unsigned* wflag;    // as in MpWinEdgeArgs
+  unsigned wflag_ver;
 };
 
 __device__ __forceinline__ void pk_axpy(f32x2& lo, f32x2& hi, float w, const float4& h) {
@@ -810,7 +815,7 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
 // construction, a weight image out of range is known at the first instruction and selects the fp32-input body.
 template <int E, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeArgs a) {
-  if (H2 && a.guard.word && range_guard_raised(a.guard)) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) {
     a.WfragN = a.WfragN32;
     mp_win_bwd_node_body<E, false>(a);
   } else {
@@ -882,7 +887,8 @@ size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E) { return (size_t)(ctx->num
 // guard.word != nullptr: WfragN is the piece image, WfragN32 the fp32 one the kernel switches to when the guard is up.
 int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
-                    float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32) {
+                    float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32,
+                    const unsigned* wflag, unsigned wflag_ver) {
   MpWinNodeArgs a{};
   a.N = N; a.ntiles = cdiv(N, WTA);
   const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
@@ -897,7 +903,7 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
     case 2: hipLaunchKernelGGL((mp_win_bwd_node_kernel<2, HH>), dim3(grid), dim3(WTHREADS), node_lds_bytes(E, HH), st, a); break; \
     case 3: hipLaunchKernelGGL((mp_win_bwd_node_kernel<3, HH>), dim3(grid), dim3(WTHREADS), node_lds_bytes(E, HH), st, a); break; \
   }
-  a.WfragN32 = WfragN32;
+  a.WfragN32 = WfragN32; a.wflag = wflag; a.wflag_ver = wflag_ver;
   {
     ProfScope ps(ctx, st, "mp_win_bwd_node");
     if (h2) { NODE(true) } else { NODE(false) }
@@ -916,7 +922,7 @@ bool mp_win_bwd_supported(int F, int E, int K) {
 int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
                     const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
                     const float* dh_out, float* dP, float* de, int de_accum, float* dummy, RangeGuard guard,
-                    const float* WfragT32) {
+                    const float* WfragT32, const unsigned* wflag, unsigned wflag_ver) {
   MpWinEdgeArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
   const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);
@@ -933,7 +939,7 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
     case 2: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<2, HH>), dim3(grid), dim3(WTHREADS), lds, st, a); break;   \
     case 3: hipLaunchKernelGGL((mp_win_bwd_edge_kernel<3, HH>), dim3(grid), dim3(WTHREADS), lds, st, a); break;   \
   }
-  a.WfragT32 = WfragT32;
+  a.WfragT32 = WfragT32; a.wflag = wflag; a.wflag_ver = wflag_ver;
   {
     ProfScope ps(ctx, st, "mp_win_bwd_edge");
     if (h2) { EDGE(true) } else { EDGE(false) }
@@ -963,33 +969,50 @@ int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, co
     guard = range_guard_begin(ctx);
     if (!guard.word) return NG_ERR_NOMEM;
   }
-  // scratch: four packed weight images (piece T, N; fp32 T, N) | dP [N,64] | records [N*K,4] (when the caller has none)
-  // | dw partials
+  // four packed weight images (piece T, N; fp32 T, N) + the flag word: a cached image while the weights are frozen /
+  // refreshed behind Adam (pack_bodies.cuh), else the head of the scratch.
+  // scratch: [images] | dP [N,64] | records [N*K,4] (when the caller has none) | dw partials
+  const size_t img_floats = (size_t)4 * KF * WF + 16;
+  bool have = false;
+  float* imgs = (float*)cached_image(ctx, w, h2 ? 8 : 14, img_floats * 4, &have);
+  const bool cached = imgs != nullptr;
   const size_t rec_floats = csc_rec ? 0 : (size_t)N * K * 4;
-  float* ws = (float*)workspace(ctx, (size_t)(4 * KF * WF + N * WF + rec_floats + dw_scr + 64) * 4);
+  float* ws = (float*)workspace(ctx, (size_t)((cached ? 0 : img_floats) + N * WF + rec_floats + dw_scr + 64) * 4);
   if (!ws) return NG_ERR_NOMEM;
-  float* WfragT = ws;
+  if (!cached) { imgs = ws; ws += img_floats; have = false; }
+  float* WfragT = imgs;
   float* WfragN = WfragT + KF * WF;
   float* WfragT32 = WfragN + KF * WF;
   float* WfragN32 = WfragT32 + KF * WF;
-  float* dP = WfragN32 + KF * WF;
+  unsigned* wflag = cached && guarded ? reinterpret_cast<unsigned*>(WfragN32 + KF * WF) : nullptr;
+  float* dP = ws;
   float* rec = dP + N * WF;
   float* scr = rec + rec_floats;
   float* dummy = scr + dw_scr;
   // deferred reductions (reduce.cuh): the dw partials of this layer stay in the reduction arena until the flush
   if (float* dscr = deferred_partials(ctx, dw_scr)) scr = dscr;
-  int rc = h2 ? mpw_pack_bwd_h2(ctx, st, E, w, WfragT, WfragN, guarded ? WfragT32 : nullptr, guarded ? WfragN32 : nullptr, guard)
-              : mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);     // all weight images in one launch
+  int rc = NG_OK;
+  if (!have) {
+    if (h2) {
+      const PackJob j = mpw_bwd_job(E, w, WfragT, WfragN, guarded ? WfragT32 : nullptr, guarded ? WfragN32 : nullptr, wflag, guard);
+      rc = pack_launch(ctx, st, j);
+      if (rc == NG_OK && cached) cache_set_job(ctx, w, 8, j);
+    } else {
+      rc = mpw_pack2(ctx, st, E, w, 2, WfragT, 1, WfragN);       // (strict-fp32 mode: two small launches, not registered)
+      if (cached) have = false;
+    }
+  }
   if (rc) return rc;
+  const unsigned wver = pack_flag_version(ctx);
   rc = mp_win_bwd_edge(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum, dummy, guard,
-                       WfragT32);
+                       WfragT32, wflag, wver);
   if (rc) return rc;
   if (!csc_rec) {
     rc = mp_win_records(ctx, st, N, K, E, csc_ptr, csc_edge, e, rec);
     if (rc) return rc;
     csc_rec = rec;
   }
-  return mp_win_bwd_node(ctx, st, N, E, h, dP, csc_ptr, csc_rec, WfragN, dh_out, dh_in, dw, scr, dummy, guard, WfragN32);
+  return mp_win_bwd_node(ctx, st, N, E, h, dP, csc_ptr, csc_rec, WfragN, dh_out, dh_in, dw, scr, dummy, guard, WfragN32, wflag, wver);
 }
 
 }  // namespace ng

@@ -11,6 +11,37 @@
 
 #include "../../include/nmrgnn_hip.h"
 
+namespace ng {
+// operand-range guard of the fp16-piece kernels (ng_internal.h has the protocol and the device helpers)
+struct RangeGuard {
+  unsigned* word;     // device word of the context (small scratch)
+  unsigned epoch;     // this call's number, never 0
+};
+
+// One weight image to (re)build — see pack_bodies.cuh for the kinds and their arguments
+enum PackKind : int {
+  PK_NONE = 0,
+  PK_EDGE_H2 = 1,    // edge forward fp16-piece image: src W0..W3, i0 = E, dst[0] = img [7][32 KB]
+  PK_EDGE_WT = 2,    // edge backward W^T piece fragments: src[0] = W2, src[1] = W3, dst[0] = img [64 KB]
+  PK_EDGE_F32 = 3,   // f32 fragments of the three hidden edge layers: src W0..W2, dst[0] = Wpk, dst[1] = WpkT (either may be null)
+  PK_MPW_FWD = 4,    // window forward: src[0] = w, i0 = E, dst[0] = piece image, dst[1] = f32 image (blocks 48) or none (24)
+  PK_MPW_BWD = 5,    // window backward: dst[0] = T pieces, dst[1] = N pieces, dst[2] / dst[3] = f32 T / N (blocks 96) or none (48)
+  PK_MPW_F32 = 6,    // one f32 fragment image: i1 = mode, dst[0]
+  PK_FC = 7,         // FC block: src[0..L-1] = W_l, i0 = L, dst[0] = Wf, dst[1] = Wb
+};
+struct PackJob {
+  int kind = PK_NONE;
+  int blocks = 0;     // of 256 threads
+  int i0 = 0, i1 = 0;
+  const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+  // weights out of the fp16 piece range (|2^8 w| >= 65504): the packer stores the image VERSION into *flag (a consumer
+  // compares with the version it was handed: nothing ever has to be cleared) and raises the per-call guard if there is one
+  unsigned* flag = nullptr;
+  RangeGuard guard = {nullptr, 0};
+};
+}  // namespace ng
+
 struct ng_prof_rec {
   const char* name;
   hipEvent_t start, stop;
@@ -38,11 +69,20 @@ struct ng_ctx {
   // packed weight images kept across calls while the caller declares the weights frozen (ng_weights_frozen):
   // inference repacks nothing.  key = (source pointer, image kind); an entry is valid while its version equals wver,
   // which ng_weights_changed / ng_adam_step / (un)freezing bump.
-  struct WImage { void* buf = nullptr; size_t bytes = 0; uint64_t ver = 0; };
+  // `job` (has_job): how to rebuild the image; ng_adam_step re-runs every registered job of the weights it has just
+  // updated in ONE launch (repack.hip) instead of leaving the images to be rebuilt one launch each at their next use
+  struct WImage { void* buf = nullptr; size_t bytes = 0; uint64_t ver = 0; bool has_job = false; ng::PackJob job; };
   bool wcache = false;
   int wowner = 0;
   uint64_t wver = 1;
   std::map<std::pair<const void*, int>, WImage> wimg;
+  // device copy of the registered jobs (rebuilt when the registry changes)
+  void* wjobs_dev = nullptr;
+  size_t wjobs_cap = 0;
+  bool wjobs_dirty = true;
+  int wjobs_n = 0, wjobs_blocks = 0;
+  uint64_t wjobs_hash = 0;      // of the job set the device copy holds
+  std::vector<char> wjobs_host;  // staging of the upload (stays alive while an asynchronous copy may read it)
   // operand-range guard of the fp16-piece kernels (ng_internal.h: RangeGuard): call counter behind the epochs
   uint32_t range_epoch = 0;
   // gradient exchange for a C-ABI caller (comm.hip): RCCL communicator of this rank, nullptr = none / world of one
@@ -113,6 +153,13 @@ void* small_scratch(ng_ctx* ctx);      // NG_SMALL_BYTES, allocated once per con
 // persistent buffer of `bytes` for (src, kind) with *valid = true when it already holds the image of the current
 // weights (skip the pack launch).  kinds: 1 MPLayer Wp, 3 GEMM fp16-piece image, 4 window fragments, 5 FC fragments, 6 edge fp16-piece image
 void* cached_image(ng_ctx* ctx, const void* src, int kind, size_t bytes, bool* valid);
+// after packing a cached image: remember how (pack_bodies.cuh), so that ng_adam_step can refresh it
+void cache_set_job(ng_ctx* ctx, const void* src, int kind, const PackJob& job);
+// one image now (first use / cache off); the version a flag word is compared with
+int pack_launch(ng_ctx* ctx, hipStream_t st, const PackJob& job);
+unsigned pack_flag_version(const ng_ctx* ctx);
+// every registered image whose sources all lie in [lo, hi): one launch on `st`; the images then carry the current version
+int repack_all(ng_ctx* ctx, hipStream_t st, const void* lo, const void* hi);
 
 // RAII-less profiling bracket: call begin before the launch(es), end after.
 struct ProfScope {

@@ -15,10 +15,7 @@ namespace ng {
 // case they recompute the whole call.  No host synchronisation, no flag to clear (epochs are unique per call, calls on
 // one stream are ordered), ~2 us of empty launch per guarded call.  A genuinely non-finite input takes the fp32 path as
 // well and comes out non-finite there too.
-struct RangeGuard {
-  unsigned* word;     // device word of the context (small scratch)
-  unsigned epoch;     // this call's number, never 0
-};
+// (struct RangeGuard {word, epoch} itself lives in ng_common.h: the context's image cache stores pack jobs that carry one)
 RangeGuard range_guard_begin(ng_ctx* ctx);
 // kernels: raise when `bad` (any lane), test at the top of the fallback
 __device__ __forceinline__ void range_guard_raise(RangeGuard g, bool bad) {
@@ -172,8 +169,7 @@ int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const f
             const float* e, float* A);
 // backward images, the dA image as fp16 piece fragments (mp_win.hip)
 // f32T / f32N (optional): the fp32 fragment images of the same launch, for the guarded fallback kernels
-int mpw_pack_bwd_h2(ng_ctx* ctx, hipStream_t st, int E, const float* w, float* outT, float* outN, float* f32T, float* f32N,
-                    RangeGuard guard);
+PackJob mpw_bwd_job(int E, const float* w, float* outT, float* outN, float* f32T, float* f32N, unsigned* flag, RangeGuard guard);
 int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
                const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
                float* s_save);
@@ -183,14 +179,15 @@ bool mp_win_bwd_supported(int F, int E, int K);
 int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h,
                     const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
                     const float* dh_out, float* dP, float* de, int de_accum, float* dummy, RangeGuard guard,
-                    const float* WfragT32);
+                    const float* WfragT32, const unsigned* wflag = nullptr, unsigned wflag_ver = 0);
 
 int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
                    const int32_t* csc_edge, const float* e, float* rec);
 size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E);
 int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
-                    float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32);
+                    float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32,
+                    const unsigned* wflag = nullptr, unsigned wflag_ver = 0);
 
 // window-resident MPLayer backward, both kernels (mp_win_bwd.hip)
 bool mp_win_bwd_enabled(int F, int E, int K);

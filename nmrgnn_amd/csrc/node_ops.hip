@@ -1048,9 +1048,13 @@ extern "C" int ng_adam_step(ng_ctx* ctx, void* stream, int64_t n, float* p, cons
   if (n == 0) return NG_OK;
   const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) /
                       (1.0 - std::pow((double)beta1, (double)step));
-  ProfScope ps(ctx, (hipStream_t)stream, "adam");
-  hipLaunchKernelGGL(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v,
-                     (float)lr_t, beta1, beta2, eps, grad_scale);
-  NG_HIP(ctx, hipGetLastError());
-  return NG_OK;
+  {
+    ProfScope ps(ctx, (hipStream_t)stream, "adam");
+    hipLaunchKernelGGL(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v,
+                       (float)lr_t, beta1, beta2, eps, grad_scale);
+    NG_HIP(ctx, hipGetLastError());
+  }
+  // every registered weight image fed by the block just updated: ONE launch here instead of one in front of each consumer
+  // of the next step (repack.hip; a no-op unless the image cache is on, ng_weights_frozen)
+  return repack_all(ctx, (hipStream_t)stream, p, p + n);
 }

@@ -83,6 +83,12 @@ class Engine:
         self.tape = None
         self._rng_calls = 0
         self._frozen = False
+        # training with refreshed images (round 4): the library keeps every packed weight image of this engine and
+        # ng_adam_step rebuilds them all in ONE launch right behind the update, instead of one small launch in front of
+        # every consumer of the next step.  Weights then have to change through adam_step / params.load_state_dict (or be
+        # followed by weights_changed()) — the Trainer, which owns the update, switches it on; a bare Engine keeps packing
+        # per call, so code that writes into parameter views directly stays correct.
+        self.cache_images = False
         self.defer_reductions = True      # backward(): queue the weight-gradient sums, one launch (ng_defer_reductions)
         # padded slots (edges == 0) are skipped by the fused edge kernels (include/nmrgnn_hip.h: ng_edge_mlp_fwd_live);
         # NG_EDGE_LIVE=0 runs every slot as rounds 1-3 did (A/B measurements, tests)
@@ -131,7 +137,7 @@ class Engine:
         forward too (no noise, no dropout — what autograd through ``model(g, training=False)`` differentiates).
         ``noise`` (xi[N,K], standard normal) / ``dropout_mask`` ([N,F/2], values 0 or 1/keep) may be
         supplied explicitly (parity tests); otherwise they are drawn on the GPU from ``seed``."""
-        if not self._frozen:
+        if not (self._frozen or self.cache_images):
             return self._forward(batch, training, noise, dropout_mask, seed, keep_tape)
         self._ck(self.lib.ng_weights_frozen(self.ctx.handle, self._id), "ng_weights_frozen")
         try:
@@ -269,9 +275,13 @@ class Engine:
         # the seven second-stage sums of the node-side weight gradients (head, FC block, MPLayers, embedding) are queued
         # and run as ONE launch before the node gradients are handed on (ng_defer_reductions: same bits, ~45 us less)
         self._ck(lib.ng_defer_reductions(h, st, 1 if self.defer_reductions else 0), "ng_defer_reductions")
+        if self.cache_images:
+            self._ck(lib.ng_weights_frozen(h, self._id), "ng_weights_frozen")
         try:
             self._backward(tp, dpeaks, on_node_grads, lib, h, st)
         finally:
+            if self.cache_images:
+                lib.ng_weights_frozen(h, 0)
             self._ck(lib.ng_defer_reductions(h, st, 0), "ng_defer_reductions")
 
     def _backward(self, tp, dpeaks, on_node_grads, lib, h, st):
@@ -370,6 +380,12 @@ class Engine:
             lr = float(self.hp.get('learning_rate'))
         self.adam_t += 1
         P = self.params
-        self._ck(self.lib.ng_adam_step(self.ctx.handle, self._st(), P.numel, ptr(P.flat), ptr(P.grad),
-                                       ptr(self.adam_m), ptr(self.adam_v), lr, beta1, beta2, eps,
-                                       self.adam_t, grad_scale), "ng_adam_step")
+        if self.cache_images:       # the update is followed by ONE launch that rebuilds this engine's packed weight images
+            self._ck(self.lib.ng_weights_frozen(self.ctx.handle, self._id), "ng_weights_frozen")
+        try:
+            self._ck(self.lib.ng_adam_step(self.ctx.handle, self._st(), P.numel, ptr(P.flat), ptr(P.grad),
+                                           ptr(self.adam_m), ptr(self.adam_v), lr, beta1, beta2, eps,
+                                           self.adam_t, grad_scale), "ng_adam_step")
+        finally:
+            if self.cache_images:
+                self.lib.ng_weights_frozen(self.ctx.handle, 0)

@@ -13,6 +13,8 @@ from .parallel import GradBuckets, shard_grad_weight
 class Trainer:
     def __init__(self, engine: Engine, lr=None, loss_balance=1.0):
         self.engine = engine
+        # the trainer owns the weight update: packed weight images are kept and refreshed in one launch behind Adam
+        engine.cache_images = True
         self.lr = lr
         self.loss_balance = float(loss_balance)      # NameLoss s (build_GNNModel's loss_balance)
         P = engine.params
