@@ -31,6 +31,8 @@ static void load_switches() {
   s.knn_serial = env_is("NG_KNN", "serial");
   s.knn_cells = env_is("NG_KNN", "cells");
   s.knn_brute = env_is("NG_KNN", "brute");
+  s.mp_gg_on = env_is("NG_MP_GG", "1");
+  if (const char* v = getenv("NG_MP_GG_MIN_ROWS")) { const long long r = atoll(v); if (r >= 1) s.mp_gg_min_rows = r; }
   g_sw = s;
   g_sw_loaded = true;
 }

@@ -116,6 +116,23 @@ __global__ __launch_bounds__(GL_BLOCK) void gl_sort_kernel(int64_t n, const int3
   if (t >= n) return;
   const int p0 = csc_ptr[t], p1 = cursor[t];      // after the fill a cursor stands at the end of its segment
   if (t == n - 1) csc_ptr[n] = p1;
+  // short segments (in-degree ~ K): all entries requested at once, ranked in registers — as a loop over memory the
+  // len^2 dependent reads of a single graph's 256 targets took 40 us of a 0.37-ms training step (profiles/r04d)
+  constexpr int GL_SORT_REG = 32;
+  const int len = p1 - p0;
+  if (len <= GL_SORT_REG) {
+    int32_t v[GL_SORT_REG];
+#pragma unroll
+    for (int a = 0; a < GL_SORT_REG; ++a) v[a] = a < len ? tmp[p0 + a] : 0x7fffffff;
+#pragma unroll
+    for (int a = 0; a < GL_SORT_REG; ++a) {
+      int rank = 0;
+#pragma unroll
+      for (int b = 0; b < GL_SORT_REG; ++b) rank += v[b] < v[a] ? 1 : 0;     // entry ids are distinct; the padding ranks last
+      if (a < len) csc_edge[p0 + rank] = v[a];
+    }
+    return;
+  }
   for (int a = p0; a < p1; ++a) {
     const int32_t v = tmp[a];
     int rank = 0;

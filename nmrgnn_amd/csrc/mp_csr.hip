@@ -426,6 +426,8 @@ int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
                    float* h_out, float* A_save, float* s_save) {
   const int64_t KF = (int64_t)E * F;
+  if (E <= 3 && mp_gg_supported(N, F, E))     // gather-GEMM (gemm_h2.hip): the aggregate only as a by-product when asked for
+    return mp_gg_fwd(ctx, st, N, K, F, E, act, residual, h, row_ptr, col, e, inv_degree, w, h_out, s_save, A_save);
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;
   bool have = false;
@@ -444,10 +446,14 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
                    const float* inv_degree, const float* w, const float* A_save, const float* s_save,
                    const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de,
-                   int de_accum, float* dw, const float* csc_rec) {
+                   int de_accum, float* dw, const float* csc_rec, int64_t nnz) {
   const int64_t KF = (int64_t)E * F;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
-  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + N * F + dw_scr + (A_save ? 0 : N * KF)) * 4);
+  // node side as a gather-GEMM over dP rows (gemm_h2.hip) needs the incoming-edge records; built here when the caller has none
+  const bool gg = E <= 3 && N > 0 && mp_gg_supported(N, F, E);
+  const int64_t n_ent = row_ptr ? nnz : N * K;
+  const size_t rec_floats = gg && !csc_rec ? (size_t)std::max<int64_t>(n_ent, 1) * 4 : 0;
+  float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + N * F + dw_scr + (A_save ? 0 : N * KF) + rec_floats) * 4);
   if (!ws) return NG_ERR_NOMEM;
   float* Wp = ws;
   float* dA = ws + KF * F;
@@ -455,9 +461,10 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
   float* scr = dP + N * F;
   int rc = mp_repack_w(ctx, st, F, E, w, Wp);
   if (rc) return rc;
+  const bool A_save_given = A_save != nullptr;
   if (!A_save) {   // the caller did not keep the forward aggregate: rebuild it
     float* Ar = scr + dw_scr;
-    rc = csr_aggregate(ctx, st, N, K, F, E, h, row_ptr, col, e, Ar);
+    rc = row_ptr ? csr_aggregate(ctx, st, N, K, F, E, h, row_ptr, col, e, Ar) : mp_aggregate_padded(ctx, st, N, K, F, E, h, col, e, Ar);
     if (rc) return rc;
     A_save = Ar;
   }
@@ -484,6 +491,17 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
   if (rc) return rc;
   rc = csr_edge_grad(ctx, st, N, K, F, E, h, row_ptr, col, dA, de, de_accum);
   if (rc) return rc;
+  // node side: dh_in = dh_out + pull of dA over the incoming edges — at the default width as a gather-GEMM over dP rows
+  // (1 KB per incoming edge instead of 3 KB of dA; gemm_h2.hip)
+  if (gg) {
+    if (!csc_rec) {
+      float* rec = scr + dw_scr + (A_save_given ? 0 : N * KF);
+      rc = mp_win_records(ctx, st, N, K, E, csc_ptr, csc_edge, e, rec, row_of, n_ent);
+      if (rc) return rc;
+      csc_rec = rec;
+    }
+    return mp_gg_pull(ctx, st, N, F, E, dP, csc_ptr, csc_rec, w, dh_out, dh_in, gsc);
+  }
   return csr_scatter_pull(ctx, st, N, K, F, E, row_of, csc_ptr, csc_edge, e, csc_rec, dA, dh_out, dh_in);
 }
 
@@ -650,7 +668,7 @@ extern "C" int ng_mp_layer_bwd_csr(ng_ctx* ctx, void* stream, int64_t N, int64_t
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "mp_layer_bwd: s_save required for an activation");
   NG_REQUIRE(ctx, nnz >= 0 && nnz < ((int64_t)1 << 31), "mp_layer (csr): nnz must fit int32");
   return mp_generic_bwd(ctx, (hipStream_t)stream, N, 0, F, E, act, h, row_ptr, col, row_of, e, inv_degree, w, A_save,
-                        s_save, csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw, nullptr);
+                        s_save, csc_ptr, csc_edge, dh_out, dh_in, de, de_accum, dw, nullptr, nnz);
 }
 
 extern "C" int ng_cutoff_count(ng_ctx* ctx, void* stream, int G, int n, float cutoff, const float* pos,

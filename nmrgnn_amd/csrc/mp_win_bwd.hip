@@ -823,9 +823,10 @@ __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeA
   }
 }
 
+// (row_of != nullptr: CSR lists — the source of entry eid is row_of[eid] instead of eid / K)
 __global__ void mp_records_kernel(int64_t N, int K, int E, const int32_t* __restrict__ csc_ptr,
                                   const int32_t* __restrict__ csc_edge, const float* __restrict__ e,
-                                  float4* __restrict__ rec) {
+                                  float4* __restrict__ rec, const int32_t* __restrict__ row_of) {
   const int64_t nnz = csc_ptr[N];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // four entries per trip: the four edge ids are requested together, then the twelve gathers (one entry per trip ran
@@ -837,7 +838,7 @@ __global__ void mp_records_kernel(int64_t N, int K, int E, const int32_t* __rest
     float4 r[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      r[u].x = __builtin_bit_cast(float, eid[u] / K);
+      r[u].x = __builtin_bit_cast(float, row_of ? row_of[eid[u]] : eid[u] / K);
       if (E == 3) {
         // one 12-byte load per entry (global_load_dwordx3): three scattered dword loads fetched the entry's sector three times
         struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
@@ -871,12 +872,12 @@ size_t edge_lds_bytes(int K, int E) {
 static bool mp_win_bwd_h2() { return !sw().gemm_math_fp32; }
 
 int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
-                   const int32_t* csc_edge, const float* e, float* rec) {
+                   const int32_t* csc_edge, const float* e, float* rec, const int32_t* row_of, int64_t n_entries) {
   if (N == 0) return NG_OK;
   ProfScope ps(ctx, st, "mp_records");
-  const int grid = (int)std::min<int64_t>(cdiv(N * K, 256), (int64_t)ctx->num_cu * 8);
+  const int grid = (int)std::min<int64_t>(cdiv(std::max<int64_t>(row_of ? n_entries : N * K, 1), 256), (int64_t)ctx->num_cu * 8);
   hipLaunchKernelGGL(mp_records_kernel, dim3(grid), dim3(256), 0, st, N, K, E, csc_ptr, csc_edge, e,
-                     reinterpret_cast<float4*>(rec));
+                     reinterpret_cast<float4*>(rec), row_of);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

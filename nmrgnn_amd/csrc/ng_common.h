@@ -28,6 +28,7 @@ enum PackKind : int {
   PK_MPW_BWD = 5,    // window backward: dst[0] = T pieces, dst[1] = N pieces, dst[2] / dst[3] = f32 T / N (blocks 96) or none (48)
   PK_MPW_F32 = 6,    // one f32 fragment image: i1 = mode, dst[0]
   PK_FC = 7,         // FC block: src[0..L-1] = W_l, i0 = L, dst[0] = Wf, dst[1] = Wb
+  PK_GG = 8,         // gather-GEMM image of an MPLayer weight (gemm_h2.hip): src[0] = w, i0 = E, i1 = F | mode << 16, dst[0] = img
 };
 struct PackJob {
   int kind = PK_NONE;
@@ -107,10 +108,14 @@ namespace ng {
 //   NG_HEAD_PATH=generic   the first head / embedding-gradient kernels
 //   NG_KNN=serial          one lane per query atom in the kNN graph kernel
 //   NG_KNN=cells / brute   the cell-grid neighbour search for every frame size / for none (default: frames >= 16384 atoms)
+//   NG_MP_GG=1             default-width MPLayer as a gather-GEMM (gemm_h2.hip: mp_gg_kernel; default: aggregate -> HBM -> GEMM)
+//   NG_MP_GG_MIN_ROWS=n    smallest call (rows) that takes the gather-GEMM (default 8192)
 struct Switches {
   bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false, knn_cells = false, knn_brute = false;
+  bool mp_gg_on = false;             // NG_MP_GG=1
+  int64_t mp_gg_min_rows = 8192;     // NG_MP_GG_MIN_ROWS
 };
 const Switches& sw();
 

@@ -58,6 +58,13 @@ size_t dense_dw_scratch_floats(ng_ctx* ctx, int64_t M, int Kin, int Nout, bool h
 bool gemm_h2_fwd_ok(int64_t M, int K, int N);
 int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag, RangeGuard guard);
+// gather-GEMM forms of the MPLayer update and of the backward's node-side pull (gemm_h2.hip): no aggregate in HBM
+bool mp_gg_supported(int64_t N, int F, int E);
+int mp_gg_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, int residual, const float* h,
+              const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
+              float* h_out, float* s_save, float* A_out = nullptr);
+int mp_gg_pull(ng_ctx* ctx, hipStream_t st, int64_t N, int F, int E, const float* dP, const int32_t* csc_ptr,
+               const float* csc_rec, const float* w, const float* dh_out, float* dh_in, const float* gscale);
 bool gemm_h2_dw_ok(int64_t M, int Kin, int Nout);
 bool gemm_h2_dw8_ok(int64_t M, int Kin, int Nout);      // 256 x 256 output tiles, one 8-wave workgroup per CU
 int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
@@ -98,7 +105,7 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const int32_t* row_of, const float* e,
                    const float* inv_degree, const float* w, const float* A_save, const float* s_save,
                    const int32_t* csc_ptr, const int32_t* csc_edge, const float* dh_out, float* dh_in, float* de,
-                   int de_accum, float* dw, const float* csc_rec = nullptr);
+                   int de_accum, float* dw, const float* csc_rec = nullptr, int64_t nnz = 0);
 int csr_aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* row_ptr,
                   const int32_t* col, const float* e, float* A);
 
@@ -182,7 +189,10 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
                     const float* WfragT32, const unsigned* wflag = nullptr, unsigned wflag_ver = 0);
 
 int mp_win_records(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, const int32_t* csc_ptr,
-                   const int32_t* csc_edge, const float* e, float* rec);
+                   const int32_t* csc_edge, const float* e, float* rec, const int32_t* row_of = nullptr, int64_t n_entries = 0);
+// neighbour aggregate over padded lists with the best kernel for the shape (node_ops.hip)
+int mp_aggregate_padded(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
+                        const float* e, float* A);
 size_t mp_win_node_scratch_floats(ng_ctx* ctx, int E);
 int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP,
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,

@@ -210,6 +210,11 @@ static int aggregate(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E
   return NG_OK;
 }
 
+int mp_aggregate_padded(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const float* h, const int32_t* nlist,
+                        const float* e, float* A) {
+  return aggregate(ctx, st, N, K, F, E, h, nlist, e, A);
+}
+
 // w[l][m][n] (reference layout, n fastest) -> Wp[k = n*F + l][m]
 __global__ void repack_w_kernel(int F, int E, const float* __restrict__ w, float* __restrict__ Wp) {
   const int total = F * F * E;
@@ -809,6 +814,10 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   }
   if (E > MAX_E)   // edge_feature_size = 64 (model.py:23): feature-chunked kernels of mp_csr.hip, fixed stride K
     return mp_generic_fwd(ctx, st, N, K, F, E, act, residual, h, nullptr, nlist, e, inv_degree, w, h_out, A_save, s_save);
+  // the reference's default width: gather-GEMM, the aggregate never reaches HBM (gemm_h2.hip: mp_gg_kernel)
+  // (a caller that keeps the aggregate for the backward's dw = A^T dP gets it as a by-product of the producer waves)
+  if (mp_gg_supported(N, F, E))
+    return mp_gg_fwd(ctx, st, N, K, F, E, act, residual, h, nullptr, nlist, e, inv_degree, w, h_out, s_save, A_save);
   const int64_t KF = (int64_t)E * F;
   // scratch: Wp [KF*F] (+ A [N*KF] when the caller does not keep it)
   const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;

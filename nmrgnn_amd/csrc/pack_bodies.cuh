@@ -190,6 +190,33 @@ __device__ __forceinline__ void fc_frag(int bid, int nb, int tid, int L, const f
   }
 }
 
+// ---- PK_GG (gemm_h2.hip: mp_gg_kernel): fp16 piece fragments of an MPLayer weight w[l][m][n] in the k-step order of the
+// gather-GEMM.  Step s = c32 * E + n covers the 32 gathered columns c = 32 c32 .. + 31 of edge feature n; output column o:
+//   mode 0 (forward update):  value(c, o) = w[l = c][m = o][n]        (A[i][(n, l)] = sum_j e_n h[nbr_j][l])
+//   mode 1 (pull, backward):  value(c, o) = w[l = o][m = c][n]        (B[i][(n, m)] = sum_in e_n dP[src][m])
+// img[s][nb][ks][p][lane][8 fp16]: lane (o = 32 nb + (l&31), k-slot t) = piece_p( 2^8 value(32 c32 + 16 ks + 8 (l>>5) + t, o) )
+__device__ __forceinline__ void gg_img(int bid, int nb_, int tid, int E, int F, int mode, const float* __restrict__ w,
+                                       unsigned* __restrict__ img) {
+  const int steps = (F / 32) * E, NB = F / 32;
+  for (int idx = bid * PKB + tid; idx < steps * NB * 2 * 64; idx += nb_ * PKB) {   // (s, nb, ks, lane)
+    const int lane = idx & 63, ks = (idx >> 6) & 1;
+    const int nb = (idx >> 7) % NB, s = (idx >> 7) / NB;
+    const int n = s % E, c32 = s / E;
+    const int o = 32 * nb + (lane & 31), c0 = 32 * c32 + 16 * ks + 8 * (lane >> 5);
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ca = c0 + 2 * j, cb = ca + 1;
+      const float va = mode == 0 ? w[((int64_t)ca * F + o) * E + n] : w[((int64_t)o * F + ca) * E + n];
+      const float vb = mode == 0 ? w[((int64_t)cb * F + o) * E + n] : w[((int64_t)o * F + cb) * E + n];
+      split2_pair(WSCALE * va, WSCALE * vb, h[j], l[j]);
+    }
+    unsigned* dst = img + (size_t)s * (NB * 2 * 2 * 256) + ((nb * 2 + ks) * 2) * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
+  }
+}
+
 }  // namespace pk
 
 // one block of one job
@@ -225,6 +252,9 @@ __device__ __forceinline__ void pack_job_block(const PackJob& j, int bid, int ti
       const float* const W[6] = {j.src[0], j.src[1], j.src[2], j.src[3], j.src[4], j.src[5]};
       pk::fc_frag(bid, j.blocks, tid, j.i0, W, (float*)j.dst[0], (float*)j.dst[1]);
     } break;
+    case PK_GG:
+      pk::gg_img(bid, j.blocks, tid, j.i0, j.i1 & 0xFFFF, j.i1 >> 16, j.src[0], (unsigned*)j.dst[0]);
+      break;
     default: break;
   }
   if (bad) {
