@@ -56,9 +56,11 @@ ARCH = dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, mp_
 GRAPHS_PER_GPU, ATOMS_PER_GRAPH, K_NEIGH, NUM_ELEM = 512, 256, 16, 10
 
 
-def kernel_work(N, K, F, E, H, Le, L, Lf, C):
-    """ALGORITHMIC work per launch of each profiled kernel: (bound, flops, bytes)  (DESIGN.md §4)."""
-    ne = N * K
+def kernel_work(N, K, F, E, H, Le, L, Lf, C, live_edges=None):
+    """ALGORITHMIC work per launch of each profiled kernel: (bound, flops, bytes)  (DESIGN.md §4).
+    ``live_edges``: slots with edges > 0 — the fused edge kernels walk only those (round 4), so their work is priced per
+    LIVE edge; every other kernel sees all N*K slots."""
+    ne = N * K if live_edges is None else int(live_edges)
     Fh = F // 2
     KF = E * F
     f4 = 4.0
@@ -72,7 +74,10 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C):
                         f4 * ne * (1 + 1 + E + (Le - 1) * H)),
         "edge_fused_bwd": ("mfma", 2.0 * ne * ((2 * (Le - 1) - 1) * H * H + 2 * H * E),
                            f4 * ne * (1 + 1 + E + (Le - 1) * H)),
-        # layered edge path
+    }
+    ne = N * K
+    w.update({
+        # layered edge path (every slot)
         "rbf": ("hbm", 0.0, f4 * ne * (2 + H)),
         "edge_dense_fwd": ("mfma", 2.0 * ne * H * H, f4 * ne * 2 * H),
         "edge_dense_dx": ("mfma", 2.0 * ne * H * H, f4 * ne * 3 * H),
@@ -104,7 +109,7 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C):
         "dense_fwd": ("mfma", 2.0 * N * F * F, f4 * N * 3 * F),
         "dense_dx": ("mfma", 2.0 * N * F * F, f4 * N * 3 * F),
         "dense_dw": ("mfma", 2.0 * N * F * F, f4 * N * 3 * F),
-    }
+    })
     # a kernel whose arithmetic intensity is below the ridge (157.3 TF / 6.3 TB/s ~ 25 flop/B) is priced
     # against HBM even when its inner loop is MFMA
     ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / 6.3e12
@@ -543,7 +548,8 @@ def main():
             torch.cuda.synchronize()
             prof = None
         if rank == 0:
-            work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM)
+            n_live = int((b["edges"] > 0).sum()) if eng.use_live_edges else None
+            work = kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM, live_edges=n_live)
             rows = roofline_rows(prof, psteps, work, h2_gemm=False)
             out["roofline_all"] = rows
             dom = next((r for r in rows if "bound" in r), None)
@@ -553,7 +559,9 @@ def main():
                 out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                                    "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic,
                                    "mfma_pipe_busy": mfma_busy, "pmc_note": note, "algorithmic_bytes": alg[2],
-                                   "algorithmic_flops": alg[1], "avg_launch_ms": dom["avg_ms"]}
+                                   "algorithmic_flops": alg[1], "avg_launch_ms": dom["avg_ms"],
+                                   "edges_priced": n_live if n_live is not None else gb.n_edges,
+                                   "edge_slots": gb.n_edges}
             out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
 
     extras = rank == 0 and world == 1 and not args.no_extras
@@ -607,7 +615,8 @@ def main():
                    "ms_per_step": float(np.median(ms)), "steps": fsteps}
             if not args.no_profile:
                 prof2 = profiled_steps(eng2, step2, 3)
-                rows2 = roofline_rows(prof2, 3, kernel_work(gb.N, K_NEIGH, 256, 3, 128, 4, 4, 4, NUM_ELEM),
+                rows2 = roofline_rows(prof2, 3, kernel_work(gb.N, K_NEIGH, 256, 3, 128, 4, 4, 4, NUM_ELEM,
+                                                            live_edges=int((b["edges"] > 0).sum()) if eng2.use_live_edges else None),
                                       h2_gemm=os.environ.get("NG_GEMM_MATH", "") != "fp32")
                 blk["roofline_all"] = rows2
                 dom2 = next((r for r in rows2 if "bound" in r), None)

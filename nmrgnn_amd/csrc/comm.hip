@@ -5,8 +5,12 @@
 //   rank 0:  ng_comm_unique_id(id)  -> the caller hands the 128 bytes to every rank (MPI, a file, a socket)
 //   all:     ng_comm_init(ctx, rank, world, id);  per step: ng_allreduce_grads(ctx, stream, grad, n);  ng_comm_destroy(ctx)
 #include <dlfcn.h>
+#include <glob.h>
+#include <link.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "ng_common.h"
 #include "ng_internal.h"
@@ -37,10 +41,46 @@ Rccl g_rccl;
 bool rccl_load() {
   if (g_rccl.tried) return g_rccl.lib != nullptr;
   g_rccl.tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // Where RCCL may live, in this order: NG_RCCL_PATH (a file, or a directory holding librccl.so[.1]); a copy some other
+  // library of the process has already mapped (torch brings its own: using a second copy beside it would be two RCCLs in one
+  // process); the loader's search path; ROCm's default prefix; the copy a torch wheel ships in torch/lib — found without
+  // importing torch, next to a mapped libc10_hip.so / libtorch_hip.so or under the usual site-packages roots (a torch-free
+  // caller on a box whose only RCCL is the wheel's).
   void* lib = nullptr;
-  for (const char* n : names)
-    if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  auto try_open = [&](const std::string& path, int extra) {
+    if (!lib && !path.empty()) lib = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL | extra);
+  };
+  if (const char* envp = getenv("NG_RCCL_PATH")) {
+    const std::string e(envp);
+    try_open(e, 0);
+    try_open(e + "/librccl.so.1", 0);
+    try_open(e + "/librccl.so", 0);
+  }
+  for (const char* n : {"librccl.so.1", "librccl.so"}) try_open(n, RTLD_NOLOAD);
+  if (!lib) {      // next to torch's HIP libraries, if they are mapped
+    struct Probe { std::string dir; } probe;
+    dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) -> int {
+      const std::string name = info->dlpi_name ? info->dlpi_name : "";
+      for (const char* key : {"/libc10_hip.so", "/libtorch_hip.so", "/libtorch.so"}) {
+        const size_t pos = name.rfind(key);
+        if (pos != std::string::npos) { static_cast<Probe*>(data)->dir = name.substr(0, pos); return 1; }
+      }
+      return 0;
+    }, &probe);
+    if (!probe.dir.empty()) try_open(probe.dir + "/librccl.so", 0);
+  }
+  for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) try_open(n, 0);
+  if (!lib) {
+    glob_t g;
+    for (const char* pat : {"/usr/local/lib/python3*/dist-packages/torch/lib/librccl.so", "/usr/lib/python3*/site-packages/torch/lib/librccl.so",
+                            "/usr/lib/python3/dist-packages/torch/lib/librccl.so", "/opt/conda/lib/python3*/site-packages/torch/lib/librccl.so"}) {
+      if (lib) break;
+      if (glob(pat, 0, nullptr, &g) == 0) {
+        for (size_t i = 0; i < g.gl_pathc && !lib; ++i) try_open(g.gl_pathv[i], 0);
+        globfree(&g);
+      }
+    }
+  }
   if (!lib) return false;
   Rccl r;
   r.get_id = (GetUniqueIdFn)dlsym(lib, "ncclGetUniqueId");

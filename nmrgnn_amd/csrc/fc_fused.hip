@@ -429,6 +429,10 @@ bool fc_fused_supported(int F, int L) {
   return F == FC_F && L >= 2 && L <= FC_MAXL;
 }
 
+// the fused BACKWARD keeps every layer's dW block in registers: four layers fit (the reference's default, model.py:33), five
+// spilled 32 B and six 192 B per lane — those depths take the layer-by-layer backward below (same tape: the layer inputs)
+bool fc_fused_bwd_supported(int F, int L) { return fc_fused_supported(F, L) && L <= 4; }
+
 size_t fc_fused_pack_floats(int L) { return (size_t)2 * L * FC_F * FC_F + 64; }
 
 // the block's packed weights (forward + backward fragments + a dummy row): the cached image of the weights when the cache is
@@ -510,8 +514,7 @@ int fc_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int L, int act, const f
       case 2: hipLaunchKernelGGL((fc_bwd_kernel<2>), dim3(grid), dim3(512), lds, st, a); break;
       case 3: hipLaunchKernelGGL((fc_bwd_kernel<3>), dim3(grid), dim3(512), lds, st, a); break;
       case 4: hipLaunchKernelGGL((fc_bwd_kernel<4>), dim3(grid), dim3(512), lds, st, a); break;
-      case 5: hipLaunchKernelGGL((fc_bwd_kernel<5>), dim3(grid), dim3(512), lds, st, a); break;
-      case 6: hipLaunchKernelGGL((fc_bwd_kernel<6>), dim3(grid), dim3(512), lds, st, a); break;
+      default: return fail(ctx, NG_ERR_UNSUPPORTED, "fc_fused_bwd: more than four layers take the layered backward");
     }
     NG_HIP(ctx, hipGetLastError());
   }
@@ -597,7 +600,7 @@ extern "C" int ng_dense_bwd(ng_ctx*, void*, int64_t, int, int, int, int, const f
                             const float*, float*, float*, float*);
 
 extern "C" int64_t ng_fc_block_scratch_floats(int64_t N, int F, int L) {
-  return ng::fc_fused_supported(F, L) ? 0 : 3 * N * (int64_t)F;
+  return ng::fc_fused_bwd_supported(F, L) ? 0 : 3 * N * (int64_t)F;
 }
 
 extern "C" int ng_fc_block_bwd(ng_ctx* ctx, void* stream, int64_t N, int F, int L, int act, const float* const* x,
@@ -607,7 +610,7 @@ extern "C" int ng_fc_block_bwd(ng_ctx* ctx, void* stream, int64_t N, int F, int 
   if (!ctx) return NG_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   NG_REQUIRE(ctx, L >= 2, "fc_block: at least two layers");
-  if (N > 0 && fc_fused_supported(F, L)) return fc_fused_bwd(ctx, st, N, L, act, x, g, W, dg, dx, dW, db);
+  if (N > 0 && fc_fused_bwd_supported(F, L)) return fc_fused_bwd(ctx, st, N, L, act, x, g, W, dg, dx, dW, db);
   // layer by layer.  Per layer ONE pass forms dP = dY * act'(s) (s = x_{l+1} - x_l rebuilt on the fly, or g for the last
   // layer) together with the bias gradient's column sums; the dX and dW GEMMs then read dP (before: a pass that wrote
   // s, then three consumers that each re-read dY and s).  scratch: [3][N][F] = dP | dX ping | dX pong

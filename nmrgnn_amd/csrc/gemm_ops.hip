@@ -306,7 +306,7 @@ extern "C" int ng_dense_bwd(ng_ctx* ctx, void* stream, int64_t M, int Kin, int N
   NG_REQUIRE(ctx, act == NG_ACT_NONE || s_save, "ng_dense_bwd: activation backward needs s_save");
   const float* S = s_save;
   hipStream_t st = (hipStream_t)stream;
-  if (dX && ng::tall_dense_ok(Nout, Kin)) {
+  if (dX && ng::tall_dense_ok(Nout, Kin) && Nout <= 128) {
     // dX[m][k] = (dY) + sum_n dP[m][n] W[k][n]: contraction over n, W(kk = n, o = k) = w[k*Nout + n]
     const int kpad = (Nout + 63) / 64 * 64, npad = (Kin + 63) / 64 * 64;
     float* Wfrag = (float*)ng::workspace(ctx, (size_t)kpad * npad * 4);

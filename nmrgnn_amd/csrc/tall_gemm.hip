@@ -187,12 +187,18 @@ __global__ __launch_bounds__(256, 2) void tall_gemm_kernel(TallArgs a) {
   }
 }
 
+// (KIN = 192 with the gradient prologue is not instantiated: its 48-float slab beside the prologue operands spilled 332 B per
+// lane; ng_dense_bwd sends that shape — a Dense with 129..192 outputs and <= 64 inputs — to the generic GEMM)
 template <int KIN, int NOUT>
 static void launch_tall(hipStream_t st, int grid, const TallArgs& a, bool pro) {
   const size_t lds = (size_t)TG_TM * (KIN + 4 + NOUT + 4) * 4;
-  if (pro)
-    hipLaunchKernelGGL((tall_gemm_kernel<KIN, NOUT, true>), dim3(grid), dim3(256), lds, st, a);
-  else
+  if constexpr (KIN < 192) {
+    if (pro) {
+      hipLaunchKernelGGL((tall_gemm_kernel<KIN, NOUT, true>), dim3(grid), dim3(256), lds, st, a);
+      return;
+    }
+  }
+  if (!pro)
     hipLaunchKernelGGL((tall_gemm_kernel<KIN, NOUT, false>), dim3(grid), dim3(256), lds, st, a);
 }
 
@@ -205,6 +211,7 @@ int tall_gemm(ng_ctx* ctx, hipStream_t st, int kpad, int npad, const TallArgs& a
               const char* tag) {
   if (a.N == 0) return NG_OK;
   NG_REQUIRE(ctx, tall_gemm_supported(kpad, npad), "tall_gemm: unsupported shape");
+  NG_REQUIRE(ctx, !(prologue && kpad == 192), "tall_gemm: the gradient prologue is not built for a 192-wide contraction");
   const int64_t ntiles = cdiv(a.N, TG_TM);
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * 2);
   ProfScope ps(ctx, st, tag);

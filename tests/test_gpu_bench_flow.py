@@ -51,6 +51,24 @@ def test_gpus_flag_without_torchrun_starts_the_ranks_itself(gpu_device):
     assert d["config"]["atoms_total"] == 24 * 256 and d["config"]["atoms_this_rank"] == 12 * 256
 
 
+def test_eight_rank_strong_scaling_form(gpu_device):
+    """what the driver launches on an 8-GPU node (BASELINE configs[3]): `--gpus 8 --scaling strong --total-graphs 4096` under
+    torch.distributed.run with EIGHT ranks — here sharing the box's one GPU over gloo, with a small total so that the run stays
+    short: shard sizes, one JSON line, exit code 0, every rank through barrier / timed steps / profile pass / destroy"""
+    env = _clean_env(NMRGNN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", "29536", BENCH,
+           "--gpus", "8", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--total-graphs", "100"]
+    d = _line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["atoms_total"] == 100 * 256
+    # parallel.shard_range(100, 0, 8): the first 100 % 8 = 4 ranks hold 13 graphs, the others 12
+    assert d["config"]["atoms_this_rank"] == 13 * 256
+    assert d["config"]["world_size"] == 8 and d["config"]["backend"] == "gloo"
+    assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert d["rank_ms_per_step"]["max"] >= d["rank_ms_per_step"]["min"] > 0
+
+
 def test_world_size_mismatch_is_an_error(gpu_device):
     env = _clean_env(NMRGNN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

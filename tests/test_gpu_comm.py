@@ -42,3 +42,33 @@ def test_allreduce_in_a_world_of_one_through_rccl(gpu_device):
         assert lib.ng_comm_init(ctx.handle, 3, 2, uid) == -1
     finally:
         ctx.close()
+
+
+def test_rccl_is_found_by_a_process_that_never_imports_torch(gpu_device):
+    """the stated purpose of ng_comm_*: a caller WITHOUT torch.  On this image RCCL exists under /opt/rocm and inside the torch
+    wheel; a fresh interpreter that loads only libnmrgnn_hip.so must get a unique id and a one-rank communicator (comm.hip:
+    rccl_load walks NG_RCCL_PATH, already-mapped copies, the loader path, /opt/rocm, the wheel's torch/lib)."""
+    import os
+    import subprocess
+    import sys
+    from nmrgnn_amd import _lib
+    code = r"""
+import ctypes as C, sys
+assert 'torch' not in sys.modules
+lib = C.CDLL(sys.argv[1])
+uid = (C.c_char * 128)()
+rc = lib.ng_comm_unique_id(uid)
+assert rc == 0, rc
+h = C.c_void_p()
+assert lib.ng_ctx_create(0, C.byref(h)) == 0
+assert lib.ng_comm_init(h, 0, 1, uid) == 0
+assert lib.ng_comm_world(h) == 1
+assert lib.ng_comm_destroy(h) == 0
+lib.ng_ctx_destroy(h)
+assert 'torch' not in sys.modules
+print('ok')
+"""
+    for extra in ({}, {"NG_RCCL_PATH": "/opt/rocm/lib"}):
+        env = dict(os.environ, **extra)
+        res = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-1500:]
