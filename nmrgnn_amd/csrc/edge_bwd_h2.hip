@@ -10,7 +10,7 @@
 //
 // Ranges.  fp16 pieces hold |x| < 65504 and resolve absolute steps of 2^-25 (subnormal l pieces are honoured by the
 // MFMA).  Activations (Z, R: O(1)) are split unscaled.  Gradients can be arbitrarily small (loss scaling, 1/G), so the
-// whole backward — linear in dE — runs on S*dE with S a power of two chosen per call by hx_scale_kernel from
+// whole backward — linear in dE — runs on S*dE with S a power of two chosen per call (kernel prologue; until round 4 a launch of its own) from
 //   max|de| * max(nWo, nWo nW3, nWo nW3 nW2),  n. = largest absolute row sum of the matrix a gradient passes through,
 // the worst case any G entry can reach: S puts that bound at 2^15, so no piece can overflow, and typical entries
 // (orders of magnitude below the bound, still >> 2^-14) keep full two-piece precision.  The partials are multiplied
@@ -85,7 +85,8 @@ struct EdgeBwdH2Args {
   const float* centers;
   float neg_inv_gap_log2e;
   const char* wt_img;   // [2 layers (W2, W3)][4 k-slabs][8 k-steps][2 pieces][1 KB], pieces of 2^8 W
-  const float* scale;   // {S, 1/S} written by hx_scale_kernel
+  const float* blockmax;   // per-block max |de| (hx_absmax_kernel); with the row-sum bounds behind wt_img the kernel forms {S, 1/S}
+  int n_blockmax;
   const float* Wo;      // [128][E]
   const float* z_save;  // [3][z_layer_stride / 128 edges][128], first edge of THIS launch's segment
   int64_t z_layer_stride;  // floats between the layers of the tape (= total edges * 128; a launch covers one segment)
@@ -296,7 +297,36 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   const int col0 = 32 * zk + 4 * half;                  // its columns: col0 + 8q + j
   const int prz = hx_prow_z(row), prg = hx_prow_g(row); // where that row lives in the images
   const int E = a.E;
-  const float gscale = a.scale[0], ginv = a.scale[1];   // gradients run scaled by a power of two (header)
+  // gradients run scaled by a power of two S (header: Ranges), formed here by every workgroup from the block maxima of |de| and the
+  // row-sum bounds the W^T pack left behind the fragments: max is exact and order-free, so S — and every bit of the result —
+  // is the same in every workgroup and for every launch geometry (round 4: this was a one-block launch of its own)
+  float gscale, ginv;
+  {
+    float* sred = reinterpret_cast<float*>(smem_hx);
+    float m = 0.f;
+    for (int i = tid; i < a.n_blockmax; i += HX_THREADS) m = fmaxf(m, a.blockmax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) sred[wave] = m;
+    __syncthreads();
+    m = sred[0];
+#pragma unroll
+    for (int w8 = 1; w8 < HX_THREADS / 64; ++w8) m = fmaxf(m, sred[w8]);
+    const float* wb = reinterpret_cast<const float*>(a.wt_img + 2 * 4 * 8 * 2 * 1024);      // {nW2, nW3, nWo}
+    const float b3 = m * wb[2], b2 = b3 * wb[1], b1 = b2 * wb[0];
+    const float bound = fmaxf(b3, fmaxf(b2, b1));
+    int ex = 0;
+    // a NaN / inf gradient keeps S = 1 and propagates; an all-zero one too
+    if (bound > 0.f && bound < 3.0e38f) {
+      int eb;
+      (void)frexpf(bound, &eb);              // bound = f * 2^eb, f in [0.5, 1)  ->  bound <= 2^eb
+      ex = 15 - eb;
+      ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+    }
+    gscale = ldexpf(1.0f, ex);
+    ginv = ldexpf(1.0f, -ex);
+    __syncthreads();
+  }
   // rows of this launch (LIVE: the segment's share of the compacted live rows, a device scalar)
   const int64_t n_edges = LIVE ? std::max<int64_t>(0, std::min<int64_t>(a.n_edges, (int64_t)*a.n_live - a.row_base)) : a.n_edges;
   // tape offsets of this wave's block for the tile starting at ROW0 (see hx_load_z)
@@ -643,39 +673,6 @@ __global__ __launch_bounds__(256) void hx_absmax_kernel(const float* __restrict_
   if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-__global__ __launch_bounds__(128) void hx_scale_kernel(const float* __restrict__ blockmax, int nblocks, const float* __restrict__ W2,
-                                                       const float* __restrict__ W3, const float* __restrict__ Wo, int E,
-                                                       float* __restrict__ scale) {
-  __shared__ float red[4][128];
-  const int k = threadIdx.x;      // row k of W2 / W3 / Wo
-  float m = 0.f, r2 = 0.f, r3 = 0.f, ro = 0.f;
-  for (int i = k; i < nblocks; i += 128) m = fmaxf(m, blockmax[i]);
-  for (int n = 0; n < FH; ++n) { r2 += fabsf(W2[k * FH + n]); r3 += fabsf(W3[k * FH + n]); }
-  for (int n = 0; n < E; ++n) ro += fabsf(Wo[k * E + n]);
-  red[0][k] = m; red[1][k] = r2; red[2][k] = r3; red[3][k] = ro;
-  __syncthreads();
-  for (int s = 64; s > 0; s >>= 1) {
-    if (k < s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) red[j][k] = fmaxf(red[j][k], red[j][k + s]);
-    __syncthreads();
-  }
-  if (k == 0) {
-    const float b3 = red[0][0] * red[3][0], b2 = b3 * red[2][0], b1 = b2 * red[1][0];
-    const float bound = fmaxf(b3, fmaxf(b2, b1));
-    int ex = 0;
-    // a NaN / inf gradient keeps S = 1 and propagates; an all-zero one too
-    if (bound > 0.f && bound < 3.0e38f) {
-      int eb;
-      (void)frexpf(bound, &eb);              // bound = f * 2^eb, f in [0.5, 1)  ->  bound <= 2^eb
-      ex = 15 - eb;
-      ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
-    }
-    scale[0] = ldexpf(1.0f, ex);
-    scale[1] = ldexpf(1.0f, -ex);
-  }
-}
-
 // Buffer offsets inside the kernel are 32-bit (one resource per array, 512 B of tape per edge), so one LAUNCH covers
 // at most HX_SEG_EDGES edges; longer edge lists run as several launches over consecutive segments (a multiple of the
 // 64-edge tile and of the 32-edge tape group), each with its own rows of the partial buffer.
@@ -687,33 +684,32 @@ bool edge_bwd_h2_supported(int E, int64_t n_edges) { (void)n_edges; return E >= 
 bool edge_tape_blocked(int E, int64_t n_edges) {
   return edge_split_enabled() && !sw().edge_bwd_math_fp32 && edge_bwd_h2_supported(E, n_edges);
 }
-constexpr size_t HX_WT_BYTES = (size_t)2 * 4 * 8 * 2 * 1024;
+constexpr size_t HX_WT_BYTES = (size_t)2 * 4 * 8 * 2 * 1024;       // the fragments; {nW2, nW3, nWo} follow
 
-size_t edge_bwd_h2_ws_bytes() { return HX_WT_BYTES + (size_t)(HX_SCALE_BLOCKS + 2) * 4; }
+size_t edge_bwd_h2_ws_bytes() { return HX_WT_BYTES + 16 + (size_t)(HX_SCALE_BLOCKS + 2) * 4; }
 
 // wt_img: edge_bwd_h2_ws_bytes() of scratch; partial: [edge_bwd_h2_segments(n_edges) * grid][part_stride]
 int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float* d_src, const float* d_eff,
                        const float* centers, float gap, const float* const* W, const float* z_save, const float* de,
                        char* wt_img, float* partial, int part_stride, int grid, int tape_blocked, RangeGuard guard,
                        LiveEdges live) {
-  float* blockmax = reinterpret_cast<float*>(wt_img + HX_WT_BYTES);
-  float* scale = blockmax + HX_SCALE_BLOCKS;
+  float* blockmax = reinterpret_cast<float*>(wt_img + HX_WT_BYTES + 16);
   // the W^T image: cached while the weights are frozen / refreshed behind Adam, else in the caller's scratch
+  int nb_max = 0;
   bool have_wt = false;
-  char* wimg = (char*)cached_image(ctx, W[1], 13, HX_WT_BYTES, &have_wt);
+  char* wimg = (char*)cached_image(ctx, W[1], 13, HX_WT_BYTES + 16, &have_wt);
   const bool cached_wt = wimg != nullptr;
   if (!wimg) wimg = wt_img;
   {
     ProfScope ps(ctx, st, "edge_bwd_h2_prep");
     if (!have_wt) {
       PackJob j;
-      j.kind = PK_EDGE_WT; j.blocks = 16; j.src[0] = W[1]; j.src[1] = W[2]; j.dst[0] = wimg;
+      j.kind = PK_EDGE_WT; j.blocks = 17; j.src[0] = W[1]; j.src[1] = W[2]; j.src[2] = W[3]; j.i0 = E; j.dst[0] = wimg;
       if (int rc = pack_launch(ctx, st, j)) return rc;
       if (cached_wt) cache_set_job(ctx, W[1], 13, j);
     }
-    const int nb = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
-    hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb), dim3(256), 0, st, de, n_edges * E, blockmax);
-    hipLaunchKernelGGL(hx_scale_kernel, dim3(1), dim3(128), 0, st, blockmax, nb, W[1], W[2], W[3], E, scale);
+    nb_max = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
+    hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb_max), dim3(256), 0, st, de, n_edges * E, blockmax);
     NG_HIP(ctx, hipGetLastError());
   }
   const int nseg = edge_bwd_h2_segments(n_edges);
@@ -722,7 +718,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     EdgeBwdH2Args a;
     a.n_edges = std::min<int64_t>(HX_SEG_EDGES, n_edges - e0); a.d_src = d_src + e0; a.d_eff = d_eff + e0; a.centers = centers;
     a.neg_inv_gap_log2e = (float)(-1.4426950408889634 / (double)gap);
-    a.wt_img = wimg; a.scale = scale; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH;
+    a.wt_img = wimg; a.blockmax = blockmax; a.n_blockmax = nb_max; a.Wo = W[3]; a.z_save = z_save + e0 * FH; a.z_layer_stride = n_edges * FH;
     a.de = live.perm ? de : de + e0 * E;
     a.perm = live.perm ? live.perm + e0 : nullptr; a.n_live = live.n_live; a.row_base = e0;
     a.partial = partial + (size_t)sg * grid * part_stride; a.part_stride = part_stride; a.E = E; a.tape_blocked = tape_blocked;

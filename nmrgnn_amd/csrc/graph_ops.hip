@@ -252,6 +252,87 @@ __global__ __launch_bounds__(GL_BLOCK) void gl_live_fill_kernel(int64_t n, const
   }
 }
 
+// ---- one graph per call (the reference's own granularity, nmrgnn/library.py:88-89): both builders in ONE launch each.  A 256-atom
+// graph has 4096 slots; the multi-launch forms above spend their time on launch boundaries (nine launches, ~40 us of a 0.37-ms
+// training step: profiles/r04n_one_graph_trace.txt).
+constexpr int GL_SMALL_THREADS = 1024, GL_SMALL_SLOTS = 16384, GL_SMALL_TARGETS = 2048;
+
+// live partition of <= GL_SMALL_SLOTS slots: thread t owns slots [t * per, t * per + per)
+__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_live_small_kernel(int n, const float* __restrict__ edges, int32_t* __restrict__ perm,
+                                                                         int32_t* __restrict__ pos, float* __restrict__ d_c,
+                                                                         int32_t* __restrict__ total) {
+  __shared__ int32_t s[GL_SMALL_THREADS];
+  const int per = (n + GL_SMALL_THREADS - 1) / GL_SMALL_THREADS;      // <= 16
+  const int b0 = threadIdx.x * per, b1 = min(n, b0 + per);
+  int32_t c = 0;
+  for (int g = b0; g < b1; ++g) c += edges[g] > 0.f ? 1 : 0;
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < GL_SMALL_THREADS; off <<= 1) {
+    const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const int32_t n_live = s[GL_SMALL_THREADS - 1];
+  int32_t rank = s[threadIdx.x] - c;
+  for (int g = b0; g < b1; ++g) {
+    const float d = edges[g];
+    if (d > 0.f) { perm[rank] = g; pos[g] = rank; d_c[rank] = d; ++rank; }
+    else { perm[n_live + (g - rank)] = g; pos[g] = -1; }
+  }
+  if (threadIdx.x == 0) *total = n_live;
+}
+
+// incoming lists of <= GL_SMALL_TARGETS targets and <= GL_SMALL_SLOTS entries: histogram (LDS integer atomics: order-free), scan,
+// unordered fill through LDS cursors, per-target rank sort back into ascending entry id — the stable order of the big form
+__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_lists_small_kernel(int n_entries, int N, int K, const int32_t* __restrict__ nlist,
+                                                                          const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
+                                                                          int32_t* __restrict__ csc_ptr, int32_t* __restrict__ csc_edge) {
+  __shared__ int32_t s_cnt[GL_SMALL_TARGETS], s_cur[GL_SMALL_TARGETS], s_scan[GL_SMALL_THREADS];
+  extern __shared__ int32_t s_tmp[];          // [n_entries]
+  for (int t = threadIdx.x; t < N; t += GL_SMALL_THREADS) s_cnt[t] = 0;
+  __syncthreads();
+  for (int eid = threadIdx.x; eid < n_entries; eid += GL_SMALL_THREADS) {
+    const int32_t t = nlist[eid];
+    const bool live = (edges == nullptr || edges[eid] > 0.f) && t >= 0 && t < N;
+    if (nlist_c) nlist_c[eid] = live ? t : eid / K;
+    if (live) atomicAdd(&s_cnt[t], 1);
+  }
+  __syncthreads();
+  // exclusive scan over the N counts: thread t owns targets [2t, 2t + 2)
+  const int t0 = 2 * threadIdx.x;
+  const int32_t c0 = t0 < N ? s_cnt[t0] : 0, c1 = t0 + 1 < N ? s_cnt[t0 + 1] : 0;
+  s_scan[threadIdx.x] = c0 + c1;
+  __syncthreads();
+  for (int off = 1; off < GL_SMALL_THREADS; off <<= 1) {
+    const int32_t add = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const int32_t p0 = s_scan[threadIdx.x] - c0 - c1;
+  if (t0 < N) { csc_ptr[t0] = p0; s_cur[t0] = p0; }
+  if (t0 + 1 < N) { csc_ptr[t0 + 1] = p0 + c0; s_cur[t0 + 1] = p0 + c0; }
+  if (threadIdx.x == 0) csc_ptr[N] = s_scan[GL_SMALL_THREADS - 1];
+  __syncthreads();
+  for (int eid = threadIdx.x; eid < n_entries; eid += GL_SMALL_THREADS) {
+    const int32_t t = nlist[eid];
+    if ((edges != nullptr && !(edges[eid] > 0.f)) || t < 0 || t >= N) continue;
+    s_tmp[atomicAdd(&s_cur[t], 1)] = eid;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < N; t += GL_SMALL_THREADS) {
+    const int q1 = s_cur[t], q0 = q1 - s_cnt[t];
+    for (int a = q0; a < q1; ++a) {
+      const int32_t v = s_tmp[a];
+      int rank = 0;
+      for (int b = q0; b < q1; ++b) rank += s_tmp[b] < v ? 1 : 0;
+      csc_edge[q0 + rank] = v;
+    }
+  }
+}
+
 }  // namespace ng
 
 using namespace ng;
@@ -264,6 +345,12 @@ extern "C" int ng_build_live_edges(ng_ctx* ctx, void* stream, int64_t n_slots, c
   hipStream_t st = (hipStream_t)stream;
   DeviceGuard dg(ctx->device);
   if (n_slots == 0) { NG_HIP(ctx, hipMemsetAsync(n_live, 0, sizeof(int32_t), st)); return NG_OK; }
+  if (n_slots <= GL_SMALL_SLOTS) {      // one graph: one launch
+    ProfScope ps(ctx, st, "live_edges");
+    hipLaunchKernelGGL(gl_live_small_kernel, dim3(1), dim3(GL_SMALL_THREADS), 0, st, (int)n_slots, edges, perm, pos, d_c, n_live);
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
   const int nb = (int)cdiv(n_slots, GL_SCAN_TILE);
   int32_t* bcnt = (int32_t*)aux_workspace(ctx, (size_t)(nb + 16) * sizeof(int32_t));
   if (!bcnt) return NG_ERR_HIP;
@@ -314,6 +401,13 @@ extern "C" int ng_build_incoming_lists(ng_ctx* ctx, void* stream, int64_t N, int
   hipStream_t st = (hipStream_t)stream;
   DeviceGuard dg(ctx->device);
   if (N == 0) { NG_HIP(ctx, hipMemsetAsync(csc_ptr, 0, sizeof(int32_t), st)); return NG_OK; }
+  if (N <= GL_SMALL_TARGETS && n_entries <= GL_SMALL_SLOTS && n_entries > 0 && K > 0) {      // one graph: one launch, no scratch
+    ProfScope ps(ctx, st, "incoming_lists");
+    hipLaunchKernelGGL(gl_lists_small_kernel, dim3(1), dim3(GL_SMALL_THREADS), (size_t)n_entries * sizeof(int32_t), st, (int)n_entries,
+                       (int)N, K, nlist, edges, nlist_c, csc_ptr, csc_edge);
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
   const int nb = (int)cdiv(N, GL_SCAN_TILE);
   int32_t* ws = (int32_t*)aux_workspace(ctx, ng_incoming_lists_scratch_bytes(N, n_entries));
   if (!ws) return NG_ERR_HIP;

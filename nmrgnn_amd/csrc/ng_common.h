@@ -22,7 +22,8 @@ struct RangeGuard {
 enum PackKind : int {
   PK_NONE = 0,
   PK_EDGE_H2 = 1,    // edge forward fp16-piece image: src W0..W3, i0 = E, dst[0] = img [7][32 KB]
-  PK_EDGE_WT = 2,    // edge backward W^T piece fragments: src[0] = W2, src[1] = W3, dst[0] = img [64 KB]
+  PK_EDGE_WT = 2,    // edge backward W^T piece fragments: src[0] = W2, src[1] = W3, dst[0] = img [64 KB + 16 B]; src[2] = Wo, i0 = E: + the
+                     // row-sum bounds {nW2, nW3, nWo} behind the fragments (blocks = 17)
   PK_EDGE_F32 = 3,   // f32 fragments of the three hidden edge layers: src W0..W2, dst[0] = Wpk, dst[1] = WpkT (either may be null)
   PK_MPW_FWD = 4,    // window forward: src[0] = w, i0 = E, dst[0] = piece image, dst[1] = f32 image (blocks 48) or none (24)
   PK_MPW_BWD = 5,    // window backward: dst[0] = T pieces, dst[1] = N pieces, dst[2] / dst[3] = f32 T / N (blocks 96) or none (48)

@@ -59,8 +59,30 @@ __device__ __forceinline__ void edge_h2_img(int bid, int nb, int tid, const floa
 
 // ---- PK_EDGE_WT (edge_bwd_h2.hip): W^T fragments of the dZ GEMMs: [2 layers (W2, W3)][4 k-slabs][8 k-steps][2 pieces][1 KB]
 //   lane (row k = 32 zk + (l&31), k-slot t) = piece_p( 2^8 W[k][n = 16 ks + 8 (l>>5) + t] )
+// Behind the fragments (byte 64 K of the image): {nW2, nW3, nWo} = the largest absolute row sums of W2, W3, Wo — the growth bounds
+// of the backward's power-of-two gradient scale (edge_bwd_h2.hip: Ranges), formed here because the weights are at hand;
+// the kernel combines them with max|de| itself (round 4: one launch less per step than a separate scale kernel).
 __device__ __forceinline__ void edge_wt_img(int bid, int nb, int tid, const float* __restrict__ W2, const float* __restrict__ W3,
-                                            unsigned* __restrict__ img) {
+                                            const float* __restrict__ Wo, int E, unsigned* __restrict__ img) {
+  if (bid == nb - 1 && Wo) {      // the last block (it has no fragment work when nb = 17)
+    __shared__ float red[3][PKB];
+    float r2 = 0.f, r3 = 0.f, ro = 0.f;
+    if (tid < FHd) {
+      for (int n = 0; n < FHd; ++n) { r2 += fabsf(W2[tid * FHd + n]); r3 += fabsf(W3[tid * FHd + n]); }
+      for (int n = 0; n < E; ++n) ro += fabsf(Wo[tid * E + n]);
+    }
+    red[0][tid] = r2; red[1][tid] = r3; red[2][tid] = ro;
+    __syncthreads();
+    for (int s = PKB / 2; s > 0; s >>= 1) {
+      if (tid < s)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[j][tid] = fmaxf(red[j][tid], red[j][tid + s]);
+      __syncthreads();
+    }
+    if (tid < 3) reinterpret_cast<float*>(img)[(2 * 4 * 8 * 2 * 1024) / 4 + tid] = red[tid][0];
+    return;
+  }
+  if (Wo) nb -= 1;
   for (int idx = bid * PKB + tid; idx < 2 * 4 * 8 * 64; idx += nb * PKB) {   // (L, zk, ks, lane)
     const int lane = idx & 63, ks = (idx >> 6) & 7, zk = (idx >> 9) & 3, L = idx >> 11;
     const float* W = L == 0 ? W2 : W3;
@@ -227,7 +249,7 @@ __device__ __forceinline__ void pack_job_block(const PackJob& j, int bid, int ti
       pk::edge_h2_img(bid, j.blocks, tid, j.src[0], j.src[1], j.src[2], j.src[3], j.i0, (unsigned*)j.dst[0]);
       break;
     case PK_EDGE_WT:
-      pk::edge_wt_img(bid, j.blocks, tid, j.src[0], j.src[1], (unsigned*)j.dst[0]);
+      pk::edge_wt_img(bid, j.blocks, tid, j.src[0], j.src[1], j.src[2], j.i0, (unsigned*)j.dst[0]);
       break;
     case PK_EDGE_F32:
       pk::edge_f32_frag(bid, j.blocks, tid, j.src[0], j.src[1], j.src[2], (float*)j.dst[0], (float*)j.dst[1]);

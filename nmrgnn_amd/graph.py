@@ -34,6 +34,25 @@ def _norm_device(device):
     return device
 
 
+_GRAPH_PTR_CACHE = {}
+
+
+def _graph_ptr_dev(host, device):
+    """device copy of a graph_ptr array.  Small partitions repeat from batch to batch (one graph per call: [0, n]; fixed-size
+    graphs) and a pageable host-to-device copy blocks the host until the stream has drained — per call that stall was a tenth of
+    a one-graph training step — so the copies are kept (at most 64 of at most 4096 entries)."""
+    if host.size > 4096 or device.type != "cuda":
+        return torch.as_tensor(host, device=device)
+    key = (device.index, host.tobytes())
+    t = _GRAPH_PTR_CACHE.get(key)
+    if t is None:
+        if len(_GRAPH_PTR_CACHE) >= 64:
+            _GRAPH_PTR_CACHE.clear()
+        t = torch.as_tensor(host, device=device)
+        _GRAPH_PTR_CACHE[key] = t
+    return t
+
+
 def _to_dev(x, dtype, device):
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=dtype).contiguous()
@@ -67,7 +86,7 @@ class GraphBatch:
         if graph_ptr is None:
             graph_ptr = [0, self.N]
         self.graph_ptr_host = np.asarray(graph_ptr, dtype=np.int32)
-        self.graph_ptr = torch.as_tensor(self.graph_ptr_host, device=self.device)
+        self.graph_ptr = _graph_ptr_dev(self.graph_ptr_host, self.device)
         self.G = len(self.graph_ptr_host) - 1
         self._csc = None
         self._live = None
@@ -104,7 +123,7 @@ class GraphBatch:
         if graph_ptr is None:
             graph_ptr = [0, self.N]
         self.graph_ptr_host = np.asarray(graph_ptr, dtype=np.int32)
-        self.graph_ptr = torch.as_tensor(self.graph_ptr_host, device=self.device)
+        self.graph_ptr = _graph_ptr_dev(self.graph_ptr_host, self.device)
         self.G = len(self.graph_ptr_host) - 1
         if validate:
             rp = self.row_ptr.to(torch.int64)
