@@ -23,4 +23,8 @@ python tools/edge_ab.py > gpurun_out/${TAG}_edge_ab.txt 2>&1
 python tools/frame_loop.py > gpurun_out/${TAG}_frame_loop.txt 2>&1
 bash tools/frame_trace.sh > gpurun_out/${TAG}_frame_trace.txt 2>&1
 tools/ubench/mfma_fill > gpurun_out/${TAG}_mfma_fill.txt 2>&1 || true
+# round 4: ordered traces of the batched step and of the one-graph step, savedmodel errors (every printed row)
+bash tools/step_trace.sh > /dev/null 2>&1; cp gpurun_out/step_trace.txt gpurun_out/${TAG}_step_trace.txt
+bash tools/one_graph_trace.sh > gpurun_out/${TAG}_one_graph_trace.txt 2>&1
+python -m pytest tests/test_gpu_savedmodel.py -m gpu -q -s 2>&1 | grep -o '\[[a-z0-9]*/[a-z]*\].*' > gpurun_out/${TAG}_savedmodel_errors.txt
 tail -3 gpurun_out/${TAG}_bench.err; head -c 400 gpurun_out/${TAG}_bench.json; echo; tail -4 gpurun_out/${TAG}_eval_bench.txt
