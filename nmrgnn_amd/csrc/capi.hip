@@ -29,6 +29,7 @@ static void load_switches() {
   s.dense_generic = env_is("NG_DENSE_PATH", "generic");
   s.head_generic = env_is("NG_HEAD_PATH", "generic");
   s.knn_serial = env_is("NG_KNN", "serial");
+  s.knn_lanes = env_is("NG_KNN", "lanes");
   s.knn_cells = env_is("NG_KNN", "cells");
   s.knn_brute = env_is("NG_KNN", "brute");
   s.mp_gg_on = env_is("NG_MP_GG", "1");

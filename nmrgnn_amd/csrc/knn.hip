@@ -173,6 +173,96 @@ __global__ __launch_bounds__(256) void knn_kernel_s8(int n, int K, float scale, 
   inv_degree[row] = deg > 0 ? 1.0f / (float)deg : 0.f;
 }
 
+// ---- one WAVE per query atom, for molecule-sized calls (round 4).  A single 2770-atom frame gives the lane kernels above 693
+// waves that each walk 173 candidates with a 64-instruction branch-free insertion paid at almost every step (some lane of the
+// wave always qualifies): 48 us, a quarter of a one-frame call, all of it the serial chain of one wave.  Here the 64 lanes of a
+// wave take 64 candidates per step for ONE query and nothing is inserted before the bar is low:
+//   A  every lane computes the keys of its candidates (key = bits(d^2) << 32 | index: the (distance, index) order of the other
+//      kernels, so the lists come out the same bit for bit) into registers and keeps its smallest;
+//   B  the K-th smallest of the 64 lane minima is an upper bound of the K-th smallest key overall (K distinct candidates lie at or
+//      below it) — found by ranking the 64 minima against each other;
+//   C  only keys at or below that bound are inserted (a few more than K) into a sorted list held ACROSS the lanes (lane k = k-th
+//      smallest): one wave-wide shift and two compares per insertion, whatever K is.
+// The frame's positions are staged in LDS once per workgroup (n <= 4096); the four waves of a workgroup take four queries.
+typedef unsigned long long knn_u64;
+__device__ __forceinline__ knn_u64 knn_readlane64(knn_u64 v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((knn_u64)hi << 32) | lo;
+}
+// lane l gets lane l - 1's value, lane 0 gets 0 (DPP wave_shr:1)
+__device__ __forceinline__ knn_u64 knn_shr1(knn_u64 v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((knn_u64)hi << 32) | lo;
+}
+constexpr int KNN_WAVE_MAXN = 4096;
+
+template <int STEPS>
+__global__ __launch_bounds__(256) void knn_wave_kernel(int n, int K, float scale, const float* __restrict__ pos,
+                                                       int32_t* __restrict__ nlist, float* __restrict__ edges,
+                                                       float* __restrict__ inv_degree) {
+  extern __shared__ float spos[];                 // [3][64 * STEPS]
+  constexpr int NP = 64 * STEPS;
+  float* sx = spos; float* sy = spos + NP; float* sz = spos + 2 * NP;
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* fp = pos + (int64_t)frame * n * 3;
+  for (int t = threadIdx.x; t < n; t += 256) { sx[t] = fp[3 * t]; sy[t] = fp[3 * t + 1]; sz[t] = fp[3 * t + 2]; }
+  __syncthreads();
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n) return;                             // uniform over the wave
+  const float qx = sx[i], qy = sy[i], qz = sz[i];
+  // A: keys of this lane's candidates t = 64 s + lane, and their minimum
+  knn_u64 key[STEPS];
+  knn_u64 mn = ~0ull;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int t = 64 * s + lane;
+    const int tc = min(t, n - 1);
+    const float d2 = knn_dist2(sx[tc] - qx, sy[tc] - qy, sz[tc] - qz);
+    knn_u64 k = ((knn_u64)__builtin_bit_cast(unsigned, d2) << 32) | (unsigned)t;
+    if (t >= n || t == i) k = ~0ull;
+    key[s] = k;
+    mn = k < mn ? k : mn;
+  }
+  // B: the K-th smallest lane minimum (keys of real candidates are distinct; absent ones are ~0 and rank last)
+  knn_u64 tau = ~0ull;
+  {
+    int rank = 0;
+    for (int b = 0; b < 64; ++b) rank += knn_readlane64(mn, b) < mn ? 1 : 0;
+    const unsigned long long hit = __ballot(rank == K - 1 && mn != ~0ull);
+    if (hit) tau = knn_readlane64(mn, __builtin_ctzll(hit));
+  }
+  // C: insert what lies at or below the bound
+  knn_u64 list = ~0ull, kth = ~0ull;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    unsigned long long m = __ballot(key[s] <= tau && key[s] != ~0ull);
+    while (m) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1;
+      const knn_u64 c = knn_readlane64(key[s], b);
+      if (c < kth) {
+        const knn_u64 prev = knn_shr1(list);
+        list = c < prev ? prev : (c < list ? c : list);
+        kth = knn_readlane64(list, K - 1);
+      }
+    }
+  }
+  const int64_t row = (int64_t)frame * n + i;
+  const bool ok = lane < K && list != ~0ull;
+  const int idx = (int)(unsigned)list;
+  const float d2 = __builtin_bit_cast(float, (unsigned)(list >> 32));
+  if (lane < K) {
+    nlist[row * K + lane] = ok ? frame * n + idx : 0;
+    edges[row * K + lane] = ok ? sqrtf(d2) * scale : 0.f;
+  }
+  const int deg = __popcll(__ballot(ok && idx > 0));
+  if (lane == 0) inv_degree[row] = deg > 0 ? 1.0f / (float)deg : 0.f;
+}
+
 }  // namespace ng
 
 extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, float scale,
@@ -190,7 +280,14 @@ extern "C" int ng_knn_graph(ng_ctx* ctx, void* stream, int G, int n, int K, floa
     return knn_cells(ctx, st, G, n, K, scale, pos, nlist, edges, inv_degree);
   ProfScope ps(ctx, st, "knn_graph");
   const dim3 grid((unsigned)cdiv(n, 256), (unsigned)G), block(256);
-  if (K <= 16 && !sw().knn_serial)      // NG_KNN=serial: one lane per query (the first kernel)
+  // molecule-sized calls: one wave per query (NG_KNN=serial / lanes: the earlier kernels for every size)
+  if (!sw().knn_serial && !sw().knn_lanes && n <= KNN_WAVE_MAXN && (int64_t)G * n <= 16384) {
+    const dim3 gw((unsigned)cdiv(n, 4), (unsigned)G);
+    if (n <= 1024) hipLaunchKernelGGL((knn_wave_kernel<16>), gw, block, 3 * 64 * 16 * 4, st, n, K, scale, pos, nlist, edges, inv_degree);
+    else if (n <= 2048) hipLaunchKernelGGL((knn_wave_kernel<32>), gw, block, 3 * 64 * 32 * 4, st, n, K, scale, pos, nlist, edges, inv_degree);
+    else if (n <= 3072) hipLaunchKernelGGL((knn_wave_kernel<48>), gw, block, 3 * 64 * 48 * 4, st, n, K, scale, pos, nlist, edges, inv_degree);
+    else hipLaunchKernelGGL((knn_wave_kernel<64>), gw, block, 3 * 64 * 64 * 4, st, n, K, scale, pos, nlist, edges, inv_degree);
+  } else if (K <= 16 && !sw().knn_serial)      // 8 / 16 lanes per query
   {
     const int64_t nq = (int64_t)G * n;          // few queries: more lanes per query, so that the launch still fills the chip
     if (nq <= 16384)

@@ -107,7 +107,7 @@ namespace ng {
 //   NG_FC_PATH=layered     one launch per FC layer
 //   NG_DENSE_PATH=generic  no register-resident tall-skinny kernels
 //   NG_HEAD_PATH=generic   the first head / embedding-gradient kernels
-//   NG_KNN=serial          one lane per query atom in the kNN graph kernel
+//   NG_KNN=serial / lanes  one lane / 8-16 lanes per query atom in the kNN graph kernel (default: one wave per query)
 //   NG_KNN=cells / brute   the cell-grid neighbour search for every frame size / for none (default: frames >= 16384 atoms)
 //   NG_MP_GG=1             default-width MPLayer as a gather-GEMM (gemm_h2.hip: mp_gg_kernel; default: aggregate -> HBM -> GEMM)
 //   NG_MP_GG_MIN_ROWS=n    smallest call (rows) that takes the gather-GEMM (default 8192)
@@ -116,6 +116,7 @@ struct Switches {
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false, knn_cells = false, knn_brute = false;
   bool mp_gg_on = false;             // NG_MP_GG=1
+  bool knn_lanes = false;            // NG_KNN=lanes
   int64_t mp_gg_min_rows = 8192;     // NG_MP_GG_MIN_ROWS
 };
 const Switches& sw();

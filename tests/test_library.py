@@ -202,20 +202,46 @@ def test_gpu_knn_tiny_and_ragged(gpu_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 7, 33, 1500])
-def test_gpu_knn_eight_lane_kernel_equals_serial_kernel(gpu_device, monkeypatch, n):
-    """the 8-lanes-per-query kernel and the one-lane kernel give identical lists, exact distance ties included
-    (integer grid coordinates): (distance, index) ascending in both"""
+@pytest.mark.parametrize("n,K", [(1, 16), (7, 16), (33, 16), (1500, 16), (3000, 16), (70, 40), (2100, 40), (65, 64)])
+def test_gpu_knn_kernels_give_identical_lists(gpu_device, monkeypatch, n, K):
+    """the one-wave-per-query kernel (default up to 16384 queries of frames up to 4096 atoms), the 8 / 16-lanes-per-query kernels
+    (NG_KNN=lanes) and the one-lane kernel (NG_KNN=serial) give identical lists, exact distance ties included (integer grid coordinates): (distance, index)
+    ascending in all of them; three frames, so that the frame offsets take part"""
     from nmrgnn_amd.graph import frames_to_batch
-    rng = np.random.default_rng(n)
-    pos = rng.integers(0, 6, size=(2, n, 3)).astype(np.float32)
+    rng = np.random.default_rng(n + K)
+    pos = rng.integers(0, 6 if n < 2000 else 14, size=(3, n, 3)).astype(np.float32)
     atoms = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]
     out = {}
-    for mode in ("serial", "lanes8"):
-        monkeypatch.setenv("NG_KNN", mode)
+    for mode in ("serial", "lanes", "wave"):
+        if mode == "wave":
+            monkeypatch.delenv("NG_KNN", raising=False)
+        else:
+            monkeypatch.setenv("NG_KNN", mode)
+        gb = frames_to_batch(atoms, pos, K, device=gpu_device)
+        out[mode] = (gb.nlist.cpu().numpy(), gb.edges.cpu().numpy(), gb.inv_degree.cpu().numpy())
+    for mode in ("lanes", "wave"):
+        for a, b in zip(out["serial"], out[mode]):
+            assert np.array_equal(a, b), mode
+
+
+@pytest.mark.gpu
+def test_gpu_knn_many_queries_default_path(gpu_device, monkeypatch):
+    """more than 16384 queries in a call: the default goes back to the lanes-per-query kernels (the wave-per-query kernel is for
+    molecule-sized calls); still the serial kernel's lists"""
+    from nmrgnn_amd.graph import frames_to_batch
+    rng = np.random.default_rng(5)
+    n, G = 1100, 64
+    pos = (rng.random((G, n, 3)) * 30).astype(np.float32)
+    atoms = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]
+    out = {}
+    for mode in ("serial", "wave"):
+        if mode == "wave":
+            monkeypatch.delenv("NG_KNN", raising=False)
+        else:
+            monkeypatch.setenv("NG_KNN", mode)
         gb = frames_to_batch(atoms, pos, 16, device=gpu_device)
         out[mode] = (gb.nlist.cpu().numpy(), gb.edges.cpu().numpy(), gb.inv_degree.cpu().numpy())
-    for a, b in zip(out["serial"], out["lanes8"]):
+    for a, b in zip(out["serial"], out["wave"]):
         assert np.array_equal(a, b)
 
 
