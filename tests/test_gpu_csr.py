@@ -94,6 +94,35 @@ def _host_cutoff(pos, cutoff, scale=0.1):
     return np.asarray(rp, np.int64), np.asarray(col, np.int64), np.asarray(dist, np.float64)
 
 
+@pytest.mark.parametrize("case", ["7lgi", "grid", "tiny"])
+def test_cutoff_kernels_give_identical_rows(gpu_device, monkeypatch, case):
+    """one wave per atom (default for molecule-sized calls), 16 lanes per atom (NG_KNN=lanes) and one lane per atom
+    (NG_KNN=serial): the same CSR rows bit for bit — the count and the fill pass of every form use one distance expression"""
+    from nmrgnn_amd.graph import frames_to_batch_cutoff
+    from nmrgnn_amd.structure import atoms_onehot, read_pdb
+    if case == "7lgi":
+        s = read_pdb(PDB2)
+        frames, atoms, cut = np.stack(s.frames[:3]), atoms_onehot(s.elements), 4.0
+    elif case == "grid":        # integer coordinates: many pairs exactly AT the cutoff distance
+        rng = np.random.default_rng(2)
+        frames = rng.integers(0, 9, size=(2, 1500, 3)).astype(np.float32)
+        atoms, cut = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 1500)], 3.0
+    else:
+        frames = np.array([[[0, 0, 0], [1, 0, 0], [0, 2, 0], [9, 9, 9]]], np.float32)
+        atoms, cut = np.eye(10, dtype=np.float32)[[4, 2, 3, 4]], 2.5
+    out = {}
+    for mode in ("serial", "lanes", "wave"):
+        if mode == "wave":
+            monkeypatch.delenv("NG_KNN", raising=False)
+        else:
+            monkeypatch.setenv("NG_KNN", mode)
+        gc = frames_to_batch_cutoff(atoms, frames, cutoff=cut, device=gpu_device)
+        out[mode] = [t.cpu().numpy() for t in (gc.row_ptr, gc.nlist, gc.edges, gc.inv_degree, gc.row_of)]
+    for mode in ("lanes", "wave"):
+        for a, b in zip(out["serial"], out[mode]):
+            assert np.array_equal(a, b), mode
+
+
 def test_cutoff_builder_matches_host(gpu_device):
     from nmrgnn_amd.graph import frames_to_batch_cutoff
     from nmrgnn_amd.structure import atoms_onehot, read_pdb
