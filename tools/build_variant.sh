@@ -10,7 +10,7 @@ pids=()
 for s in $SRCS; do
   fl="$EXTRA"
   for kv in "$@"; do [ "${kv%%=*}" = "$s" ] && fl="$fl ${kv#*=}"; done
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include $fl -c $s -o $OUT/${s%.hip}.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -I../../include $fl -c $s -o $OUT/${s%.hip}.o &
   pids+=($!)
   if [ ${#pids[@]} -ge 8 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
 done
