@@ -55,6 +55,9 @@ struct FcFwdArgs {
 
 __device__ __forceinline__ float4 act4(int act, const f32x4& a) {
   float4 v = make_float4(a[0], a[1], a[2], a[3]);
+#ifdef FC_ABL_NOACT      // timing experiment: what the activation costs
+  return v;
+#endif
   if (act == NG_ACT_SOFTPLUS) {
     v.x = softplus_f(v.x); v.y = softplus_f(v.y); v.z = softplus_f(v.z); v.w = softplus_f(v.w);
   } else if (act != NG_ACT_NONE) {
@@ -76,6 +79,10 @@ __device__ __forceinline__ void fc_unit2(const float (&wf)[16], const float* __r
   }
   acc0 = f32x4{bias.x, bias.y, bias.z, bias.w};
   acc1 = acc0;
+#ifdef FC_ABL_NOMFMA     // timing experiment: the matrix products removed (operands still read)
+  acc0[0] += xa[0].x + xa[1].y + xa[2].z + xa[3].w + wf[0]; acc1[0] += xb[0].x + xb[1].y + xb[2].z + xb[3].w;
+  return;
+#endif
 #pragma unroll
   for (int T = 0; T < 4; ++T) {
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * T + 0], xa[T].x, acc0, 0, 0, 0);
@@ -158,7 +165,12 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs a) {
           const float4 xo = *reinterpret_cast<const float4*>(Xin + r * FC_LD + col);
           const float4 y = make_float4(s.x + xo.x, s.y + xo.y, s.z + xo.z, s.w + xo.w);
           *reinterpret_cast<float4*>(Xout + r * FC_LD + col) = y;
-          if (a.p.y[l]) {
+#ifndef FC_ABL_NOSTORE
+          if (a.p.y[l])
+#else
+          if (a.p.y[l] && a.N < 0)
+#endif
+          {
             const int64_t row = row0 + r;
             *reinterpret_cast<float4*>(row < a.N ? a.p.y[l] + row * FC_F + col : a.dummy + col) = y;
           }

@@ -25,9 +25,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // softplus(x) = log(1+exp(x)) = max(x,0) + log1p(exp(-|x|))   (keras 'softplus')
 // v_exp / v_log hardware transcendentals; below t = 2^-11 the series t - t^2/2 keeps the relative
 // accuracy where 1+t would round (both arms computed: a v_cndmask, no branch).  |error| < 2e-7.
+// The logarithm is v_log_f32 (log2) times ln 2, not __logf: its argument lies in [1, 2], so the denormal-input scaling
+// and the two-word ln 2 product of the library expansion (14 instructions around the v_log) buy nothing against the
+// 6e-8 rounding of 1 + t; in fc_fwd the activation was 22 of 71 us (-DFC_ABL_NOACT), in mp_win_fwd ~1.1 k of 6.7 k cycles.
 __device__ __forceinline__ float softplus_f(float x) {
   const float t = __expf(-fabsf(x));
-  const float l_big = __logf(1.0f + t);
+  const float l_big = 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + t);
   const float l_small = t * (1.0f - 0.5f * t);
   return fmaxf(x, 0.0f) + (t > 4.8828125e-4f ? l_big : l_small);
 }

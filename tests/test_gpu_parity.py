@@ -335,7 +335,11 @@ def test_gradients_with_upstream_gradients_spanning_six_decades(gpu_device, monk
     and unlabelled atoms).  The fp16-piece kernels scale gradient operands per row / per tile by powers of two
     (mp_win_bwd.hip: the h operand of the dw product takes the inverse of the B rows' scales); the round-2 advisor asked
     whether small rows then lose their contribution.  Every gradient tensor against the float64 oracle: within 5e-5 of the
-    tensor's largest entry, and no worse than the f32-input MFMA kernels on the same inputs (x4 + rounding floor)."""
+    tensor's largest entry, and no worse than the f32-input MFMA kernels on the same inputs times 8 (+ a rounding floor): two
+    fp16 pieces carry 22 mantissa bits, so a piece product is good to 2^-21 where the f32-input one is good to 2^-24, and
+    both paths see the same cancellation in these sums.  (The factor was 4 while the fp32 path's own error on edge_fc/3
+    at F = 256 sat at 5e-6; with the shorter softplus of round 4 that error fell to 2.7e-6 and the piece path's
+    1.7e-5 - 2.1e-5 before - no longer fitted 4 x.)"""
     import torch
     from oracle import nmrgnn_oracle as O
     from nmrgnn_amd.engine import Engine
@@ -367,6 +371,6 @@ def test_gradients_with_upstream_gradients_spanning_six_decades(gpu_device, monk
         mx = np.abs(g).max()
         e2 = np.abs(res["f16x2"][k] - g).max() / mx
         e1 = np.abs(res["fp32"][k] - g).max() / mx
-        if e2 > 5e-5 or e2 > 4.0 * e1 + 2e-6:
+        if e2 > 5e-5 or e2 > 8.0 * e1 + 2e-6:
             bad[k] = (e2, e1)
     assert not bad, bad
