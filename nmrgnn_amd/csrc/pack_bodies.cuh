@@ -212,6 +212,38 @@ __device__ __forceinline__ void fc_frag(int bid, int nb, int tid, int L, const f
   }
 }
 
+// fp16 piece fragments of the FC block for v_mfma_f32_16x16x32_f16 (round 4; fc_fused.hip: the H2 bodies), 2^8 W_l:
+//   WfH[((((l*4 + ct)*2 + T)*2 + p)*64 + lane)*4 + j] = pair (k = 32T + 8(lane>>4) + 2j, +1) of piece p, n = 16ct + (lane&15)
+//   WbH[((((l*4 + kt)*2 + T)*2 + p)*64 + lane)*4 + j] = pair (n = 32T + 8(lane>>4) + 2j, +1) of piece p, k = 16kt + (lane&15)
+// (columns n >= n_out of the last layer are zero).  Returns true when a weight leaves the piece range.
+__device__ __forceinline__ bool fc_h2(int bid, int nb, int tid, int L, const float* const (&W)[6], unsigned* __restrict__ WfH,
+                                      unsigned* __restrict__ WbH) {
+  bool bad = false;
+  for (int idx = bid * PKB + tid; idx < L * 512; idx += nb * PKB) {      // (l, ct, T, lane)
+    const int lane = idx & 63, T = (idx >> 6) & 1, ct = (idx >> 7) & 3, l = idx >> 9;
+    const int nout = l == L - 1 ? FC_Hd : FC_Fd;
+    const float* Wl = W[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) Wl = l == q ? W[q] : Wl;
+    const int i16 = 16 * ct + (lane & 15), s0 = 32 * T + 8 * (lane >> 4);
+    unsigned fh[4], fl[4], bh[4], bl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sa = s0 + 2 * j, sb = sa + 1;
+      // forward: k = slot, n = i16;  backward: k = i16, n = slot
+      const float f0 = i16 < nout ? WSCALE * Wl[sa * nout + i16] : 0.f, f1 = i16 < nout ? WSCALE * Wl[sb * nout + i16] : 0.f;
+      const float b0 = sa < nout ? WSCALE * Wl[i16 * nout + sa] : 0.f, b1 = sb < nout ? WSCALE * Wl[i16 * nout + sb] : 0.f;
+      bad |= mpw_out_of_range(f0) || mpw_out_of_range(f1) || mpw_out_of_range(b0) || mpw_out_of_range(b1);
+      split2_pair(f0, f1, fh[j], fl[j]);
+      split2_pair(b0, b1, bh[j], bl[j]);
+    }
+    const size_t o = ((size_t)(((l * 4 + ct) * 2 + T) * 2) * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { WfH[o + j] = fh[j]; WfH[o + 256 + j] = fl[j]; WbH[o + j] = bh[j]; WbH[o + 256 + j] = bl[j]; }
+  }
+  return bad;
+}
+
 // ---- PK_GG (gemm_h2.hip: mp_gg_kernel): fp16 piece fragments of an MPLayer weight w[l][m][n] in the k-step order of the
 // gather-GEMM.  Step s = c32 * E + n covers the 32 gathered columns c = 32 c32 .. + 31 of edge feature n; output column o:
 //   mode 0 (forward update):  value(c, o) = w[l = c][m = o][n]        (A[i][(n, l)] = sum_j e_n h[nbr_j][l])
@@ -273,6 +305,7 @@ __device__ __forceinline__ void pack_job_block(const PackJob& j, int bid, int ti
     case PK_FC: {
       const float* const W[6] = {j.src[0], j.src[1], j.src[2], j.src[3], j.src[4], j.src[5]};
       pk::fc_frag(bid, j.blocks, tid, j.i0, W, (float*)j.dst[0], (float*)j.dst[1]);
+      if (j.dst[2]) bad = pk::fc_h2(bid, j.blocks, tid, j.i0, W, (unsigned*)j.dst[2], (unsigned*)j.dst[3]);
     } break;
     case PK_GG:
       pk::gg_img(bid, j.blocks, tid, j.i0, j.i1 & 0xFFFF, j.i1 >> 16, j.src[0], (unsigned*)j.dst[0]);
