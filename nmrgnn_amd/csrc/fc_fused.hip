@@ -597,7 +597,11 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs& a) {
         } else {
           accb[H2 ? 0 : l].x += p.x; accb[H2 ? 0 : l].y += p.y; accb[H2 ? 0 : l].z += p.z; accb[H2 ? 0 : l].w += p.w;
         }
+#ifdef FC_ABL_H2_NOP
+        if (H2 && a.N < 0) {
+#else
         if (H2) {
+#endif
           float m = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), fabsf(p.w)));
           m = fmaxf(m, fc_ror<8>(m)); m = fmaxf(m, fc_ror<4>(m)); m = fmaxf(m, fc_ror<2>(m)); m = fmaxf(m, fc_ror<1>(m));
           const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
@@ -626,7 +630,11 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs& a) {
         // steps.  The P rows carry different scales S_r, so the x operand takes the inverse: x'[r] = x[r] * S_ref / S_r with
         // S_ref the smallest S of the tile (its largest row; ratio <= 1), the step's product goes into a fresh accumulator and
         // is added to the running sums times 1 / S_ref (mp_win_bwd.hip, node kernel: the same scheme).
+#ifdef FC_ABL_H2_NODW
+        if (a.N < 0) {
+#else
         if (!last || pr == 0) {
+#endif
           int sbref = s_wmin[0];
 #pragma unroll
           for (int i = 1; i < 8; ++i) sbref = min(sbref, s_wmin[i]);
@@ -709,6 +717,9 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs& a) {
         if (H2) {
           // piece body: per row tile three MFMAs per 32-wide step (the last layer's dP has 32 columns: one step); the small
           // products and the leading one in separate accumulators, the row's 2^-8 / S at the end
+#ifdef FC_ABL_H2_NODX
+          if (a.N < 0)
+#endif
 #pragma unroll
           for (int h = 0; h < 2; ++h) {      // one row tile after the other: eight operand registers live, not sixteen
             const char* xr = planes + (16 * (2 * pr + h) + a16) * FC_ROWB + 16 * g4;

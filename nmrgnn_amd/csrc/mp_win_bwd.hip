@@ -36,6 +36,7 @@ constexpr int WROWS = 288;
 constexpr int WC4 = WF / 4;
 constexpr int WTHREADS = 512;
 constexpr int SDP_LD = 68;      // dP / h tile row stride (== 4 mod 16: conflict-free K-strided reads)
+constexpr int SDP_SLOT = 2304;  // floats per dP tile slot of the edge kernel: [32][68] fp32, or two fp16 piece planes [32][72]
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -192,9 +193,12 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* win = smem;                                                   // [WROWS][64]
   float* tile = win + WROWS * WF;                                      // [32][LD]   dA
-  float* sdp = tile + WTA * LD;                                        // [2][32][SDP_LD]
-  int32_t* s_nl = reinterpret_cast<int32_t*>(sdp + 2 * WTA * SDP_LD);  // [2][32*K]
+  float* sdp = tile + WTA * LD;                                        // [2][32][SDP_LD]   (piece form: [2][2 planes][32][72] fp16)
+  int32_t* s_nl = reinterpret_cast<int32_t*>(sdp + 2 * SDP_SLOT);      // [2][32*K]
   int* ctl = reinterpret_cast<int*>(s_nl + 2 * WTA * a.K);             // [2][16]
+  float* s_inv = reinterpret_cast<float*>(ctl + 32);                   // [2][32]  2^-8 / S per dP row (piece form)
+  constexpr int PROWB = (WF + 8) * 2, PPLANE = WTA * PROWB;            // dP piece planes: 144 B per row
+  static_assert(2 * PPLANE <= SDP_SLOT * 4 && WTA * SDP_LD <= SDP_SLOT, "one tile's dP slot holds either form");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,7 +269,7 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
   };
   auto commit = [&](int64_t t) {
     int32_t* nl = s_nl + (t & 1) * per_tile;
-    float* dp = sdp + (t & 1) * WTA * SDP_LD;
+    float* dp = sdp + (t & 1) * SDP_SLOT;
     int lo = 0x7fffffff, hi = -1;
     if (tid < per_tile / 4) {
       reinterpret_cast<int4*>(nl)[tid] = p_nl;
@@ -278,18 +282,24 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
       g.z *= act_grad_from_out(a.act, p_s.z); g.w *= act_grad_from_out(a.act, p_s.w);
     }
     g.x *= p_rs; g.y *= p_rs; g.z *= p_rs; g.w *= p_rs;
-    *reinterpret_cast<float4*>(dp + prow * SDP_LD + 4 * pc) = g;
     if (H2) {
       // row max over the 16 lanes of this DPP row -> S = 2^(14 - e), 2^e > max (biased exponent arithmetic; an all-zero
-      // or non-finite row keeps S = 1)
+      // or non-finite row keeps S = 1).  The row is split HERE, once, into the two fp16 planes the matrix interval reads
+      // (round 4; until then every one of the four waves that multiply a row split it again from an fp32 copy: 50 of a
+      // wave's ~500 instructions per tile)
       float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
       m = fmaxf(m, ror_f<8>(m)); m = fmaxf(m, ror_f<4>(m)); m = fmaxf(m, ror_f<2>(m)); m = fmaxf(m, ror_f<1>(m));
       const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
       const int sb = (ef == 0 || ef == 255) ? 127 : min(267 - ef, 253);
-      if (pc == 0) {
-        dp[prow * SDP_LD + 64] = __builtin_bit_cast(float, sb << 23);
-        dp[prow * SDP_LD + 65] = __builtin_bit_cast(float, (254 - sb) << 23);
-      }
+      const float S = __builtin_bit_cast(float, sb << 23);
+      if (pc == 0) s_inv[(t & 1) * WTA + prow] = __builtin_bit_cast(float, (254 - sb) << 23) * (1.0f / 256.0f);
+      unsigned h0, l0, h1, l1;
+      split2_pair(S * g.x, S * g.y, h0, l0); split2_pair(S * g.z, S * g.w, h1, l1);
+      char* q = reinterpret_cast<char*>(dp) + prow * PROWB + 8 * pc;
+      *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(q + PPLANE) = u32x2{l0, l1};
+    } else {
+      *reinterpret_cast<float4*>(dp + prow * SDP_LD + 4 * pc) = g;
     }
     const int64_t row = t * WTA + prow;
     *reinterpret_cast<float4*>(row < a.N ? a.dP + row * WF + 4 * pc : a.dummy + 4 * pc) = g;
@@ -317,18 +327,13 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
       float oscale = 1.0f;
       if (H2) {
         // B operand of step Ts: this lane's row (atom a16), k-slots 32 Ts + 8 g4 + (0..7), scaled and split here
-        const float* xr = sdp + (t & 1) * WTA * SDP_LD + (16 * hh + a16) * SDP_LD;
-        const float S = xr[64];
-        oscale = xr[65] * (1.0f / 256.0f);
+        const char* xr = reinterpret_cast<const char*>(sdp + (t & 1) * SDP_SLOT) + (16 * hh + a16) * PROWB + 16 * g4;
+        oscale = s_inv[(t & 1) * WTA + 16 * hh + a16];
         u32x4 xh[2], xl[2];
 #pragma unroll
         for (int Ts = 0; Ts < 2; ++Ts) {
-          const float4 v0 = *reinterpret_cast<const float4*>(xr + 32 * Ts + 8 * g4);
-          const float4 v1 = *reinterpret_cast<const float4*>(xr + 32 * Ts + 8 * g4 + 4);
-          unsigned h0, l0, h1, l1, h2, l2, h3, l3;
-          split2_pair(S * v0.x, S * v0.y, h0, l0); split2_pair(S * v0.z, S * v0.w, h1, l1);
-          split2_pair(S * v1.x, S * v1.y, h2, l2); split2_pair(S * v1.z, S * v1.w, h3, l3);
-          xh[Ts] = u32x4{h0, h1, h2, h3}; xl[Ts] = u32x4{l0, l1, l2, l3};
+          xh[Ts] = *reinterpret_cast<const u32x4*>(xr + 64 * Ts);
+          xl[Ts] = *reinterpret_cast<const u32x4*>(xr + 64 * Ts + PPLANE);
         }
 #pragma unroll
         for (int Ts = 0; Ts < 2; ++Ts) {
@@ -343,7 +348,7 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[u][Ts]), __builtin_bit_cast(f16x8, xh[Ts]), acc[u], 0, 0, 0);
         }
       } else {
-      const float* xrow = sdp + (t & 1) * WTA * SDP_LD + (16 * hh + a16) * SDP_LD + 4 * g4;
+      const float* xrow = sdp + (t & 1) * SDP_SLOT + (16 * hh + a16) * SDP_LD + 4 * g4;
       float4 x[4];
 #pragma unroll
       for (int T = 0; T < 4; ++T) x[T] = *reinterpret_cast<const float4*>(xrow + 16 * T);
@@ -892,7 +897,7 @@ size_t node_lds_bytes(int E, bool h2) {
 }
 
 size_t edge_lds_bytes(int K, int E) {
-  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + 2 * WTA * SDP_LD + 2 * WTA * K + 32) * 4;
+  return (size_t)(WROWS * WF + WTA * (E * WF + 4) + 2 * SDP_SLOT + 2 * WTA * K + 32 + 2 * WTA) * 4;
 }
 
 }  // namespace
