@@ -116,6 +116,7 @@ struct Switches {
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false, knn_cells = false, knn_brute = false;
   bool mp_gg_on = false;             // NG_MP_GG=1
+  bool mp_w16 = true;                // NG_MP_W16=0: the eight-wave forward window kernel instead of the 16-wave one (mp_win16.hip)
   bool knn_lanes = false;            // NG_KNN=lanes
   int64_t mp_gg_min_rows = 8192;     // NG_MP_GG_MIN_ROWS
 };

@@ -6,6 +6,7 @@ power-of-two scales and cannot leave the fp16 range; a weight with |2^8 w| >= 65
 raises the range guard (ng_internal.h: RangeGuard), and each kernel then runs its fp32-input body.
 Property: results equal float64 within the fp32 bound; with out-of-range weights they equal the NG_GEMM_MATH=fp32 bits."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -71,8 +72,14 @@ def test_window_forward_beyond_the_piece_range(gpu_device, monkeypatch, trigger,
         assert np.abs(out - out_ref).max() < 3e-6 * max(1.0, mag.max()), math
         assert np.abs(S - S_ref).max() < 3e-6 * max(1.0, mag.max()), math
     if trigger == "weights":       # the kernel ran its fp32-input body
-        np.testing.assert_array_equal(res["f16x2"][0], res["fp32"][0])
-        np.testing.assert_array_equal(res["f16x2"][1], res["fp32"][1])
+        if K <= 16 and os.environ.get("NG_MP_W16", "1") != "0":
+            # the sixteen-wave forward (mp_win16.hip) sums the two halves of the contraction in separate waves: the same
+            # f32-input products as the NG_GEMM_MATH=fp32 kernel, met in another order
+            for i in (0, 1):
+                assert np.abs(res["f16x2"][i] - res["fp32"][i]).max() <= 1e-6 * max(1.0, mag.max())
+        else:
+            np.testing.assert_array_equal(res["f16x2"][0], res["fp32"][0])
+            np.testing.assert_array_equal(res["f16x2"][1], res["fp32"][1])
 
 
 def test_window_forward_keeps_the_range_flag_with_a_frozen_image(gpu_device, monkeypatch):
