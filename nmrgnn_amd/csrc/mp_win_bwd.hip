@@ -88,6 +88,21 @@ __device__ __forceinline__ void win_stage(float4* __restrict__ win4, const float
   for (int u = 0; u < 9; ++u) win4[tid + WTHREADS * u] = v[u];
 }
 
+// The window by LDS-DMA (round 4): its 288 rows are one contiguous 72-KB block of the source array — 72 wave-instructions
+// of 1 KB, nine per wave, straight into LDS with no registers in between, so the request can be made as soon as no wave
+// reads the old window any more and awaited (s_waitcnt vmcnt(0)) in front of the barrier before the next gather: the
+// HBM / L2 round trip runs beside the matrix interval.  Rows past the end read as zeros (buffer bounds).  32-bit byte
+// offsets: up to 16.7 M rows, beyond that the register staging above.
+__device__ __forceinline__ void win_dma(float* __restrict__ win, __amdgpu_buffer_rsrc_t rs, int wlo, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < WROWS * WF * 4 / 1024 / 8; ++j) {
+    const int kb = wave + 8 * j;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
+                                             lane * 16, wlo * (WF * 4) + kb * 1024, 0, 0);
+  }
+}
+static_assert(WROWS * WF * 4 == 72 * 1024 && WTHREADS == 512, "win_dma: nine 1-KB instructions for each of eight waves");
+
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
@@ -211,6 +226,8 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
   const float4* src4 = reinterpret_cast<const float4*>(a.h);
   float4* win4 = reinterpret_cast<float4*>(win);
   for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
+  const bool dma_ok = a.N * (int64_t)(WF * 4) < ((int64_t)1 << 32);
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h, 0, dma_ok ? (int)(unsigned)(a.N * (WF * 4)) : 0, 0x00020000);
 
   // weight fragments: this wave's NCT column tiles of dA (o = 16*ct + ...), contraction over m (4 k-steps)
   const int hh = wave >> 2, ct0 = (wave & 3) * NCT;
@@ -318,7 +335,12 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
   const int a16 = lane & 15, g4 = lane >> 4;
 #pragma unroll 1
   for (int64_t t = T0; t < T1; ++t) {
-    if (win_decide(ctl + (t & 1) * 16, wlo, mode)) win_stage(win4, src4, wlo, a.N, tid);
+    // (no wave reads the window between the last barrier and the one behind the matrix interval)
+    const bool staged = win_decide(ctl + (t & 1) * 16, wlo, mode);
+    if (staged) {
+      if (dma_ok) win_dma(win, hrsrc, wlo, wave, lane);
+      else win_stage(win4, src4, wlo, a.N, tid);
+    }
     // ---- matrix interval: dA tile = dP tile x Wp^T
     {
       f32x4 acc[NCT];
@@ -370,6 +392,7 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
         *reinterpret_cast<float4*>(tile + (16 * hh + a16) * LD + 16 * (ct0 + u) + 4 * g4) =
             make_float4(acc[u][0] * oscale, acc[u][1] * oscale, acc[u][2] * oscale, acc[u][3] * oscale);
     }
+    if (staged && dma_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NG_LDS_BARRIER();
     // ---- vector interval: de of tile t, then dP / lists of tile t+1 into LDS, requests for t+2
     {
@@ -598,6 +621,8 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
   const float4* src4 = reinterpret_cast<const float4*>(a.dP);
   float4* win4 = reinterpret_cast<float4*>(win);
   for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
+  const bool dma_ok = a.N * (int64_t)(WF * 4) < ((int64_t)1 << 32);
+  const __amdgpu_buffer_rsrc_t psrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dP, 0, dma_ok ? (int)(unsigned)(a.N * (WF * 4)) : 0, 0x00020000);
 
   const int ct = wave & 3, hh = wave >> 2;      // dh: column tile, atom half;  dw: l-tile ct, column half hh
   float wf[H2 ? 1 : KF / 4];
@@ -701,6 +726,14 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
       issue(t + 2 < T1 ? t + 2 : t);
       issue_rows(t + 1 < T1 ? t + 1 : t);
       NG_LDS_BARRIER();
+      // the next tile's window, when it needs one: every gather of this tile is done and the range of t + 1 was published
+      // before the barrier; nothing reads the window until the gather behind the interval's last barrier
+      bool restage = false;
+      if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * 16, wlo, mode);
+      if (restage) {
+        if (dma_ok) win_dma(win, psrc, wlo, wave, lane);
+        else win_stage(win4, src4, wlo, a.N, tid);
+      }
       // ---- matrix interval: dh = dH + B Wn ;  dw += h^T B
       {
         // operand reads run two k-steps ahead of their MFMAs (pinned): holding all NT of them kept 48 VGPRs
@@ -825,13 +858,8 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
             accW[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb[ro * LD + 16 * u], accW[u], 0, 0, 0);
         }
       }
-      bool restage = false;
-      if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * 16, wlo, mode);
+      if (restage && dma_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       NG_LDS_BARRIER();
-      if (restage) {
-        win_stage(win4, src4, wlo, a.N, tid);
-        NG_LDS_BARRIER();
-      }
     }
   }
   // ---- dw partial of this workgroup, layout [(n,m)][l]: lane holds l = 16ct + 4(lane>>4) + r, column = 16(NCT*hh+u) + (lane&15)
