@@ -987,6 +987,9 @@ int mp_win_bwd_edge(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
                     const int32_t* nlist, const float* inv_degree, const float* WfragT, const float* s_save,
                     const float* dh_out, float* dP, float* de, int de_accum, float* dummy, RangeGuard guard,
                     const float* WfragT32, const unsigned* wflag, unsigned wflag_ver) {
+  if (mp_win_bwd_h2() && guard.word && sw().mp_w16 && mp_win16_bwd_edge_supported(E, K))
+    return mp_win16_bwd_edge_launch(ctx, st, N, K, E, act, h, nlist, inv_degree, WfragT, s_save, dh_out, dP, de, de_accum, dummy, guard,
+                                    WfragT32, wflag, wflag_ver);
   MpWinEdgeArgs a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
   const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);

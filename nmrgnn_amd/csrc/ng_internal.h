@@ -177,7 +177,13 @@ int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const f
 // backward images, the dA image as fp16 piece fragments (mp_win.hip)
 // f32T / f32N (optional): the fp32 fragment images of the same launch, for the guarded fallback kernels
 PackJob mpw_bwd_job(int E, const float* w, float* outT, float* outN, float* f32T, float* f32N, unsigned* flag, RangeGuard guard);
-// 16-wave form of the forward window kernel (mp_win16.hip; opt-in NG_MP_W16=1), launched by mp_win_fwd on its images
+// 16-wave form of the edge-side backward window kernel (mp_win16_bwd.hip), launched by mp_win_bwd_edge on its images
+bool mp_win16_bwd_edge_supported(int E, int K);
+int mp_win16_bwd_edge_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h, const int32_t* nlist,
+                             const float* inv_degree, const float* WfragT, const float* s_save, const float* dh_out, float* dP,
+                             float* de, int de_accum, float* dummy, RangeGuard guard, const float* WfragT32, const unsigned* wflag,
+                             unsigned wflag_ver);
+// 16-wave form of the forward window kernel (mp_win16.hip; default; NG_MP_W16=0: the eight-wave kernels), launched by mp_win_fwd on its images
 bool mp_win16_supported(int E, int K);
 int mp_win16_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
                     const int32_t* nlist, const float* e, const float* inv_degree, const float* Wfrag, const float* Wf32,
