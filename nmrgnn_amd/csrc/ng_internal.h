@@ -177,6 +177,11 @@ int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const f
 // backward images, the dA image as fp16 piece fragments (mp_win.hip)
 // f32T / f32N (optional): the fp32 fragment images of the same launch, for the guarded fallback kernels
 PackJob mpw_bwd_job(int E, const float* w, float* outT, float* outN, float* f32T, float* f32N, unsigned* flag, RangeGuard guard);
+// 16-wave form of the node-side backward window kernel (mp_win16_node.hip), launched by mp_win_bwd_node on its images
+bool mp_win16_bwd_node_supported(int E);
+int mp_win16_bwd_node_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP, const int32_t* csc_ptr,
+                             const float* rec, const float* WfragN, const float* dh_out, float* dh_in, float* scratch, float* dummy,
+                             RangeGuard guard, const float* WfragN32, const unsigned* wflag, unsigned wflag_ver, int* grid_out);
 // 16-wave form of the edge-side backward window kernel (mp_win16_bwd.hip), launched by mp_win_bwd_edge on its images
 bool mp_win16_bwd_edge_supported(int E, int K);
 int mp_win16_bwd_edge_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h, const int32_t* nlist,
