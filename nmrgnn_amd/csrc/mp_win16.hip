@@ -150,24 +150,20 @@ __device__ __forceinline__ bool win_decide(const int* __restrict__ ctl, int& wlo
   return true;
 }
 
-constexpr int WIN_NV = (WROWS * WC4 + WTHREADS - 1) / WTHREADS;      // 5 float4 per thread, the last one for half the threads
-__device__ __forceinline__ void win_fetch(float4 (&v)[WIN_NV], const float4* __restrict__ src4, int wlo, int64_t N, int tid) {
+// The window by LDS-DMA: its 288 rows are one contiguous 72-KB block of the source array — 72 wave-instructions of 1 KB
+// straight into LDS, no registers in between.  The buffer is the block itself (base = row wlo, clipped at the array's end:
+// rows past it read as zeros), so there is no 32-bit limit on the array and no register-staged second path.
+__device__ __forceinline__ void win_dma(float* __restrict__ win, const float* __restrict__ src, int wlo_v, int64_t N, int wave, int lane) {
+  const int wlo = __builtin_amdgcn_readfirstlane(wlo_v);
+  const int64_t rows = std::min<int64_t>(N - wlo, WROWS);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)wlo * WF), 0, (int)(rows * (WF * 4)), 0x00020000);
 #pragma unroll
-  for (int u = 0; u < WIN_NV; ++u) {
-    const int idx = min(tid + WTHREADS * u, WROWS * WC4 - 1);
-    const int64_t row = (int64_t)wlo + (idx >> 4);
-    v[u] = row < N ? src4[row * WC4 + (idx & 15)] : f4zero();
+  for (int j = 0; j < (WROWS * WF * 4 / 1024 + NW - 1) / NW; ++j) {
+    const int kb = wave + NW * j;
+    if (kb < WROWS * WF * 4 / 1024)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
+                                               lane * 16, kb * 1024, 0, 0);
   }
-}
-__device__ __forceinline__ void win_put(float4* __restrict__ win4, const float4 (&v)[WIN_NV], int tid) {
-#pragma unroll
-  for (int u = 0; u < WIN_NV; ++u)
-    if (tid + WTHREADS * u < WROWS * WC4) win4[tid + WTHREADS * u] = v[u];
-}
-__device__ __forceinline__ void win_stage(float4* __restrict__ win4, const float4* __restrict__ src4, int wlo, int64_t N, int tid) {
-  float4 v[WIN_NV];
-  win_fetch(v, src4, wlo, N, tid);
-  win_put(win4, v, tid);
 }
 
 // one lane's list entry: neighbour index and E edge weights of (atom, slot)
@@ -284,11 +280,6 @@ __device__ __forceinline__ void body(const Args& a) {
 
   const float4* src4 = reinterpret_cast<const float4*>(a.h);
   float4* win4 = reinterpret_cast<float4*>(win);
-  // h as a buffer for the window's LDS-DMA (32-bit byte offsets: up to 16.7 M atoms; beyond that the register staging)
-  const bool dma_ok = a.N * (int64_t)(WF * 4) < ((int64_t)1 << 32);
-  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h, 0, dma_ok ? (int)(unsigned)(a.N * (WF * 4)) : 0, 0x00020000);
-  for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();       // clamped reads of padded slots must hit finite values
-
   // matrix role: column tile, row-tile pair, k-half; the block this wave finishes is row tile 2 rp + kh
   const int ct = wave & 3, rp = (wave >> 2) & 1, kh = wave >> 3;
   const int a16 = lane & 15, g = lane >> 4;
@@ -318,7 +309,10 @@ __device__ __forceinline__ void body(const Args& a) {
   range_of(cur, T0, ctl + (T0 & 1) * (2 * NW));
   int wlo = -(1 << 30), mode = 0;
   NG_LDS_BARRIER();
-  if (win_decide(ctl + (T0 & 1) * (2 * NW), wlo, mode)) win_stage(win4, src4, wlo, a.N, tid);
+  if (win_decide(ctl + (T0 & 1) * (2 * NW), wlo, mode)) {
+    win_dma(win, a.h, wlo, a.N, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   NG_LDS_BARRIER();
 
   const int rt_own = 2 * rp + kh;
@@ -344,24 +338,11 @@ __device__ __forceinline__ void body(const Args& a) {
     NG_LDS_BARRIER();
     W16_T(3);
     // the next tile's window, when it needs one: requested NOW (every gather of this tile is done, its range was published
-    // before the barrier) as LDS-DMA — 72 wave-instructions of 1 KB straight from h into the window, no registers — and
-    // awaited in front of the tile's last barrier: the HBM / L2 round trip runs beside the matrix interval and the epilogue.
-    // Rows past the end read as zeros (buffer bounds).
+    // before the barrier) as LDS-DMA and awaited in front of the tile's last barrier: the HBM / L2 round trip runs beside
+    // the matrix interval and the epilogue.
     bool restage = false;
     if (t + 1 < T1) restage = win_decide(ctl + ((t + 1) & 1) * (2 * NW), wlo, mode);
-    if (restage) {
-      if (dma_ok) {
-#pragma unroll
-        for (int j = 0; j < (WROWS * WF * 4 / 1024 + NW - 1) / NW; ++j) {
-          const int kb = wave + NW * j;
-          if (kb < WROWS * WF * 4 / 1024)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(hrsrc, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024),
-                                                     16, lane * 16, wlo * (WF * 4) + kb * 1024, 0, 0);
-        }
-      } else {
-        win_stage(win4, src4, wlo, a.N, tid);
-      }
-    }
+    if (restage) win_dma(win, a.h, wlo, a.N, wave, lane);
     // ---- matrix interval: this wave's k-half of its two blocks; the partial of the block it does not finish goes to LDS
     f32x4 part[2];
     if (H2) {
@@ -439,7 +420,7 @@ __device__ __forceinline__ void body(const Args& a) {
     cur = nxt;
     nxt = nn;
     W16_T(6);
-    if (restage && dma_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (restage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next gather writes the tile planes and s_rs, which this tile's matrix interval and epilogue read; a restaged
     // window must be complete: one barrier for both
     NG_LDS_BARRIER();

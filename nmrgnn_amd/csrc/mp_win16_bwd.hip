@@ -90,26 +90,19 @@ __device__ __forceinline__ bool win_decide(const int* __restrict__ ctl, int& wlo
   return true;
 }
 
-__device__ __forceinline__ void win_stage(float4* __restrict__ win4, const float4* __restrict__ src4, int wlo, int64_t N, int tid) {
-  constexpr int NV = (WROWS * WC4 + WTHREADS - 1) / WTHREADS;
-  float4 v[NV];
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int idx = min(tid + WTHREADS * u, WROWS * WC4 - 1);
-    const int64_t row = (int64_t)wlo + (idx >> 4);
-    v[u] = row < N ? src4[row * WC4 + (idx & 15)] : f4zero();
-  }
-#pragma unroll
-  for (int u = 0; u < NV; ++u)
-    if (tid + WTHREADS * u < WROWS * WC4) win4[tid + WTHREADS * u] = v[u];
-}
-__device__ __forceinline__ void win_dma(float* __restrict__ win, __amdgpu_buffer_rsrc_t rs, int wlo, int wave, int lane) {
+// The window by LDS-DMA: its 288 rows are one contiguous 72-KB block of the source array — 72 wave-instructions of 1 KB
+// straight into LDS, no registers in between.  The buffer is the block itself (base = row wlo, clipped at the array's end:
+// rows past it read as zeros), so there is no 32-bit limit on the array and no register-staged second path.
+__device__ __forceinline__ void win_dma(float* __restrict__ win, const float* __restrict__ src, int wlo_v, int64_t N, int wave, int lane) {
+  const int wlo = __builtin_amdgcn_readfirstlane(wlo_v);
+  const int64_t rows = std::min<int64_t>(N - wlo, WROWS);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)wlo * WF), 0, (int)(rows * (WF * 4)), 0x00020000);
 #pragma unroll
   for (int j = 0; j < (WROWS * WF * 4 / 1024 + NW - 1) / NW; ++j) {
     const int kb = wave + NW * j;
     if (kb < WROWS * WF * 4 / 1024)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
-                                               lane * 16, wlo * (WF * 4) + kb * 1024, 0, 0);
+                                               lane * 16, kb * 1024, 0, 0);
   }
 }
 
@@ -191,8 +184,6 @@ __device__ __forceinline__ void body(const Args& a) {
   const float4* src4 = reinterpret_cast<const float4*>(a.h);
   float4* win4 = reinterpret_cast<float4*>(win);
   for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
-  const bool dma_ok = a.N * (int64_t)(WF * 4) < ((int64_t)1 << 32);
-  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h, 0, dma_ok ? (int)(unsigned)(a.N * (WF * 4)) : 0, 0x00020000);
 
   // matrix role: column tile `wave` of dA (waves >= NCT have none)
   const bool mx = wave < NCT;
@@ -276,10 +267,7 @@ __device__ __forceinline__ void body(const Args& a) {
   for (int64_t t = T0; t < T1; ++t) {
     // (no wave reads the window between the last barrier and the one behind the matrix interval)
     const bool staged = win_decide(ctl + (t & 1) * (2 * NW), wlo, mode);
-    if (staged) {
-      if (dma_ok) win_dma(win, hrsrc, wlo, wave, lane);
-      else win_stage(win4, src4, wlo, a.N, tid);
-    }
+    if (staged) win_dma(win, a.h, wlo, a.N, wave, lane);
     // ---- matrix interval: dA tile = dP tile x Wp^T, column tile `wave`, row tile after row tile
     if (mx) {
       if (H2) {
@@ -321,7 +309,7 @@ __device__ __forceinline__ void body(const Args& a) {
         }
       }
     }
-    if (staged && dma_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NG_LDS_BARRIER();
     // ---- vector interval: de of tile t, then the dP rows / range of tile t+1, requests for t+2
     {
