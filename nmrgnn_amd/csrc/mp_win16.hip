@@ -450,8 +450,8 @@ int mp_win16_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int ac
   using namespace w16;
   Args a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, (int64_t)ctx->num_cu);      // contiguous runs of tiles, a multiple of 4 (256 atoms)
-  per = cdiv(per, 4) * 4;
+  // contiguous runs of tiles per workgroup: multiples of 4 (256 atoms) when the batch is large enough (ng_internal.h)
+  const int64_t per = win16_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.h = h; a.nlist = nlist; a.e = e; a.Wfrag = Wfrag; a.Wfrag32 = Wf32; a.rowscale = inv_degree; a.residual = residual;
   a.out = h_out; a.S_save = s_save; a.act = act; a.dummy = const_cast<float*>(Wfrag) + (size_t)E * WF * WF;

@@ -355,8 +355,8 @@ int mp_win16_bwd_edge_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int 
   using namespace w16b;
   Args a{};
   a.N = N; a.K = K; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, (int64_t)ctx->num_cu);      // contiguous runs of tiles, a multiple of 4 (256 atoms)
-  per = cdiv(per, 4) * 4;
+  // contiguous runs of tiles per workgroup: multiples of 4 (256 atoms) when the batch is large enough (ng_internal.h)
+  const int64_t per = win16_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.dH = dh_out; a.S = act == NG_ACT_NONE ? nullptr : s_save; a.rowscale = inv_degree; a.h = h;
   a.nlist = nlist; a.WfragT = WfragT; a.WfragT32 = WfragT32; a.dP = dP; a.de = de; a.dummy = dummy; a.act = act;

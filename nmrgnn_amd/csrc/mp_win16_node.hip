@@ -590,8 +590,8 @@ int mp_win16_bwd_node_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int E, cons
   using namespace w16n;
   Args a{};
   a.N = N; a.ntiles = cdiv(N, WTA);
-  int64_t per = cdiv(a.ntiles, (int64_t)ctx->num_cu);      // contiguous runs of tiles, a multiple of 4 (256 atoms)
-  per = cdiv(per, 4) * 4;
+  // contiguous runs of tiles per workgroup: multiples of 4 (256 atoms) when the batch is large enough (ng_internal.h)
+  const int64_t per = win16_tiles_per_wg(a.ntiles, ctx->num_cu);
   a.tiles_per_wg = (int)per;
   a.dP = dP; a.dH = dh_out; a.h = h; a.csc_ptr = csc_ptr; a.rec = reinterpret_cast<const float4*>(rec);
   a.WfragN = WfragN; a.WfragN32 = WfragN32; a.dh = dh_in; a.partial = scratch; a.dummy = dummy;

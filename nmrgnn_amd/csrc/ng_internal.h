@@ -166,6 +166,17 @@ inline int64_t win_tiles_per_wg(int64_t ntiles, int num_cu) {
   return base;
 }
 
+// the same for the 64-atom tiles of the sixteen-wave kernels: runs of 4 tiles (256 atoms) unless that idles CUs
+inline int64_t win16_tiles_per_wg(int64_t ntiles, int num_cu) {
+  const int64_t base = std::max<int64_t>(cdiv(ntiles, num_cu), 1);
+  const int64_t want = std::min<int64_t>(num_cu, ntiles);
+  for (int align = 4; align > 1; align >>= 1) {
+    const int64_t per = cdiv(base, align) * align;
+    if (cdiv(ntiles, per) * 10 >= want * 9) return per;
+  }
+  return base;
+}
+
 // window-resident neighbour aggregation for F % 128 == 0 (mp_win.hip); padded lists with K % 4 == 0, K <= 16, E <= 3
 bool agg_win_supported(int F, int E, int K);
 int agg_win_rows();
