@@ -18,22 +18,17 @@
 #include "ng_internal.h"
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "h2_common.cuh"
+#include "mp_win16_common.cuh"
 
 namespace ng {
 namespace w16b {
 
-constexpr int WF = 64;
-constexpr int WTA = 64;         // atoms per tile
-constexpr int WROWS = 288;      // window rows
-constexpr int WC4 = WF / 4;
-constexpr int WTHREADS = 1024;
-constexpr int NW = WTHREADS / 64;
+using namespace w16c;
+
 constexpr int PROWB = (WF + 8) * 2, PPLANE = WTA * PROWB;      // dP piece planes: 144 B per row
 constexpr int SDP_LD = 68;                                     // fp32 dP rows (fp32 body)
 constexpr int DP_BYTES = 2 * PPLANE;                           // >= WTA * SDP_LD * 4
 static_assert(DP_BYTES >= WTA * SDP_LD * 4, "the dP slot holds either form");
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
   int64_t N;
@@ -57,54 +52,7 @@ struct Args {
   unsigned wflag_ver;
 };
 
-__device__ __forceinline__ int wave_min_i32(int v) {
-  const int big = 0x7fffffff;
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false));
-  return v;
-}
-template <int S>
-__device__ __forceinline__ int ror_i(int v) {
-  if (S == 0) return v;
-  return __builtin_amdgcn_update_dpp(0, v, 0x120 + (S & 15), 0xf, 0xf, false);
-}
-template <int S>
-__device__ __forceinline__ float ror_f(float v) {
-  return __builtin_bit_cast(float, ror_i<S>(__builtin_bit_cast(int, v)));
-}
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-__device__ __forceinline__ bool win_decide(const int* __restrict__ ctl, int& wlo, int& mode) {
-  int lo = ctl[0], hi = ctl[NW];
-#pragma unroll
-  for (int i = 1; i < NW; ++i) { lo = min(lo, ctl[i]); hi = max(hi, ctl[NW + i]); }
-  mode = 0;
-  if (hi < lo) return false;
-  if (lo >= wlo && hi < wlo + WROWS) return false;
-  if (hi - lo + 1 > WROWS) { mode = 1; return false; }
-  wlo = max(0, lo - (WROWS - (hi - lo + 1)) / 2);
-  return true;
-}
-
-// The window by LDS-DMA: its 288 rows are one contiguous 72-KB block of the source array — 72 wave-instructions of 1 KB
-// straight into LDS, no registers in between.  The buffer is the block itself (base = row wlo, clipped at the array's end:
-// rows past it read as zeros), so there is no 32-bit limit on the array and no register-staged second path.
-__device__ __forceinline__ void win_dma(float* __restrict__ win, const float* __restrict__ src, int wlo_v, int64_t N, int wave, int lane) {
-  const int wlo = __builtin_amdgcn_readfirstlane(wlo_v);
-  const int64_t rows = std::min<int64_t>(N - wlo, WROWS);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)wlo * WF), 0, (int)(rows * (WF * 4)), 0x00020000);
-#pragma unroll
-  for (int j = 0; j < (WROWS * WF * 4 / 1024 + NW - 1) / NW; ++j) {
-    const int kb = wave + NW * j;
-    if (kb < WROWS * WF * 4 / 1024)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
-                                               lane * 16, kb * 1024, 0, 0);
-  }
-}
 
 // one rotation step of the edge-gradient dot (mp_win_bwd.hip: edge_step): this lane's chunk of dA[i][n][:] against the row
 // of the slot that the rotation brings here; the partial goes back to the accumulator of that slot's lane

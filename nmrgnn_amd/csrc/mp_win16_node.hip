@@ -25,21 +25,16 @@
 #include "ng_internal.h"
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "h2_common.cuh"
+#include "mp_win16_common.cuh"
 
 namespace ng {
 namespace w16n {
 
-constexpr int WF = 64;
-constexpr int WTA = 64;         // atoms per tile
-constexpr int WROWS = 288;      // window rows
-constexpr int WC4 = WF / 4;
-constexpr int WTHREADS = 1024;
-constexpr int NW = WTHREADS / 64;
+using namespace w16c;
+
 constexpr int HROWB = (WF + 8) * 2, HPLANE = WTA * HROWB;      // h piece planes: 144 B per row
 constexpr int SDP_LD = 68;                                     // fp32 h rows (fp32 body)
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short gs16x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
@@ -78,59 +73,6 @@ struct Tile {
   static constexpr int BYTES = (2 * PLANE > WTA * LD * 4) ? 2 * PLANE : WTA * LD * 4;
 };
 constexpr int H_BYTES = (2 * HPLANE > WTA * SDP_LD * 4) ? 2 * HPLANE : WTA * SDP_LD * 4;
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-  const int big = 0x7fffffff;
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false));
-  return v;
-}
-template <int S>
-__device__ __forceinline__ int ror_i(int v) {
-  if (S == 0) return v;
-  return __builtin_amdgcn_update_dpp(0, v, 0x120 + (S & 15), 0xf, 0xf, false);
-}
-template <int S>
-__device__ __forceinline__ float ror_f(float v) {
-  return __builtin_bit_cast(float, ror_i<S>(__builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ void pk_axpy(f32x2& lo, f32x2& hi, float w, const float4& h) {
-  const f32x2 ww = {w, w};
-  lo = __builtin_elementwise_fma(ww, f32x2{h.x, h.y}, lo);
-  hi = __builtin_elementwise_fma(ww, f32x2{h.z, h.w}, hi);
-}
-
-__device__ __forceinline__ bool win_decide(const int* __restrict__ ctl, int& wlo, int& mode) {
-  int lo = ctl[0], hi = ctl[NW];
-#pragma unroll
-  for (int i = 1; i < NW; ++i) { lo = min(lo, ctl[i]); hi = max(hi, ctl[NW + i]); }
-  mode = 0;
-  if (hi < lo) return false;
-  if (lo >= wlo && hi < wlo + WROWS) return false;
-  if (hi - lo + 1 > WROWS || hi - lo < 0) { mode = 1; return false; }
-  wlo = max(0, lo - (WROWS - (hi - lo + 1)) / 2);
-  return true;
-}
-// The window by LDS-DMA: its 288 rows are one contiguous 72-KB block of the source array — 72 wave-instructions of 1 KB
-// straight into LDS, no registers in between.  The buffer is the block itself (base = row wlo, clipped at the array's end:
-// rows past it read as zeros), so there is no 32-bit limit on the array and no register-staged second path (whose five
-// per-lane 64-bit addresses, hoisted out of the tile loop, were spilled and reloaded every tile).
-__device__ __forceinline__ void win_dma(float* __restrict__ win, const float* __restrict__ src, int wlo_v, int64_t N, int wave, int lane) {
-  const int wlo = __builtin_amdgcn_readfirstlane(wlo_v);
-  const int64_t rows = std::min<int64_t>(N - wlo, WROWS);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)wlo * WF), 0, (int)(rows * (WF * 4)), 0x00020000);
-#pragma unroll
-  for (int j = 0; j < (WROWS * WF * 4 / 1024 + NW - 1) / NW; ++j) {
-    const int kb = wave + NW * j;
-    if (kb < WROWS * WF * 4 / 1024)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
-                                               lane * 16, kb * 1024, 0, 0);
-  }
-}
 
 // four rotation steps of the first sixteen records (mp_win_bwd.hip: node_steps4)
 template <int E, int S0, bool GLOBAL>

@@ -64,6 +64,7 @@ def test_edge_backward_is_bit_identical_given_the_same_forward(gpu_device, monke
     import torch
     from nmrgnn_amd import _lib
     from nmrgnn_amd._lib import ptr
+    monkeypatch.delenv("NG_MP_W16_NODE", raising=False)   # the node-side kernel is the same (eight-wave) one in both runs
     rng = np.random.default_rng(5)
     N, K, E, F = 1000, 16, 3, 64
     h = rng.standard_normal((N, F)).astype(np.float32)
