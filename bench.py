@@ -395,7 +395,7 @@ def main():
 
     from nmrgnn_amd import _lib, parallel, synth
     from nmrgnn_amd.engine import Engine
-    from nmrgnn_amd.graph import GraphBatch
+    from nmrgnn_amd.graph import BatchPrefetcher, GraphBatch
     from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
     from nmrgnn_amd.train import Trainer
 
@@ -534,6 +534,41 @@ def main():
                                          "unit": "atoms/s", "list_build_ms": t_csc * 1e3,
                                          "note": "raw (atoms, nlist, edges, inv_degree) resident in HBM; GraphBatch and "
                                                  "its lists rebuilt every step"}
+        # the same with the next batch's lists built on a side stream while the step runs (graph.py: BatchPrefetcher)
+        n_pf = max(5, args.steps // 2)
+        stream = iter(BatchPrefetcher(((raw, b["graph_ptr"]) for _ in range(n_pf + 2)), device=dev, validate=False))
+        for _ in range(2):
+            tr.step(next(stream), y, w, total_graphs=total_graphs)
+        ms = event_timed(lambda: tr.step(next(stream), y, w, total_graphs=total_graphs), n_pf)
+        # ... and with the tuple in HOST memory (numpy arrays, what a data loader yields): PCIe-inclusive
+        host_raw = tuple(t.cpu().numpy() for t in raw)
+        def host_step():
+            g2 = GraphBatch(*host_raw, graph_ptr=b["graph_ptr"], device=dev, validate=False)
+            return tr.step(g2, y, w, total_graphs=total_graphs)
+        host_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_pf):
+            host_step()
+        torch.cuda.synchronize()
+        host_plain = (time.perf_counter() - t0) / n_pf * 1e3
+        hstream = iter(BatchPrefetcher(((host_raw, b["graph_ptr"]) for _ in range(n_pf + 1)), device=dev, validate=False))
+        tr.step(next(hstream), y, w, total_graphs=total_graphs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_pf):
+            tr.step(next(hstream), y, w, total_graphs=total_graphs)
+        torch.cuda.synchronize()
+        host_pf = (time.perf_counter() - t0) / n_pf * 1e3
+        out["fresh_batch_every_step"]["from_host_memory"] = {
+            "ms_per_step": host_plain, "value": gb.N / (host_plain * 1e-3),
+            "prefetched_ms_per_step": host_pf, "prefetched_value": gb.N / (host_pf * 1e-3),
+            "bytes_per_step": int(sum(a.nbytes for a in host_raw)),
+            "note": "wall clock; numpy tuple -> device copy + lists + step, every step (PCIe-inclusive); prefetched: the "
+                    "copy and the lists of batch t+1 on a side stream during step t"}
+        out["fresh_batch_every_step"]["prefetched"] = {
+            "ms_per_step": float(np.median(ms)), "value": gb.N / (np.median(ms) * 1e-3),
+            "note": "BatchPrefetcher: batch t+1's copy and lists on a side stream (own library context) during step t"}
 
     # ---- per-kernel hipEvent pass (same step, events bracketed inside the C library).  EVERY rank runs the
     # steps — they contain the gradient all-reduce, a collective — only rank 0 reads the events.

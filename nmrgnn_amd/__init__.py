@@ -11,7 +11,7 @@ __version__ = "0.1.0"
 from .hypers import HyperParameters, declare_gnn_space  # noqa: F401
 
 _LAZY = {
-    "Engine": "engine", "GraphBatch": "graph", "concat_graphs": "graph",
+    "Engine": "engine", "GraphBatch": "graph", "concat_graphs": "graph", "BatchPrefetcher": "graph",
     "MPLayer": "layers", "AMPLayer": "layers", "RBFExpansion": "layers", "EdgeFCBlock": "layers", "MPBlock": "layers",
     "FCBlock": "layers", "GNNModel": "model", "build_GNNModel": "model",
     "load_model": "library", "universe2graph": "library", "check_peaks": "library",

@@ -122,3 +122,18 @@ def test_two_piece_fp16_split_bounds():
     ax, ay = np.abs(f(x)), np.abs(f(y))
     bound = ax * np.maximum(2.0 ** -22 * ay, 2.0 ** -25) + ay * np.maximum(2.0 ** -22 * ax, 2.0 ** -25) + 2.0 ** -21.9 * ax * ay
     assert np.all(np.abs(prod3 - exact) <= bound)
+
+
+def test_batch_prefetcher_on_a_host_device_builds_each_batch_when_asked():
+    """without a GPU the prefetcher has no side stream: it hands out plain GraphBatches, in order, with graph_ptr kept"""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.graph import BatchPrefetcher, GraphBatch
+    bs = [synth.make_batch(2, 20 + i, 16, 10, 0.1, seed=i) for i in range(3)]
+    items = [((b["atoms"], b["nlist"], b["edges"], b["inv_degree"]), b["graph_ptr"]) for b in bs]
+    got = list(BatchPrefetcher(items, device="cpu"))
+    assert [g.N for g in got] == [40, 42, 44]
+    for b, g in zip(bs, got):
+        ref = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device="cpu")
+        assert g.G == 2 and torch.equal(g.csc()[0], ref.csc()[0]) and torch.equal(g.csc()[1], ref.csc()[1])
+    assert list(BatchPrefetcher([], device="cpu")) == []
