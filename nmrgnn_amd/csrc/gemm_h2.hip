@@ -41,26 +41,14 @@ constexpr int gx_wchunk(int nbw) { return 2 * nbw * 2 * 2 * 1024; }   // [n-bloc
 constexpr int gx_lds(int nbw) { return 2 * GX_XPLANE + gx_wchunk(nbw); } // 36,864 / 53,248: two workgroups per CU
 constexpr float GX_WSCALE = 256.0f, GX_WINV = 1.0f / 256.0f;      // weight pieces are taken from 2^8 W
 
-// image[(ct * KT + kt)][nb][ks][p][lane][8 fp16]:  lane (row n = 128 ct + 32 nb + (l&31), k-slot t) =
-//   piece_p( 2^8 W[k = 32 kt + 16 ks + 8 (l>>5) + t][n] )
-// trans: the weights are stored [N][K] (dX = dP W^T: contraction over the stored matrix's columns)
-__global__ void gx_pack_kernel(int K, int N, const float* __restrict__ W, unsigned* __restrict__ img, int trans, int nbw) {
-  const int KT = K / GX_BK;
-  const int BN = 64 * nbw, NB = 2 * nbw;           // columns / 32-column blocks per tile
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (ct, kt, nb, ks, lane)
-  if (idx >= (int64_t)(N / BN) * KT * NB * 2 * 64) return;
-  const int lane = idx & 63, ks = (idx >> 6) & 1;
-  const int nb = (int)((idx >> 7) % NB);
-  const int kt = (int)(((idx >> 7) / NB) % KT), ct = (int)(((idx >> 7) / NB) / KT);
-  const int n = BN * ct + 32 * nb + (lane & 31), k0 = GX_BK * kt + 16 * ks + 8 * (lane >> 5);
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    split2_pair(GX_WSCALE * (trans ? W[(int64_t)n * K + k0 + 2 * j] : W[(int64_t)(k0 + 2 * j) * N + n]),
-                GX_WSCALE * (trans ? W[(int64_t)n * K + k0 + 2 * j + 1] : W[(int64_t)(k0 + 2 * j + 1) * N + n]), h[j], l[j]);
-  unsigned* dst = img + ((int64_t)(ct * KT + kt) * (NB * 2 * 2 * 256)) + ((nb * 2 + ks) * 2) * 256 + lane * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
+// weight image: pack_bodies.cuh gx_img (PK_GX), [(ct * KT + kt)][nb][ks][p][lane][8 fp16], pieces of 2^8 W
+static_assert(GX_BK == pk::GXP_BK && GX_WSCALE == pk::GXP_WSCALE, "pack_bodies.cuh");
+static int gx_image_kind(int trans, int nbw) { return 3 + 16 * trans + 32 * nbw; }       // cache kind of the image
+static PackJob gx_pack_job(int K, int N, int mode, int nbw, const float* W, void* img) {
+  PackJob j;
+  j.kind = PK_GX; j.i0 = K; j.i1 = N | (mode << 20) | (nbw << 24); j.src[0] = W; j.dst[0] = img;
+  j.blocks = (int)std::min<int64_t>(cdiv((int64_t)(N / 32) * (K / 16) * 64, PKB), 1024);
+  return j;
 }
 
 struct GxArgs {
@@ -631,14 +619,17 @@ static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int
   const int BN = 64 * nbw;
   const size_t img_bytes = (size_t)a.N * a.K * 4;  // two fp16 pieces per weight
   bool have = false;
-  char* img = (char*)cached_image(ctx, W, 3 + 16 * trans + 32 * nbw, img_bytes, &have);
+  char* img = (char*)cached_image(ctx, W, gx_image_kind(trans, nbw), img_bytes, &have);
+  const bool cached = img != nullptr;
   if (!img) img = (char*)aux_workspace(ctx, img_bytes);   // callers hold pointers into the main workspace
   if (!img) return NG_ERR_NOMEM;
   if (!have) {
-    const int64_t n_thr = (int64_t)(a.N / 32) * (a.K / 16) * 64;
-    hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)cdiv(n_thr, 256)), dim3(256), 0, st, a.K, a.N, W, (unsigned*)img, trans,
-                       nbw);
-    NG_HIP(ctx, hipGetLastError());
+    // (an image whose source is a weight tensor itself is rebuilt behind ng_adam_step from here on; one registered by
+    // gemm_h2_prepack_mp arrives valid and never comes here)
+    const PackJob j = gx_pack_job(a.K, a.N, trans, nbw, W, img);
+    const int rc = pack_launch(ctx, st, j);
+    if (rc) return rc;
+    if (cached) cache_set_job(ctx, W, gx_image_kind(trans, nbw), j);
   }
   a.Wimg = img;
   ProfScope ps(ctx, st, tag);
@@ -682,6 +673,24 @@ int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int ac
   }
   a.gscale = gscale;
   return gx_launch(ctx, st, a, W, 1, true, tag);
+}
+
+// The images of an MPLayer weight in its GEMM form Wp[n F + l][m] (`Wp`: the cached plain copy, the key the products will look
+// their image up by) for the update product (trans = 0: [M][E F] x [E F][F]) or the dA product (trans = 1: [M][F] x Wp^T),
+// packed from `w` itself and registered with `w` as their source: ng_adam_step's one pack launch refreshes them together with
+// the plain copy, and gx_launch finds them valid.  No-op when the image cache is off or the product will not take this path.
+int gemm_h2_prepack_mp(ng_ctx* ctx, hipStream_t st, int64_t M, int F, int E, const float* w, const float* Wp, int trans) {
+  const int K = trans ? F : E * F, N = trans ? E * F : F;
+  if (!ctx->wcache || !gemm_h2_fwd_ok(M, K, N) || (int64_t)N >= (1 << 20)) return NG_OK;
+  const int nbw = N % 256 == 0 ? 4 : 2;
+  bool have = false;
+  char* img = (char*)cached_image(ctx, Wp, gx_image_kind(trans, nbw), (size_t)N * K * 4, &have);
+  if (!img || have) return NG_OK;
+  const PackJob j = gx_pack_job(K, N, 2 + trans, nbw, w, img);
+  const int rc = pack_launch(ctx, st, j);
+  if (rc) return rc;
+  cache_set_job(ctx, Wp, gx_image_kind(trans, nbw), j);
+  return NG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

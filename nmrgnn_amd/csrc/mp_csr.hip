@@ -430,11 +430,9 @@ int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
     return mp_gg_fwd(ctx, st, N, K, F, E, act, residual, h, row_ptr, col, e, inv_degree, w, h_out, s_save, A_save);
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;
-  bool have = false;
-  float* Wc = (float*)cached_image(ctx, w, 1, (size_t)KF * F * 4, &have);
-  float* Wp = Wc ? Wc : ws;
+  const float* Wp = nullptr;
   float* A = A_save ? A_save : ws + KF * F;
-  int rc = have ? NG_OK : mp_repack_w(ctx, st, F, E, w, Wp);
+  int rc = mp_plain_weights(ctx, st, N, F, E, w, ws, 0, &Wp);
   if (rc) return rc;
   rc = csr_aggregate(ctx, st, N, K, F, E, h, row_ptr, col, e, A);
   if (rc) return rc;
@@ -455,11 +453,11 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
   const size_t rec_floats = gg && !csc_rec ? (size_t)std::max<int64_t>(n_ent, 1) * 4 : 0;
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + N * F + dw_scr + (A_save ? 0 : N * KF) + rec_floats) * 4);
   if (!ws) return NG_ERR_NOMEM;
-  float* Wp = ws;
+  const float* Wp = nullptr;
   float* dA = ws + KF * F;
   float* dP = dA + N * KF;
   float* scr = dP + N * F;
-  int rc = mp_repack_w(ctx, st, F, E, w, Wp);
+  int rc = mp_plain_weights(ctx, st, N, F, E, w, ws, 1, &Wp);
   if (rc) return rc;
   const bool A_save_given = A_save != nullptr;
   if (!A_save) {   // the caller did not keep the forward aggregate: rebuild it

@@ -30,6 +30,9 @@ enum PackKind : int {
   PK_MPW_F32 = 6,    // one f32 fragment image: i1 = mode, dst[0]
   PK_FC = 7,         // FC block: src[0..L-1] = W_l, i0 = L, dst[0] = Wf, dst[1] = Wb
   PK_GG = 8,         // gather-GEMM image of an MPLayer weight (gemm_h2.hip): src[0] = w, i0 = E, i1 = F | mode << 16, dst[0] = img
+  PK_GX = 9,         // piece image of a GEMM weight operand (gemm_h2.hip: gx_launch): src[0] = W (or an MPLayer weight w), i0 = K,
+                     // i1 = N | mode << 20 | nbw << 24, dst[0] = img; mode: pack_bodies.cuh gx_img
+  PK_MP_PLAIN = 10,  // MPLayer weight w[l][m][n] as the plain GEMM operand Wp[n F + l][m]: src[0] = w, i0 = F, i1 = E, dst[0] = Wp
 };
 struct PackJob {
   int kind = PK_NONE;

@@ -70,6 +70,8 @@ bool gemm_h2_dw8_ok(int64_t M, int Kin, int Nout);      // 256 x 256 output tile
 int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X, const float* dY,
                const float* S, const float* rowscale, float* partial, int nz, int64_t rows_per_z, const float* gscale,
                const char* tag, RangeGuard guard);
+// images of an MPLayer weight for the generic GEMMs, packed from w and refreshed behind the weight update (gemm_h2.hip)
+int gemm_h2_prepack_mp(ng_ctx* ctx, hipStream_t st, int64_t M, int F, int E, const float* w, const float* Wp, int trans);
 int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* dY, const float* S,
                const float* rowscale, const float* W, const float* add, float* dX, const float* gscale, const char* tag,
                RangeGuard guard);
@@ -94,6 +96,7 @@ int edge_fused_fwd_f32(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
                        LiveEdges live = LiveEdges());
 
 // elementwise helpers (node_ops.hip)
+int mp_plain_weights(ng_ctx* ctx, hipStream_t st, int64_t M, int F, int E, const float* w, float* scratch, int trans, const float** Wp);
 int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float* Wp);
 
 // generic MPLayer over CSR lists, or padded lists when row_ptr == nullptr (row i = [i*K, (i+1)*K)); any

@@ -233,6 +233,28 @@ int mp_repack_w(ng_ctx* ctx, hipStream_t st, int F, int E, const float* w, float
   return NG_OK;
 }
 
+// The GEMM form Wp[n F + l][m] of an MPLayer weight for a product over M rows: the context's cached copy (rebuilt behind
+// ng_adam_step together with the piece image of the product — gemm_h2_prepack_mp — so that a training step packs nothing), or
+// `scratch` filled here when the image cache is off.  trans: 0 = the update product, 1 = the dA product.
+int mp_plain_weights(ng_ctx* ctx, hipStream_t st, int64_t M, int F, int E, const float* w, float* scratch, int trans, const float** Wp) {
+  bool have = false;
+  float* Wc = (float*)cached_image(ctx, w, 1, (size_t)E * F * F * 4, &have);
+  if (!Wc) {
+    *Wp = scratch;
+    return mp_repack_w(ctx, st, F, E, w, scratch);
+  }
+  *Wp = Wc;
+  if (!have) {
+    PackJob j;
+    j.kind = PK_MP_PLAIN; j.i0 = F; j.i1 = E; j.src[0] = w; j.dst[0] = Wc;
+    j.blocks = (int)std::min<int64_t>(cdiv((int64_t)E * F * F, 256), 1024);
+    const int rc = pack_launch(ctx, st, j);
+    if (rc) return rc;
+    cache_set_job(ctx, w, 1, j);
+  }
+  return gemm_h2_prepack_mp(ctx, st, M, F, E, w, Wc, trans);
+}
+
 // ------------------------------------------------------------------------------------ head
 // peaks[i] = sum_c atoms[i,c] * ((g*mask)[i,:] @ Wout[:,c] + bout[c]) * std[c] + atoms[i,c]*avg[c]
 __global__ __launch_bounds__(256) void head_fwd_kernel(int64_t N, int Fh, int C,
@@ -823,11 +845,9 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
   const size_t need = (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4;
   float* ws = (float*)workspace(ctx, need);
   if (!ws) return NG_ERR_NOMEM;
-  bool have = false;
-  float* Wc = (float*)cached_image(ctx, w, 1, (size_t)KF * F * 4, &have);
-  float* Wp = Wc ? Wc : ws;
+  const float* Wp = nullptr;
   float* A = A_save ? A_save : ws + KF * F;
-  int rc = have ? NG_OK : mp_repack_w(ctx, st, F, E, w, Wp);
+  int rc = mp_plain_weights(ctx, st, N, F, E, w, ws, 0, &Wp);
   if (rc) return rc;
   rc = aggregate(ctx, st, N, K, F, E, h, nlist, e, A);
   if (rc) return rc;

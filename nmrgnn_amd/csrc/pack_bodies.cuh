@@ -271,6 +271,52 @@ __device__ __forceinline__ void gg_img(int bid, int nb_, int tid, int E, int F, 
   }
 }
 
+// ---- PK_GX (gemm_h2.hip: gx_launch): fp16 piece image of the weight operand of a [M][K] x [K][N] product,
+//   image[(ct * KT + kt)][nb][ks][p][lane][8 fp16]:  lane (row n = BN ct + 32 nb + (l&31), k-slot t) =
+//     piece_p( 2^8 B[k = 32 kt + 16 ks + 8 (l>>5) + t][n] ),   BN = 64 nbw
+// mode 0: B[k][n] = W[k][n];  mode 1: W is stored [N][K] (dX = dP W^T);
+// mode 2 / 3: the same two with W = Wp[ne F + l][m] = w[l][m][ne], the GEMM form of an MPLayer weight (PK_MP_PLAIN), read from w
+// itself: the image does not wait for the plain copy, so both are rebuilt in the one launch behind the weight update
+constexpr int GXP_BK = 32;
+constexpr float GXP_WSCALE = 256.0f;
+__device__ __forceinline__ float gx_src(const float* __restrict__ W, int mode, int K, int N, int k, int n) {
+  switch (mode) {
+    case 0: return W[(int64_t)k * N + n];
+    case 1: return W[(int64_t)n * K + k];
+    case 2: { const int F = N, E = K / N; return W[((int64_t)(k % F) * F + n) * E + k / F]; }        // Wp [K = E F][N = F]
+    default: { const int F = K, E = N / K; return W[((int64_t)(n % F) * F + k) * E + n / F]; }       // Wp stored [N = E F][K = F]
+  }
+}
+__device__ __forceinline__ void gx_img(int bid, int nblk, int tid, int K, int N, int mode, int nbw, const float* __restrict__ W,
+                                       unsigned* __restrict__ img) {
+  const int KT = K / GXP_BK;
+  const int BN = 64 * nbw, NB = 2 * nbw;           // columns / 32-column blocks per tile
+  const int64_t total = (int64_t)(N / BN) * KT * NB * 2 * 64;
+  for (int64_t idx = (int64_t)bid * PKB + tid; idx < total; idx += (int64_t)nblk * PKB) {    // (ct, kt, nb, ks, lane)
+    const int lane = idx & 63, ks = (idx >> 6) & 1;
+    const int nb = (int)((idx >> 7) % NB);
+    const int kt = (int)(((idx >> 7) / NB) % KT), ct = (int)(((idx >> 7) / NB) / KT);
+    const int n = BN * ct + 32 * nb + (lane & 31), k0 = GXP_BK * kt + 16 * ks + 8 * (lane >> 5);
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      split2_pair(GXP_WSCALE * gx_src(W, mode, K, N, k0 + 2 * j, n), GXP_WSCALE * gx_src(W, mode, K, N, k0 + 2 * j + 1, n), h[j], l[j]);
+    unsigned* dst = img + ((int64_t)(ct * KT + kt) * (NB * 2 * 2 * 256)) + ((nb * 2 + ks) * 2) * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dst[j] = h[j]; dst[256 + j] = l[j]; }
+  }
+}
+
+// ---- PK_MP_PLAIN (node_ops.hip / mp_csr.hip): w[l][m][n] (reference layout, n fastest) -> Wp[k = n F + l][m]
+__device__ __forceinline__ void mp_plain(int bid, int nblk, int tid, int F, int E, const float* __restrict__ w, float* __restrict__ Wp) {
+  const int total = F * F * E;
+  for (int idx = bid * PKB + tid; idx < total; idx += nblk * PKB) {
+    const int k = idx / F, m = idx % F;
+    const int n = k / F, l = k % F;
+    Wp[idx] = w[((int64_t)l * F + m) * E + n];
+  }
+}
+
 }  // namespace pk
 
 // one block of one job
@@ -309,6 +355,12 @@ __device__ __forceinline__ void pack_job_block(const PackJob& j, int bid, int ti
     } break;
     case PK_GG:
       pk::gg_img(bid, j.blocks, tid, j.i0, j.i1 & 0xFFFF, j.i1 >> 16, j.src[0], (unsigned*)j.dst[0]);
+      break;
+    case PK_GX:
+      pk::gx_img(bid, j.blocks, tid, j.i0, j.i1 & 0xFFFFF, (j.i1 >> 20) & 15, j.i1 >> 24, j.src[0], (unsigned*)j.dst[0]);
+      break;
+    case PK_MP_PLAIN:
+      pk::mp_plain(bid, j.blocks, tid, j.i0, j.i1, j.src[0], (float*)j.dst[0]);
       break;
     default: break;
   }
