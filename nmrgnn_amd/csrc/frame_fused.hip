@@ -8,7 +8,7 @@
 // the CU.  (Nine launches of the layered path: four GEMMs, their four range-fallback launches, the head kernel.)
 //
 // Arithmetic = gemm_h2_short_kernel's: X as two fp16 pieces in LDS, W^T fragments (pieces of 2^8 W, the images
-// gx_pack_kernel builds and the frozen-weight cache keeps) streamed from L2 three k-halves ahead, three piece products
+// the PK_GX pack job builds and the frozen-weight cache keeps) streamed from L2 three k-halves ahead, three piece products
 // per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulate; wave w owns output columns [64 w, 64 w + 64).
 // The residual input of a layer IS the previous epilogue's output and stays in registers in the accumulator layout.
 //
@@ -46,7 +46,7 @@ constexpr int FF_MAXC = 16;
 #define FF_NB 8
 #endif                    // element columns the head handles
 
-// image of a [K][n_valid] weight matrix in the layout of gx_pack_kernel (gemm_h2.hip) for 256-column tiles, columns
+// image of a [K][n_valid] weight matrix in the layout of pk::gx_img (pack_bodies.cuh) for 256-column tiles, columns
 // n_valid .. 255 zero:  lane (row n = 32 nb + (l&31), k-slot t) = piece_p(2^8 W[k = 32 kt + 16 ks + 8 (l>>5) + t][n])
 __global__ void ff_pack_kernel(int K, int n_valid, const float* __restrict__ W, unsigned* __restrict__ img) {
   const int KT = K / 32;
