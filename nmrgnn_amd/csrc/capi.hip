@@ -148,7 +148,7 @@ struct ReduceBatch {
 // The job of a block is picked with compile-time indices (scalar selects over the kernel arguments): a run-time index
 // into the argument struct made the compiler copy the struct to scratch per thread — 0.45 ms for seven jobs.
 static __global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch b) {
-  __shared__ float red[16][64];
+  __shared__ __attribute__((aligned(16))) float red[16 * 4][64];      // [16][64] floats, or float4 (wide jobs: reduce.cuh)
   ReduceJob job = b.job[0];
   unsigned b0 = 0;
 #pragma unroll
@@ -238,7 +238,7 @@ static int queue_job(ng_ctx* ctx, hipStream_t st, const ReduceJob& j) {
   const int k = b.njobs++;
   if (k == 0) b.block0[0] = 0;
   b.job[k] = j;
-  b.block0[k + 1] = b.block0[k] + (unsigned)cdiv(j.n_elem, 64);
+  b.block0[k + 1] = b.block0[k] + reduce_job_blocks(j);
   return NG_OK;
 }
 

@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
                                                             const float* __restrict__ pavg,
                                                             float* __restrict__ peaks, HeadDraw dr) {
   constexpr int Fh = LPR * 4;
-  __shared__ float sWs[Fh * HC_MAX];     // std_c * Wout[f][c]
+  __shared__ __attribute__((aligned(16))) float sWs[Fh * HC_MAX];     // [c][f]: std_c * Wout[f][c] (a lane's four f are one 16-byte read)
   __shared__ float sV[HC_MAX];           // std_c * b_c + avg_c
-  for (int t = threadIdx.x; t < Fh * C; t += 256) sWs[t] = Wout[t] * pstd[t % C];
+  for (int t = threadIdx.x; t < Fh * C; t += 256) sWs[(t % C) * Fh + t / C] = Wout[t] * pstd[t % C];
   if (threadIdx.x < C) sV[threadIdx.x] = pstd[threadIdx.x] * bout[threadIdx.x] + pavg[threadIdx.x];
   __syncthreads();
   const int q = threadIdx.x % LPR;
@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
     float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, v = 0.f;
     for (int c = 0; c < C; ++c) {
       const float a = atoms[i * C + c];
-      u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
-      u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
+      const float4 w4 = *reinterpret_cast<const float4*>(sWs + c * Fh + 4 * q);
+      u0 += a * w4.x; u1 += a * w4.y;
+      u2 += a * w4.z; u3 += a * w4.w;
       v += a * sV[c];
     }
     // explicit fused chain: left to the compiler the two instantiations contracted this sum differently (1 ulp apart)
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t N, int C, in
                                                             float* __restrict__ dg, float* __restrict__ partial) {
   constexpr int Fh = LPR * 4;
   constexpr int RL = 256 / LPR;          // row lanes
-  __shared__ float sWs[Fh * HC_MAX];
+  __shared__ __attribute__((aligned(16))) float sWs[Fh * HC_MAX];     // [c][f], as in the forward
   __shared__ float sStd[HC_MAX];
   extern __shared__ __attribute__((aligned(16))) float red[];     // [RL][Fh*C + C] for the final sum
-  for (int t = threadIdx.x; t < Fh * C; t += 256) sWs[t] = Wout[t] * pstd[t % C];
+  for (int t = threadIdx.x; t < Fh * C; t += 256) sWs[(t % C) * Fh + t / C] = Wout[t] * pstd[t % C];
   if (threadIdx.x < C) sStd[threadIdx.x] = pstd[threadIdx.x];
   __syncthreads();
   const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t N, int C, in
     for (int c = 0; c < CM; ++c) {
       if (c < C) {
         const float a = av[c];
-        u0 += a * sWs[(4 * q + 0) * C + c]; u1 += a * sWs[(4 * q + 1) * C + c];
-        u2 += a * sWs[(4 * q + 2) * C + c]; u3 += a * sWs[(4 * q + 3) * C + c];
+        const float4 w4 = *reinterpret_cast<const float4*>(sWs + c * Fh + 4 * q);
+        u0 += a * w4.x; u1 += a * w4.y;
+        u2 += a * w4.z; u3 += a * w4.w;
         const float d = dp * a * sStd[c];            // dfull[i][c]
         acc[c][0] += x.x * d; acc[c][1] += x.y * d; acc[c][2] += x.z * d; acc[c][3] += x.w * d;
         db[c] += d;
