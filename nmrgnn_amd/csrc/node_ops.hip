@@ -3,6 +3,7 @@
 // Reference: nmrgnn/layers.py:26-46 (MPLayer), nmrgnn/model.py:158-169 (MPBlock), 236-274 (GNNModel),
 // nmrgnn/losses.py:30-39 (NameLoss s=1).
 #include <algorithm>
+#include <type_traits>
 
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
@@ -65,6 +66,14 @@ __global__ void embed_fwd_kernel(int64_t N, int C, int F, const float* __restric
 // The same for rows of 16 / 32 / 64 float4 (F = 64 / 128 / 256) and C <= 16: a row is one lane group, lane j of the group
 // reads atoms[i][j] once and the group passes the C values round (no per-lane re-read of the row, no branch); the lane's
 // column chunk of every Wemb row stays in registers across the grid-stride loop (its chunk index never changes).
+template <int C0, class Fn>
+__device__ __forceinline__ void static_for16(Fn&& f) {
+  if constexpr (C0 < 16) {
+    f(std::integral_constant<int, C0>());
+    static_for16<C0 + 1>(f);
+  }
+}
+
 template <int C4N>
 __global__ __launch_bounds__(256) void embed_fwd_rows_kernel(int64_t N, int C, const float* __restrict__ atoms,
                                                              const float* __restrict__ Wemb, float* __restrict__ h0) {
@@ -81,17 +90,18 @@ __global__ __launch_bounds__(256) void embed_fwd_rows_kernel(int64_t N, int C, c
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t i = i0 + u * rows_per_pass;
-      mine[u] = (c4 < C && i < N) ? atoms[i * C + c4] : 0.f;
+      mine[u] = ((c4 & 15) < C && i < N) ? atoms[i * C + (c4 & 15)] : 0.f;      // every 16-lane row of the group holds the C values
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t i = i0 + u * rows_per_pass;
       float4 acc = f4zero();
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const float a = __shfl(mine[u], c, C4N);
+      // lane c of this lane's 16-lane row, by DPP row_share (a VALU move; __shfl is an LDS-crossbar op per class and row)
+      static_for16<0>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine[u]), 0x150 + c, 0xf, 0xf, false));
         acc.x = fmaf(a, w[c].x, acc.x); acc.y = fmaf(a, w[c].y, acc.y); acc.z = fmaf(a, w[c].z, acc.z); acc.w = fmaf(a, w[c].w, acc.w);
-      }
+      });
       if (i < N) *reinterpret_cast<float4*>(h0 + i * F + c4 * 4) = acc;
     }
   }
