@@ -611,7 +611,8 @@ static bool gx_short_ok(int K, int N) { return N % 256 == 0 && K % 128 == 0; }
 bool gemm_h2_fwd_ok(int64_t M, int K, int N) {
   if (sw().gemm_math_fp32) return false;
   const bool tall = M >= 4096, short_op = M >= 256 && gx_short_ok(K, N);
-  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && (tall || short_op) && (int64_t)N * K * 4 < ((int64_t)1 << 31);
+  // (N < 2^20: the pack job carries N in 20 bits of one int — gx_pack_job)
+  return K % GX_BK == 0 && N % GX_BN == 0 && K >= 64 && (tall || short_op) && (int64_t)N * K * 4 < ((int64_t)1 << 31) && N < (1 << 20);
 }
 
 static int gx_launch(ng_ctx* ctx, hipStream_t st, GxArgs& a, const float* W, int trans, bool grad, const char* tag) {
@@ -681,7 +682,7 @@ int gemm_h2_dx(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int ac
 // the plain copy, and gx_launch finds them valid.  No-op when the image cache is off or the product will not take this path.
 int gemm_h2_prepack_mp(ng_ctx* ctx, hipStream_t st, int64_t M, int F, int E, const float* w, const float* Wp, int trans) {
   const int K = trans ? F : E * F, N = trans ? E * F : F;
-  if (!ctx->wcache || !gemm_h2_fwd_ok(M, K, N) || (int64_t)N >= (1 << 20)) return NG_OK;
+  if (!ctx->wcache || !gemm_h2_fwd_ok(M, K, N)) return NG_OK;
   const int nbw = N % 256 == 0 ? 4 : 2;
   bool have = false;
   char* img = (char*)cached_image(ctx, Wp, gx_image_kind(trans, nbw), (size_t)N * K * 4, &have);
