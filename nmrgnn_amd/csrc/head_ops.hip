@@ -10,6 +10,7 @@
 // `a` is read as general floats (the reference feeds one-hot rows but does not require it).
 // Weight-gradient sums are two-stage and deterministic: per-workgroup partials, then reduce_z.
 #include <algorithm>
+#include <cstdlib>
 
 #include "mfma_gemm.cuh"
 #include "ng_internal.h"
@@ -304,7 +305,7 @@ int embed_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int C, int F, const f
                    float* dWemb) {
   const int rl = 256 / (F / 4);
   const int items = C * F;
-  const int grid = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 2);
+  const int grid = (int)std::min<int64_t>(cdiv(N, rl), (int64_t)ctx->num_cu * 4);      // four workgroups per CU (their LDS allows it): 19.6 -> 15 us at F = 64, 55 -> 40 at F = 256; the head backward is fastest at two
   const int64_t rows = cdiv(cdiv(N, grid), rl) * rl;
   const int nb = (int)cdiv(N, rows);
   float* partial = deferred_partials(ctx, (size_t)nb * items);
