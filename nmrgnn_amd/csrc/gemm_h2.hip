@@ -387,7 +387,11 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_fwdr_kernel(GxArgs a) {
 
   // this thread's slice of an X tile: row tid >> 1, 16 floats at column 16 (tid & 1) of the k-step
   const int xr = tid >> 1, xh = tid & 1;
+#ifdef GX_ABL_XL2      // ablation: every workgroup reads the same 1024 rows of X (L2 hits instead of HBM) — results are wrong
+  const int64_t xrow = std::min<int64_t>(m0 + xr, a.M - 1) & 1023;
+#else
   const int64_t xrow = std::min<int64_t>(m0 + xr, a.M - 1);
+#endif
   const float* xp = a.X + xrow * a.K + 16 * xh;
   const float* sp = GRAD && a.Sin ? a.Sin + xrow * a.K + 16 * xh : nullptr;
   const float gS = GRAD && a.gscale ? a.gscale[0] : 1.0f;          // power of two (gemm_grad_scale)
