@@ -435,7 +435,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_fwdr_kernel(GxArgs a) {
   };
   // W^T fragments of the k-half (kt, ks) for this wave's two 32-column blocks
   auto w_request = [&](u32x4 (&wa)[2][2], int i, int ks) {
+#ifdef GX_ABL_WL1      // ablation: every request reads the fragments of k-tile 0 (L1 hits instead of L2) — results are wrong
+    const int ktc = 0;
+    (void)i;
+#else
     const int ktc = kstep(i);
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -485,6 +490,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_fwdr_kernel(GxArgs a) {
     NG_LDS_BARRIER();
   }
 
+#ifdef GX_ABL_NOEPI    // ablation: the products are formed, nothing is written
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][i][r]));
+  return;
+#endif
   // epilogue: lane holds, for row m = m0 + 32 i + l31, columns n = 256 ct + 32 (2 nq + j) + 8 q + 4 half + (0..3)
   float rsv[4];
 #pragma unroll
