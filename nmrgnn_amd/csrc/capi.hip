@@ -34,6 +34,7 @@ static void load_switches() {
   s.knn_brute = env_is("NG_KNN", "brute");
   s.mp_gg_on = env_is("NG_MP_GG", "1");
   s.mp_w16 = !env_is("NG_MP_W16", "0");
+  s.reduce_narrow = env_is("NG_REDUCE", "narrow");
   if (const char* v = getenv("NG_MP_GG_MIN_ROWS")) { const long long r = atoll(v); if (r >= 1) s.mp_gg_min_rows = r; }
   g_sw = s;
   g_sw_loaded = true;
@@ -245,7 +246,7 @@ static int queue_job(ng_ctx* ctx, hipStream_t st, const ReduceJob& j) {
 int reduce_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out, int w_map, int F,
                     int E, int Nout, int64_t z_stride) {
   if (ctx->defer_reduce && in_arena(ctx, partial))
-    return queue_job(ctx, st, ReduceJob{partial, out, n_elem, z_stride ? z_stride : n_elem, nz, w_map, F, E, Nout});
+    return queue_job(ctx, st, ReduceJob{partial, out, n_elem, z_stride ? z_stride : n_elem, nz, w_map, F, E, Nout, sw().reduce_narrow ? 1 : 0});
   launch_reduce_z(st, partial, nz, n_elem, out, w_map, F, E, Nout, z_stride);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
@@ -258,7 +259,7 @@ int reduce_seg_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int n
     // depend on which block holds it: the bits are those of reduce_z_seg_kernel)
     (void)n_elem;
     for (int k = 0; k < sg.n; ++k) {
-      const int rc = queue_job(ctx, st, ReduceJob{partial + sg.begin[k], sg.dst[k], (int64_t)sg.len[k], z_stride, nz, 0, 0, 0, 1});
+      const int rc = queue_job(ctx, st, ReduceJob{partial + sg.begin[k], sg.dst[k], (int64_t)sg.len[k], z_stride, nz, 0, 0, 0, 1, sw().reduce_narrow ? 1 : 0});
       if (rc) return rc;
     }
     return NG_OK;

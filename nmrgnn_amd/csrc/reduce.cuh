@@ -38,6 +38,7 @@ struct ReduceJob {
   float* out;                    // plain / mapped form (sg == nullptr)
   int64_t n_elem, z_stride;
   int nz, w_map, F, E, Nout;
+  int narrow;                    // NG_REDUCE=narrow: 64 elements per block whatever the size (tests compare the two forms' bits)
 };
 
 // Jobs of 32 K elements and more (the weight gradients of the default width: 196,608 elements x ~40 partials) run 256
@@ -45,7 +46,7 @@ struct ReduceJob {
 // requests for the same bytes (reduce_batch_kernel 150 -> ~80 us per F = 256 step).  Per element the order of the sum — wave w
 // adds z = w, w + 16, ..., then the sixteen waves' sums in wave order — is that of the narrow form: the same bits.
 __host__ __device__ inline bool reduce_job_wide(const ReduceJob& j) {
-  return j.n_elem >= 32768 && (j.n_elem & 3) == 0 && (j.z_stride & 3) == 0 && ((uintptr_t)j.partial & 15) == 0;
+  return !j.narrow && j.n_elem >= 32768 && (j.n_elem & 3) == 0 && (j.z_stride & 3) == 0 && ((uintptr_t)j.partial & 15) == 0;
 }
 __host__ __device__ inline unsigned reduce_job_blocks(const ReduceJob& j) {
   const int64_t per = reduce_job_wide(j) ? 256 : 64;
@@ -137,23 +138,23 @@ __device__ __forceinline__ void reduce_job_block(const ReduceJob& j, const Reduc
 static __global__ __launch_bounds__(1024) void reduce_z_kernel(const float* __restrict__ partial, int nz,
                                                         int64_t n_elem, float* __restrict__ out,
                                                         int w_map, int F, int E, int Nout,
-                                                        int64_t z_stride) {
+                                                        int64_t z_stride, int narrow) {
   __shared__ __attribute__((aligned(16))) float red[16 * 4][64];      // [16][64] floats, or float4 (wide jobs)
-  const ReduceJob j{partial, out, n_elem, z_stride, nz, w_map, F, E, Nout};
+  const ReduceJob j{partial, out, n_elem, z_stride, nz, w_map, F, E, Nout, narrow};
   reduce_job_block(j, nullptr, blockIdx.x, red);
 }
 
 static inline void launch_reduce_z(hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out,
                             int w_map = 0, int F = 0, int E = 0, int Nout = 1, int64_t z_stride = 0) {
-  const ReduceJob j{partial, out, n_elem, z_stride ? z_stride : n_elem, nz, w_map, F, E, Nout};
+  const ReduceJob j{partial, out, n_elem, z_stride ? z_stride : n_elem, nz, w_map, F, E, Nout, sw().reduce_narrow ? 1 : 0};
   hipLaunchKernelGGL(reduce_z_kernel, dim3(reduce_job_blocks(j)), dim3(1024), 0, st, partial,
-                     nz, n_elem, out, w_map, F, E, Nout, j.z_stride);
+                     nz, n_elem, out, w_map, F, E, Nout, j.z_stride, j.narrow);
 }
 
 static __global__ __launch_bounds__(1024) void reduce_z_seg_kernel(const float* __restrict__ partial, int nz,
                                                                    int64_t n_elem, int64_t z_stride, ReduceSegs sg) {
   __shared__ float red[16][64];
-  const ReduceJob j{partial, nullptr, n_elem, z_stride, nz, 0, 0, 0, 1};
+  const ReduceJob j{partial, nullptr, n_elem, z_stride, nz, 0, 0, 0, 1, 1};
   reduce_job_block(j, &sg, blockIdx.x, red);
 }
 

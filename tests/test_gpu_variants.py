@@ -124,3 +124,29 @@ def test_switch_flipped_between_forward_and_backward(gpu_device, monkeypatch, fw
     var = eng.params.grads_dict()
     for k in base:
         assert rel_err(var[k], base[k]) < 2e-4, k
+
+
+@pytest.mark.parametrize("deferred", [True, False])
+def test_wide_second_stage_reduction_gives_the_narrow_form_s_bits(gpu_device, monkeypatch, deferred):
+    """reduce.cuh: jobs of 32 K elements and more run 256 elements per block, four per lane; per element the order of the sum is
+    that of the 64-element form (NG_REDUCE=narrow), so every weight gradient of a default-width backward — 196,608-element MPLayer
+    sums, 65,536-element dense ones, the small ones that stay narrow — must come out bit for bit, queued or eager."""
+    import torch
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    hp = make_hp(atom_feature_size=256, edge_feature_size=3, edge_hidden_size=128)
+    b = small_batch(40, 120, seed=4)         # 4800 atoms: the generic GEMM path with split-K partials
+    eng = Engine(hp, 10, device=gpu_device, seed=3)
+    eng.defer_reductions = deferred
+    randomize_biases(eng)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=5)
+    mask = eng.dropout_mask(N * 128, seed=6)
+    dpe = torch.from_numpy(np.random.default_rng(1).standard_normal(N).astype(np.float32)).to(gpu_device)
+    wide = _run(gpu_device, eng, gb, xi, mask, dpe)
+    monkeypatch.setenv("NG_REDUCE", "narrow")
+    narrow = _run(gpu_device, eng, gb, xi, mask, dpe)
+    assert np.array_equal(wide[0], narrow[0])
+    for k in wide[2]:
+        assert np.array_equal(wide[2][k], narrow[2][k]), k
