@@ -104,6 +104,52 @@ def test_batch_invariance(gpu_device):
         np.testing.assert_allclose(part, full[sl], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("F,graphs,atoms", [(64, 48, 256), (256, 12, 200)])
+def test_relabelling_the_atoms_of_a_graph_permutes_the_peaks(gpu_device, F, graphs, atoms):
+    """A property of the model that needs no oracle and holds at any size: the model sees atoms only through their lists, so
+    relabelling the atoms of every graph (rows permuted, neighbour indices renamed, slot order kept) must permute the peaks.  Per
+    atom every sum runs over the atom's own slots and features in an order that does not depend on where the atom sits in the batch
+    (tiles, windows, workgroups), so the inference peaks must agree BIT FOR BIT; the weight gradients are sums over atoms in another
+    order and agree to rounding."""
+    import torch
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    b = synth.make_batch(graphs, atoms, 16, 10, 0.08, seed=F + graphs)
+    N = graphs * atoms
+    rng = np.random.default_rng(7)
+    new_of_old = np.concatenate([g * atoms + rng.permutation(atoms) for g in range(graphs)])      # old row -> new row
+    old_of_new = np.empty(N, np.int64)
+    old_of_new[new_of_old] = np.arange(N)
+    nl_new = new_of_old[b["nlist"][old_of_new]]
+    # padded slots point at LOCAL atom 0 of their graph in the reference's convention (index 0 + offset): keep that form
+    pad = b["edges"][old_of_new] == 0
+    nl_new[pad] = (np.arange(N)[:, None] // atoms * atoms + 0 * nl_new)[pad]
+    bp = dict(atoms=b["atoms"][old_of_new], nlist=nl_new.astype(np.int32), edges=b["edges"][old_of_new],
+              inv_degree=b["inv_degree"][old_of_new])
+    eng = Engine(make_hp(atom_feature_size=F), 10, device=gpu_device, seed=5)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    gp = GraphBatch(bp["atoms"], bp["nlist"], bp["edges"], bp["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    peaks, peaks_p = eng.forward(gb).cpu().numpy(), eng.forward(gp).cpu().numpy()
+    np.testing.assert_array_equal(peaks_p[new_of_old], peaks)
+    # training pass with the draws handed in (noise per slot, dropout per atom), permuted alike
+    xi = eng.randn(N * 16, seed=3).reshape(N, 16)
+    Fh = F // 2
+    mask = eng.dropout_mask(N * Fh, seed=4).reshape(N, Fh)
+    dpe = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(gpu_device)
+    idx = torch.from_numpy(old_of_new).to(gpu_device)
+    pk = eng.forward(gb, training=True, noise=xi.reshape(-1), dropout_mask=mask.reshape(-1)).clone()
+    eng.backward(dpe)
+    g0 = eng.params.grads_dict()
+    pkp = eng.forward(gp, training=True, noise=xi[idx].reshape(-1).contiguous(), dropout_mask=mask[idx].reshape(-1).contiguous()).clone()
+    eng.backward(dpe[idx].contiguous())
+    g1 = eng.params.grads_dict()
+    np.testing.assert_array_equal(pkp.cpu().numpy()[new_of_old], pk.cpu().numpy())
+    for k in g0:
+        scale = max(np.abs(g0[k]).max(), 1e-30)
+        assert np.abs(g1[k] - g0[k]).max() <= 2e-5 * scale, k
+
+
 def test_padded_slot_index_is_irrelevant(gpu_device):
     """KAT-3: changing nlist in a padded (edges == 0) slot must not change any peak."""
     from nmrgnn_amd.graph import GraphBatch
