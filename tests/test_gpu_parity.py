@@ -150,6 +150,33 @@ def test_relabelling_the_atoms_of_a_graph_permutes_the_peaks(gpu_device, F, grap
         assert np.abs(g1[k] - g0[k]).max() <= 2e-5 * scale, k
 
 
+@pytest.mark.parametrize("F", [64, 256])
+@pytest.mark.parametrize("k", [-9, 6])
+def test_backward_is_homogeneous_in_powers_of_two(gpu_device, F, k):
+    """The backward is linear in the upstream gradient, and every scale the fp16-piece kernels choose for their gradient operands
+    is a power of two taken from a maximum (edge backward: per call; FC block and window kernels: per row; generic GEMMs: per
+    call), so multiplying dpeaks by 2^k must multiply every weight gradient by exactly 2^k — the pieces, products and sums are
+    the same bits with another exponent."""
+    import torch
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    b = small_batch(6, 150, seed=9)
+    eng = Engine(make_hp(atom_feature_size=F), 10, device=gpu_device, seed=2)
+    randomize_biases(eng)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    N, K = b["edges"].shape
+    xi = eng.randn(N * K, seed=5)
+    mask = eng.dropout_mask(N * (F // 2), seed=6)
+    dpe = torch.from_numpy(np.random.default_rng(1).standard_normal(N).astype(np.float32)).to(gpu_device)
+    out = []
+    for scale in (1.0, 2.0 ** k):
+        eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
+        eng.backward(dpe * scale)
+        out.append(eng.params.grads_dict())
+    for name in out[0]:
+        np.testing.assert_array_equal(out[1][name], out[0][name] * np.float32(2.0 ** k), err_msg=name)
+
+
 def test_padded_slot_index_is_irrelevant(gpu_device):
     """KAT-3: changing nlist in a padded (edges == 0) slot must not change any peak."""
     from nmrgnn_amd.graph import GraphBatch
