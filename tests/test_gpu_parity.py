@@ -104,7 +104,7 @@ def test_batch_invariance(gpu_device):
         np.testing.assert_allclose(part, full[sl], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("F,graphs,atoms", [(64, 48, 256), (256, 12, 200)])
+@pytest.mark.parametrize("F,graphs,atoms", [(64, 48, 256), (256, 12, 200), (64, 512, 256)])      # the last: BASELINE configs[2] at full size
 def test_relabelling_the_atoms_of_a_graph_permutes_the_peaks(gpu_device, F, graphs, atoms):
     """A property of the model that needs no oracle and holds at any size: the model sees atoms only through their lists, so
     relabelling the atoms of every graph (rows permuted, neighbour indices renamed, slot order kept) must permute the peaks.  Per
