@@ -43,7 +43,9 @@ def _graph_ptr_dev(host, device):
     a one-graph training step — so the copies are kept (at most 64 of at most 4096 entries)."""
     if host.size > 4096 or device.type != "cuda":
         return torch.as_tensor(host, device=device)
-    key = (device.index, host.tobytes())
+    # keyed by the allocating stream as well: a copy made under the prefetcher's side stream is never handed to a batch
+    # built on another stream (the caching allocator recycles a block on the stream that allocated it)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, host.tobytes())
     t = _GRAPH_PTR_CACHE.get(key)
     if t is None:
         if len(_GRAPH_PTR_CACHE) >= 64:
@@ -321,9 +323,12 @@ class BatchPrefetcher:
         consumer = torch.cuda.current_stream(self.device)
         consumer.wait_event(ready)
         # the tensors were allocated under the side stream: tell the caching allocator who uses them from here on
-        held = [gb.atoms, gb.nlist, gb.edges, gb.inv_degree, gb.nlist_c, *(gb._csc or ()), *(gb._live or ())]
+        # (graph_ptr included: the loss kernels read it on the consumer's stream, and a cached or evicted copy that was
+        # allocated under the side stream could otherwise be handed back to the side stream while a step is still queued)
+        held = [gb.atoms, gb.nlist, gb.edges, gb.inv_degree, gb.nlist_c, gb.graph_ptr, gb.row_ptr,
+                getattr(gb, "row_of", None), *(gb._csc or ()), *(gb._live or ())]
         for t in held:
-            if t.is_cuda:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(consumer)
         gb._ctx = None          # nothing lazy is left to build; later calls on this batch use the shared context
         return gb
