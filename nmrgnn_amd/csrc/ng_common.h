@@ -105,6 +105,7 @@ namespace ng {
 //   NG_EDGE_MATH=fp32      edge MLP forward+backward on f32-input MFMA (default: two-piece fp16 split operands)
 //   NG_EDGE_BWD_MATH=fp32  only the edge backward on f32-input MFMA
 //   NG_GEMM_MATH=fp32      generic GEMMs on f32-input MFMA (default: split operands where the shape allows)
+//   NG_EDGE_BWD=rs         split-operand edge backward with sixteen role-split waves (edge_bwd_rs.hip; default: eight waves, edge_bwd_h2.hip)
 //   NG_EDGE_PATH=layered   one launch per edge-MLP layer (any H / Le)
 //   NG_MP_PATH=layered     aggregate -> A[N,E*F] -> GEMM for every width (default: window kernels at F == 64)
 //   NG_FC_PATH=layered     one launch per FC layer
@@ -122,6 +123,7 @@ struct Switches {
   bool mp_w16 = true;                // NG_MP_W16=0: the eight-wave forward window kernel instead of the 16-wave one (mp_win16.hip)
   bool reduce_narrow = false;        // NG_REDUCE=narrow: second-stage reductions 64 elements per block at every size (reduce.cuh)
   bool knn_lanes = false;            // NG_KNN=lanes
+  bool edge_bwd_rs = false;          // NG_EDGE_BWD=rs: the role-split sixteen-wave split-operand edge backward (edge_bwd_rs.hip; measured, not faster) instead of the eight-wave one (edge_bwd_h2.hip)
   int64_t mp_gg_min_rows = 8192;     // NG_MP_GG_MIN_ROWS
 };
 const Switches& sw();
