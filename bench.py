@@ -49,6 +49,9 @@ PEAK_MFMA_F16_TFLOPS = 2516.6   # dense fp16 (= bf16): 256 CU x 4 SIMD x 1024 fl
 H2_KERNELS = {"edge_fwd_h2", "edge_bwd_h2"}
 # window kernels whose matrix phase runs on the fp16 pipe unless NG_GEMM_MATH=fp32 (mp_win.hip)
 H2_WINDOW_KERNELS = {"mp_win_fwd", "mp_win_bwd_edge", "mp_win_bwd_node"}
+# the fused FC block at F = 64 (fc_fused.hip: fc_h2_on()) runs on fp16 pieces as well unless NG_GEMM_MATH=fp32 — priced against
+# the pipe it uses (round-4 verdict: it was priced at the f32-input peak, 0.45 instead of 0.085)
+H2_FC_KERNELS = {"fc_fused_fwd", "fc_fused_bwd"}
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 achievable
 
 ARCH = dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
@@ -264,7 +267,7 @@ def pmc_lookup(kernel):
     """(traffic bytes per launch, matrix-pipe busy share, note) from the rocprofv3 PMC passes committed under
     profiles/ (tools/pmc_traffic.sh, tools/pmc_mfma.sh).  The files carry the digest of the kernel sources they were
     collected on; a number whose kernel has changed since is NOT printed."""
-    traffic = busy = None
+    traffic = busy = coexec = None
     notes = []
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -288,12 +291,15 @@ def pmc_lookup(kernel):
             for kname, v in pm.items():
                 if kname != "_meta" and kernel + "_kernel" in kname and v.get("GRBM_GUI_ACTIVE", 0) > 0:
                     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+                    # share of the matrix pipe's busy cycles during which the SIMD's VALU also executed
+                    if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and "SQ_VALU_MFMA_COEXEC_CYCLES" in v:
+                        coexec = v["SQ_VALU_MFMA_COEXEC_CYCLES"] / v["SQ_VALU_MFMA_BUSY_CYCLES"]
                     notes.append(f"mfma_pipe_busy: profiles/pmc_mfma.json @ {meta.get('commit', '?')}")
         elif kernel in meta.get("source_digest", {}):
             notes.append("mfma_pipe_busy: committed PMC pass predates the current kernel source (stale, not shown)")
     except Exception:
         pass
-    return traffic, busy, "; ".join(notes) or None
+    return traffic, busy, coexec, "; ".join(notes) or None
 
 
 def roofline_rows(prof, psteps, work, h2_gemm):
@@ -304,7 +310,7 @@ def roofline_rows(prof, psteps, work, h2_gemm):
         if name in work and avg_ms > 0:
             _, fl, by = work[name]
             on_h2 = name in H2_KERNELS or (h2_gemm and name in H2_GEMM_TAGS) or (
-                name in H2_WINDOW_KERNELS and os.environ.get("NG_GEMM_MATH", "") != "fp32")
+                name in (H2_WINDOW_KERNELS | H2_FC_KERNELS) and os.environ.get("NG_GEMM_MATH", "") != "fp32")
             peak_tf = PEAK_MFMA_F16_TFLOPS / 3.0 if on_h2 else PEAK_MFMA_F32_TFLOPS
             # both rooflines, the binding one is reported: floor = max(flops at the matrix peak, bytes at the HBM peak)
             t_mfma = fl / (peak_tf * 1e12) * 1e3 if fl > 0 else 0.0
@@ -514,10 +520,12 @@ def main():
                                   "fresh_batch_every_step for the step that includes it"},
         "loss": final_loss,
         "matrix_math": ("f32-input MFMA everywhere" if os.environ.get("NG_EDGE_MATH", "") == "fp32" else
-                        "edge MLP forward and backward: fp16 MFMA on fp32 operands split into 2 fp16 pieces (22-24 "
-                        "significand bits), 3 piece products per multiply, fp32 accumulate; error against float64 at or "
-                        "below the f32-input MFMA kernels' (tests/test_gpu_edge_h2.py); all other contractions: "
-                        "f32-input MFMA"),
+                        "fp16 MFMA on fp32 operands split into 2 fp16 pieces (22-24 significand bits), 3 piece products per "
+                        "multiply, fp32 accumulate: edge MLP forward and backward, the matrix phases of the F = 64 window "
+                        "kernels (mp_win*), the fused FC block (fc_fused_fwd / _bwd, fp32 repair in-kernel) and the generic "
+                        "split-operand GEMMs (gemm_h2) unless NG_GEMM_MATH=fp32; head, embedding, loss, Adam: fp32 VALU; "
+                        "range fall-backs: f32-input MFMA.  Error against float64 at or below the f32-input MFMA kernels' "
+                        "(tests/test_gpu_edge_h2.py, test_gpu_fc_block.py, test_gpu_mp_w16.py)"),
     }
 
     # ---- the reference sees a NEW graph tuple every step (nmrgnn/library.py:88-89): the same step with the batch
@@ -589,11 +597,11 @@ def main():
             out["roofline_all"] = rows
             dom = next((r for r in rows if "bound" in r), None)
             if dom is not None:
-                traffic, mfma_busy, note = pmc_lookup(dom["kernel"])
+                traffic, mfma_busy, mfma_coexec, note = pmc_lookup(dom["kernel"])
                 alg = work[dom["kernel"]]
                 out["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                                    "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic,
-                                   "mfma_pipe_busy": mfma_busy, "pmc_note": note, "algorithmic_bytes": alg[2],
+                                   "mfma_pipe_busy": mfma_busy, "mfma_coexec_frac": mfma_coexec, "pmc_note": note, "algorithmic_bytes": alg[2],
                                    "algorithmic_flops": alg[1], "avg_launch_ms": dom["avg_ms"],
                                    "edges_priced": n_live if n_live is not None else gb.n_edges,
                                    "edge_slots": gb.n_edges}
