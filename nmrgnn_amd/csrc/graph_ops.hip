@@ -109,36 +109,86 @@ __global__ __launch_bounds__(GL_BLOCK) void gl_fill_kernel(int64_t n_entries, in
   tmp[pos] = (int32_t)eid;
 }
 
-// one thread per target: its segment of tmp in ascending entry id -> csc_edge (rank sort; segments are in-degree long)
+// Per target: its segment of tmp in ascending entry id -> csc_edge.  Round 5: a 16-LANE GROUP per target instead of one thread
+// (round 4: registers for segments up to 32, an O(d^2) loop over memory in one thread beyond — 188 us average, 827 us at worst per
+// call in the bench trace, where a handful of the 131,072 random targets have more than 32 incoming edges, and milliseconds for a
+// solvated ion or a coarse cutoff).  A group ranks its segment sixteen entries at a time against sixteen entries passed round the
+// group (ds_bpermute): (len / 16)^2 x 16 exchanges.  Segments longer than GL_SORT_GROUP_MAX are left to the whole workgroup after a
+// barrier: bitonic sort in LDS up to GL_SORT_LDS entries, rank sort from LDS chunks beyond.  Same output order as before (entry
+// ids are distinct, so the order is total): lists bit-identical.
+constexpr int GL_SORT_GROUP_MAX = 64, GL_SORT_LDS = 4096, GL_GROUPS = GL_BLOCK / 16;
 __global__ __launch_bounds__(GL_BLOCK) void gl_sort_kernel(int64_t n, const int32_t* __restrict__ cursor, int32_t* __restrict__ csc_ptr,
                                                            const int32_t* __restrict__ tmp, int32_t* __restrict__ csc_edge) {
-  const int64_t t = (int64_t)blockIdx.x * GL_BLOCK + threadIdx.x;
-  if (t >= n) return;
-  const int p0 = csc_ptr[t], p1 = cursor[t];      // after the fill a cursor stands at the end of its segment
-  if (t == n - 1) csc_ptr[n] = p1;
-  // short segments (in-degree ~ K): all entries requested at once, ranked in registers — as a loop over memory the
-  // len^2 dependent reads of a single graph's 256 targets took 40 us of a 0.37-ms training step (profiles/r04d)
-  constexpr int GL_SORT_REG = 32;
-  const int len = p1 - p0;
-  if (len <= GL_SORT_REG) {
-    int32_t v[GL_SORT_REG];
+  __shared__ int32_t s_key[GL_SORT_LDS];
+  __shared__ int s_long[GL_GROUPS];
+  __shared__ int s_nlong;
+  const int g = threadIdx.x >> 4, gl = threadIdx.x & 15;
+  const int64_t t = (int64_t)blockIdx.x * GL_GROUPS + g;
+  if (threadIdx.x == 0) s_nlong = 0;
+  __syncthreads();
+  if (t < n) {
+    const int p0 = csc_ptr[t], p1 = cursor[t];      // after the fill a cursor stands at the end of its segment
+    const int len = p1 - p0;
+    if (len <= GL_SORT_GROUP_MAX) {
+      for (int a = 0; a < len; a += 16) {
+        const int32_t v = a + gl < len ? tmp[p0 + a + gl] : 0x7fffffff;
+        int rank = 0;
+        for (int b = 0; b < len; b += 16) {
+          const int32_t u = b + gl < len ? tmp[p0 + b + gl] : 0x7fffffff;
 #pragma unroll
-    for (int a = 0; a < GL_SORT_REG; ++a) v[a] = a < len ? tmp[p0 + a] : 0x7fffffff;
-#pragma unroll
-    for (int a = 0; a < GL_SORT_REG; ++a) {
-      int rank = 0;
-#pragma unroll
-      for (int b = 0; b < GL_SORT_REG; ++b) rank += v[b] < v[a] ? 1 : 0;     // entry ids are distinct; the padding ranks last
-      if (a < len) csc_edge[p0 + rank] = v[a];
+          for (int r = 0; r < 16; ++r) rank += __shfl(u, r, 16) < v ? 1 : 0;     // entry ids are distinct; the padding ranks last
+        }
+        if (a + gl < len) csc_edge[p0 + rank] = v;
+      }
+    } else if (gl == 0) {
+      s_long[atomicAdd(&s_nlong, 1)] = g;
     }
-    return;
   }
-  for (int a = p0; a < p1; ++a) {
-    const int32_t v = tmp[a];
-    int rank = 0;
-    for (int b = p0; b < p1; ++b) rank += tmp[b] < v ? 1 : 0;     // entry ids are distinct
-    csc_edge[p0 + rank] = v;
+  __syncthreads();
+  // (csc_ptr[n] is written at the very end: the last block's groups read csc_ptr[t] for t < n only)
+  const int nlong = s_nlong;
+  for (int i = 0; i < nlong; ++i) {
+    const int64_t tl = (int64_t)blockIdx.x * GL_GROUPS + s_long[i];
+    const int p0 = csc_ptr[tl], len = cursor[tl] - p0;
+    if (len <= GL_SORT_LDS) {
+      int m = 64;
+      while (m < len) m <<= 1;
+      for (int j = threadIdx.x; j < m; j += GL_BLOCK) s_key[j] = j < len ? tmp[p0 + j] : 0x7fffffff;
+      __syncthreads();
+      for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          // one compare-exchange per PAIR (pair q: lower element x = 2 j (q / j) + q % j, partner x + j), four pairs in flight
+          // per thread: as a loop over elements with a dependent read -> write per iteration a step took 1.7 us
+#pragma unroll 4
+          for (int q = threadIdx.x; q < (m >> 1); q += GL_BLOCK) {
+            const int x = ((q & ~(j - 1)) << 1) | (q & (j - 1)), y = x + j;
+            const int32_t kx = s_key[x], ky = s_key[y];
+            const bool up = (x & k) == 0;
+            if ((kx > ky) == up) { s_key[x] = ky; s_key[y] = kx; }
+          }
+          __syncthreads();
+        }
+      for (int j = threadIdx.x; j < len; j += GL_BLOCK) csc_edge[p0 + j] = s_key[j];
+      __syncthreads();
+    } else {
+      // beyond the LDS: every thread ranks its entries against the segment, staged through LDS in chunks (O(len^2 / 256) per thread)
+      for (int a0 = 0; a0 < len; a0 += GL_BLOCK) {
+        const int a = a0 + threadIdx.x;
+        const int32_t v = a < len ? tmp[p0 + a] : 0x7fffffff;
+        int rank = 0;
+        for (int b0 = 0; b0 < len; b0 += GL_SORT_LDS) {
+          const int cl = min(GL_SORT_LDS, len - b0);
+          __syncthreads();
+          for (int j = threadIdx.x; j < cl; j += GL_BLOCK) s_key[j] = tmp[p0 + b0 + j];
+          __syncthreads();
+          for (int j = 0; j < cl; ++j) rank += s_key[j] < v ? 1 : 0;
+        }
+        if (a < len) csc_edge[p0 + rank] = v;
+      }
+      __syncthreads();
+    }
   }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) csc_ptr[n] = cursor[n - 1];
 }
 
 // offsets of a scan over n + 1 elements applied in place; element n (a zero before the scan) ends up as the total
@@ -427,7 +477,7 @@ extern "C" int ng_build_incoming_lists(ng_ctx* ctx, void* stream, int64_t N, int
   if (n_entries > 0)
     hipLaunchKernelGGL(gl_fill_kernel, dim3((unsigned)cdiv(n_entries, GL_BLOCK)), dim3(GL_BLOCK), 0, st, n_entries, N, nlist, edges,
                        cursor, tmp);
-  hipLaunchKernelGGL(gl_sort_kernel, dim3((unsigned)cdiv(N, GL_BLOCK)), dim3(GL_BLOCK), 0, st, N, cursor, csc_ptr, tmp, csc_edge);
+  hipLaunchKernelGGL(gl_sort_kernel, dim3((unsigned)cdiv(N, GL_GROUPS)), dim3(GL_BLOCK), 0, st, N, cursor, csc_ptr, tmp, csc_edge);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

@@ -65,3 +65,34 @@ def test_scratch_size_and_refusals(gpu_device):
     assert ctx.lib.ng_incoming_lists_scratch_bytes(1000, 16000) >= (2 * 1000 + 16000) * 4
     rc = ctx.lib.ng_build_incoming_lists(ctx.handle, None, 10, 4, 39, None, None, None, None, None)
     assert rc != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hub", [40, 64, 65, 700, 4096, 4097, 9000])
+def test_incoming_lists_long_segments(gpu_device, hub):
+    """segments at and across the thresholds of gl_sort_kernel (16-lane groups up to 64 entries, LDS bitonic sort up to 4096,
+    chunked rank sort beyond): lists bit-identical to the host's, and the same from run to run"""
+    from nmrgnn_amd.graph import GraphBatch
+    rng = np.random.default_rng(hub)
+    N = max(2 * hub, 600)
+    deg = rng.integers(0, 5, N)
+    row_ptr = np.zeros(N + 1, np.int64)
+    row_ptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, N, row_ptr[-1]).astype(np.int32)
+    # exactly `hub` entries point at atom 3 and hub - 1 at atom N - 1 (the last target: its segment end is the list total)
+    idx = rng.permutation(col.shape[0])
+    col[col == 3] = 5
+    col[col == N - 1] = 6
+    col[idx[:hub]] = 3
+    col[idx[hub:2 * hub - 1]] = N - 1
+    dist = rng.uniform(0.1, 0.4, col.shape[0]).astype(np.float32)
+    atoms = np.zeros((N, 10), np.float32)
+    atoms[:, 2] = 1
+    gb = GraphBatch.from_csr(atoms, row_ptr.astype(np.int32), col, dist, device=gpu_device)
+    ptr, eid = gb.csc()
+    hp, he = _host_lists(col, None, N)
+    assert hp[4] - hp[3] == hub and hp[N] - hp[N - 1] == hub - 1
+    np.testing.assert_array_equal(ptr.cpu().numpy(), hp)
+    np.testing.assert_array_equal(eid.cpu().numpy()[:len(he)], he)
+    gb2 = GraphBatch.from_csr(atoms, row_ptr.astype(np.int32), col, dist, device=gpu_device)
+    assert torch.equal(gb2.csc()[1][:len(he)], eid[:len(he)])
