@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 6
+#define NG_ABI_VERSION 7
 
 enum {
   NG_OK = 0,
@@ -76,6 +76,26 @@ int ng_flush_reductions(ng_ctx* ctx, void* stream);
 int ng_ctx_set_graph_span(ng_ctx* ctx, int64_t max_graph_atoms);
 /* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
 int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
+
+/* ---- graph replay of small calls (ABI 7) -----------------------------------------------------------------------------
+ * The reference trains on ONE graph per step (nmrgnn/library.py:88-89, nmrgnn/main.py:74-80) and predicts one structure per
+ * call (main.py:236-245): ~33 / ~8 launches of a few microseconds each, bound by the host's launch rate.  Every entry point of
+ * this library is asynchronous on the stream it is given and allocates nothing once its scratch is sized (a warm-up call, or
+ * ng_ctx_reserve), so a chain of calls can be CAPTURED on that stream (hipStreamBeginCapture, torch.cuda.CUDAGraph) and
+ * replayed as one graph launch per shape.  Three launch arguments of a training step change from step to step and would be
+ * frozen into the captured nodes: the seed of ng_add_noise(_live) and ng_head_fwd_dropout, and ng_adam_step's bias-corrected
+ * rate.  While a context is ARMED those launches ignore these arguments and read the values ng_replay_stage last wrote to
+ * a device block of the context:
+ *   ng_replay_arm    on: arm before capturing (and leave armed while replaying: the captured nodes hold the block's address);
+ *                    off: eager calls take their arguments again.
+ *   ng_replay_stage  ONE eager launch per replayed step, before the graph launch: stores `seed` and Adam's rate for `step`
+ *                    (the expression of ng_adam_step: same bits), clears the operand-range guard word, and copies up to 8
+ *                    buffers (whole 32-bit words, device to device) — the step's inputs into the static buffers the captured
+ *                    chain reads.  Inference replays need it only for the copies (seed / step are then ignored: pass step 1).
+ * nmrgnn_amd/replay.py holds the Python side (TrainStepReplay, ForwardReplay). */
+int ng_replay_arm(ng_ctx* ctx, int on);
+int ng_replay_stage(ng_ctx* ctx, void* stream, uint64_t seed, float lr, float beta1, float beta2, int64_t step, int n_copies,
+                    const void* const* src, void* const* dst, const uint64_t* bytes);
 
 /* per-kernel hipEvent bracketing for bench.py's roofline leg */
 int ng_prof_enable(ng_ctx* ctx, int on);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "ng_ctx_destroy": (None, [_vp]),
     "ng_last_error": (C.c_char_p, [_vp]),
     "ng_ctx_reserve": (_int, [_vp, _u64]),
+    "ng_replay_arm": (_int, [_vp, _int]),
+    "ng_replay_stage": (_int, [_vp, _vp, _u64, _f, _f, _f, _i64, _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64)]),
     "ng_reload_env": (_int, []),
     "ng_weights_frozen": (_int, [_vp, _int]),
     "ng_weights_changed": (_int, [_vp]),
@@ -132,7 +134,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 6:
+        if lib.ng_abi_version() != 7:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

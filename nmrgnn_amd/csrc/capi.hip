@@ -1,4 +1,5 @@
 // Context, error reporting, scratch workspace and per-kernel hipEvent profiling.
+#include <cmath>
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -54,6 +55,12 @@ RangeGuard range_guard_begin(ng_ctx* ctx) {
   if (++ctx->range_epoch == 0) ++ctx->range_epoch;
   g.epoch = ctx->range_epoch;
   return g;
+}
+
+const uint64_t* replay_state(ng_ctx* ctx) {
+  if (!ctx->replay_armed) return nullptr;
+  char* s = (char*)small_scratch(ctx);
+  return s ? reinterpret_cast<const uint64_t*>(s + NG_REPLAY_STATE_OFFSET) : nullptr;
 }
 
 void* workspace(ng_ctx* ctx, size_t bytes) {
@@ -331,6 +338,65 @@ extern "C" int ng_flush_reductions(ng_ctx* ctx, void* stream) {
   return ng::flush_reductions(ctx, (hipStream_t)stream);
 }
 
+// ---- graph replay of small training steps (round 5) --------------------------------------------------------------------
+// One 256-atom graph per step is ~33 launches of a few microseconds: the step is bound by the host's launch rate.  The chain
+// can be captured once per shape (torch.cuda.CUDAGraph on the stream the caller passes, or hipStreamBeginCapture) and replayed
+// — if (a) nothing inside allocates or synchronises (scratch is sized by a warm-up step, ng_ctx_reserve) and (b) no kernel
+// argument changes from step to step.  Three do: the seed of GaussianNoise and Dropout and Adam's bias-corrected rate.  While
+// a context is armed those launches read them from a device block that ONE eager launch per step (ng_replay_stage) fills —
+// together with the step's inputs, copied into the static buffers the captured chain reads, and the range-guard word reset.
+struct StageArgs {
+  const uint32_t* src[8];
+  uint32_t* dst[8];
+  uint32_t words[8];
+  int n;
+  uint64_t seed;
+  float lr_t;
+  uint64_t* state;
+  unsigned* guard_word;
+};
+__global__ __launch_bounds__(256) void replay_stage_kernel(StageArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.state[0] = a.seed;
+    reinterpret_cast<float*>(a.state)[2] = a.lr_t;
+    *a.guard_word = 0;
+  }
+  for (int c = 0; c < a.n; ++c)
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.words[c]; i += gridDim.x * 256) a.dst[c][i] = a.src[c][i];
+}
+
+extern "C" int ng_replay_arm(ng_ctx* ctx, int on) {
+  if (!ctx) return NG_ERR_INVALID;
+  if (on && !ng::small_scratch(ctx)) return NG_ERR_NOMEM;
+  ctx->replay_armed = on != 0;
+  return NG_OK;
+}
+
+extern "C" int ng_replay_stage(ng_ctx* ctx, void* stream, uint64_t seed, float lr, float beta1, float beta2, int64_t step,
+                               int n_copies, const void* const* src, void* const* dst, const uint64_t* bytes) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, n_copies >= 0 && n_copies <= 8, "replay_stage: at most 8 copies");
+  NG_REQUIRE(ctx, step >= 1, "replay_stage: step counts from 1");
+  char* sm = (char*)ng::small_scratch(ctx);
+  if (!sm) return NG_ERR_NOMEM;
+  StageArgs a{};
+  uint64_t most = 0;
+  for (int c = 0; c < n_copies; ++c) {
+    NG_REQUIRE(ctx, src[c] && dst[c] && bytes[c] % 4 == 0 && bytes[c] < ((uint64_t)1 << 32), "replay_stage: copies of whole 32-bit words");
+    a.src[c] = (const uint32_t*)src[c]; a.dst[c] = (uint32_t*)dst[c]; a.words[c] = (uint32_t)(bytes[c] / 4);
+    most = std::max<uint64_t>(most, bytes[c] / 4);
+  }
+  a.n = n_copies; a.seed = seed;
+  // the expression of ng_adam_step: the same bits reach the kernel
+  a.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) / (1.0 - std::pow((double)beta1, (double)step)));
+  a.state = reinterpret_cast<uint64_t*>(sm + ng::NG_REPLAY_STATE_OFFSET);
+  a.guard_word = reinterpret_cast<unsigned*>(sm + ng::NG_SMALL_BYTES - 64);
+  const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, (most + 255) / 256));
+  hipLaunchKernelGGL(replay_stage_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 extern "C" int ng_reload_env(void) {
   ng::load_switches();
   return NG_OK;
@@ -364,6 +430,7 @@ extern "C" void ng_ctx_destroy(ng_ctx* ctx) {
   for (auto& kv : ctx->wimg)
     if (kv.second.buf) (void)hipFree(kv.second.buf);
   if (ctx->wjobs_dev) (void)hipFree(ctx->wjobs_dev);
+  for (auto& kv : ctx->wjobs_private) (void)hipFree(kv.second);
   for (auto& r : ctx->recs) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);

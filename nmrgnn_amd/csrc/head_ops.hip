@@ -37,7 +37,7 @@ __device__ __forceinline__ float sum8(float v) {
 // ---- head forward: LPR lanes per row, one float4 of the Fh features each --------------------------------
 // draw: the keep-mask is drawn here (the values of dropout_mask_kernel(seed, offset, keep) over the [N][Fh] elements: a
 // lane's four columns are one Philox counter) and written to mask_out for the backward, instead of being read
-struct HeadDraw { uint64_t seed, offset; float keep; float* mask_out; };
+struct HeadDraw { uint64_t seed, offset; float keep; float* mask_out; const uint64_t* staged; };      // staged: the seed of a replayed step (ng_replay_stage)
 
 template <int LPR, bool DRAW>
 __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, const float* __restrict__ g,
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void head_fwd_fast_kernel(int64_t N, int C, co
     float4 x = *reinterpret_cast<const float4*>(g + i * Fh + 4 * q);
     if (DRAW) {
       uint32_t r[4];
-      philox4x32(dr.seed, dr.offset + (uint64_t)(i * LPR + q), r);
+      philox4x32(dr.staged ? dr.staged[0] : dr.seed, dr.offset + (uint64_t)(i * LPR + q), r);
       const float inv = 1.0f / dr.keep;
       float4 m = make_float4(u01(r[0]) <= dr.keep ? inv : 0.f, u01(r[1]) <= dr.keep ? inv : 0.f,
                              u01(r[2]) <= dr.keep ? inv : 0.f, u01(r[3]) <= dr.keep ? inv : 0.f);
@@ -245,7 +245,7 @@ int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   const int lpr = Fh / 4;
   const int64_t rpb = 256 / lpr;
   const int grid = (int)std::min<int64_t>(cdiv(N, rpb), (int64_t)ctx->num_cu * 8);
-  const HeadDraw dr{seed, offset, keep, mask_out};
+  const HeadDraw dr{seed, offset, keep, mask_out, mask_out ? replay_state(ctx) : nullptr};
   ProfScope ps(ctx, st, "head_fwd");
 #define NG_HF(L)                                                                                                   \
   do {                                                                                                             \

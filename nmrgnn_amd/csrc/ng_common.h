@@ -96,6 +96,12 @@ struct ng_ctx {
   // deferred second-stage reductions (ng_defer_reductions; reduce.cuh): queue + partial arena, owned by capi.hip
   bool defer_reduce = false;
   void* rq = nullptr;
+  // graph replay of a training step (ng_replay_arm / ng_replay_stage): while armed, the launches whose arguments change from
+  // step to step (noise / dropout seed, Adam's bias-corrected rate) read them from the staged device block instead
+  bool replay_armed = false;
+  // job tables of repack launches recorded while armed: one per job set, never rewritten or freed before ng_ctx_destroy — a
+  // captured launch reads its table at every replay, whatever other engines of the device have registered since
+  std::map<uint64_t, void*> wjobs_private;
 };
 
 namespace ng {
@@ -163,6 +169,10 @@ void* workspace(ng_ctx* ctx, size_t bytes);
 void* aux_workspace(ng_ctx* ctx, size_t bytes);
 constexpr size_t NG_SMALL_BYTES = 64 * 1024;
 void* small_scratch(ng_ctx* ctx);      // NG_SMALL_BYTES, allocated once per context, address stable until ng_ctx_destroy
+// staged per-step state of a replayed training step: {u64 seed; f32 lr_t; ...} at a fixed place of the small scratch;
+// nullptr unless the context is armed (ng_replay_arm)
+constexpr size_t NG_REPLAY_STATE_OFFSET = NG_SMALL_BYTES - 256;
+const uint64_t* replay_state(ng_ctx* ctx);
 // Frozen-weight image cache.  Returns nullptr when the cache is off (pack into scratch as before); otherwise a
 // persistent buffer of `bytes` for (src, kind) with *valid = true when it already holds the image of the current
 // weights (skip the pack launch).  kinds: 1 MPLayer Wp, 3 GEMM fp16-piece image, 4 window fragments, 5 FC fragments, 6 edge fp16-piece image

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256) void loss_final_kernel(int G, const float* __r
 // ------------------------------------------------------------------------------------ Adam
 __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, float lr_t, float b1,
-                            float b2, float eps, float gscale) {
+                            float b2, float eps, float gscale, const uint64_t* __restrict__ staged) {
+  if (staged) lr_t = reinterpret_cast<const float*>(staged)[2];      // replayed step: the bias-corrected rate of THIS replay
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
@@ -674,7 +675,8 @@ __global__ void add_scaled_kernel(int64_t n, const float* __restrict__ x,
 // out = x + alpha * xi with the xi of randn_kernel(seed, offset) — GaussianNoise in one launch (model.py:253); same
 // expressions as randn_kernel followed by add_scaled_kernel, so the bits are those of the two-launch form
 __global__ void add_noise_kernel(uint64_t seed, uint64_t offset, int64_t n, const float* __restrict__ x, float alpha,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, const uint64_t* __restrict__ staged) {
+  if (staged) seed = staged[0];      // replayed step: the seed of THIS replay (ng_replay_stage)
   const int64_t n4 = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
        q += (int64_t)gridDim.x * blockDim.x) {
@@ -694,7 +696,8 @@ __global__ void add_noise_kernel(uint64_t seed, uint64_t offset, int64_t n, cons
 // supplies the draws.  Dead slots get nothing: the compacted edge kernels never see them.
 __global__ void add_noise_live_kernel(uint64_t seed, uint64_t offset, int64_t n, const float* __restrict__ x,
                                       const float* __restrict__ y, float alpha, const int32_t* __restrict__ pos,
-                                      float* __restrict__ out_c) {
+                                      float* __restrict__ out_c, const uint64_t* __restrict__ staged) {
+  if (staged) seed = staged[0];
   const int64_t n4 = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4;
        q += (int64_t)gridDim.x * blockDim.x) {
@@ -751,7 +754,7 @@ extern "C" int ng_add_noise(ng_ctx* ctx, void* stream, uint64_t seed, uint64_t o
   if (!ctx) return NG_ERR_INVALID;
   if (n == 0) return NG_OK;
   hipLaunchKernelGGL(add_noise_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed, offset, n, x,
-                     alpha, out);
+                     alpha, out, ng::replay_state(ctx));
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -762,7 +765,7 @@ extern "C" int ng_add_noise_live(ng_ctx* ctx, void* stream, uint64_t seed, uint6
   if (n == 0) return NG_OK;
   NG_REQUIRE(ctx, x && pos && out_c, "add_noise_live: arguments");
   hipLaunchKernelGGL(add_noise_live_kernel, ew_grid((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed, offset, n, x, y,
-                     alpha, pos, out_c);
+                     alpha, pos, out_c, ng::replay_state(ctx));
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
@@ -946,6 +949,7 @@ extern "C" int ng_head_fwd_dropout(ng_ctx* ctx, void* stream, int64_t N, int Fh,
     return head_fwd_fast(ctx, (hipStream_t)stream, N, Fh, C, g, nullptr, Wout, bout, atoms, peak_std, peak_avg, peaks,
                          seed, offset, keep, mask_out);
   // other shapes: the draw and the head as two launches
+  NG_REQUIRE(ctx, !ctx->replay_armed, "head_fwd_dropout: this head shape cannot be replayed (seed is a launch argument)");
   const int rc = ng_dropout_mask(ctx, stream, seed, offset, keep, mask_out, N * Fh);
   if (rc) return rc;
   return ng_head_fwd(ctx, stream, N, Fh, C, g, mask_out, Wout, bout, atoms, peak_std, peak_avg, peaks);
@@ -1090,7 +1094,7 @@ extern "C" int ng_adam_step(ng_ctx* ctx, void* stream, int64_t n, float* p, cons
   {
     ProfScope ps(ctx, (hipStream_t)stream, "adam");
     hipLaunchKernelGGL(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v,
-                       (float)lr_t, beta1, beta2, eps, grad_scale);
+                       (float)lr_t, beta1, beta2, eps, grad_scale, ng::replay_state(ctx));
     NG_HIP(ctx, hipGetLastError());
   }
   // every registered weight image fed by the block just updated: ONE launch here instead of one in front of each consumer

@@ -67,13 +67,7 @@ int repack_all(ng_ctx* ctx, hipStream_t st, const void* lo, const void* hi) {
     hash = (hash ^ (uint64_t)(uintptr_t)w->buf) * 1099511628211ull;
     hash = (hash ^ (uint64_t)w->job.blocks) * 1099511628211ull;
   }
-  if (ctx->wjobs_dirty || ctx->wjobs_n != n || ctx->wjobs_hash != hash || ctx->wjobs_cap < need) {
-    if (ctx->wjobs_cap < need) {
-      if (ctx->wjobs_dev) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->wjobs_dev); ctx->wjobs_dev = nullptr; ctx->wjobs_cap = 0; }
-      if (hipMalloc(&ctx->wjobs_dev, need * 2) != hipSuccess) return fail(ctx, NG_ERR_NOMEM, "repack_all: job table");
-      ctx->wjobs_cap = need * 2;
-    }
-    std::vector<char>& host = ctx->wjobs_host;
+  auto fill_host = [&](std::vector<char>& host, unsigned* blocks_out) {
     host.assign(need, 0);
     unsigned* b0 = reinterpret_cast<unsigned*>(host.data() + jobs_bytes);
     unsigned blocks = 0;
@@ -83,17 +77,54 @@ int repack_all(ng_ctx* ctx, hipStream_t st, const void* lo, const void* hi) {
       blocks += (unsigned)sel[k]->job.blocks;
     }
     b0[n] = blocks;
-    NG_HIP(ctx, hipMemcpyAsync(ctx->wjobs_dev, host.data(), need, hipMemcpyHostToDevice, st));
+    *blocks_out = blocks;
+  };
+  const void* table = nullptr;
+  int table_blocks = 0;
+  if (ctx->replay_armed) {
+    // a launch that may be captured (ng_replay_arm): its own immutable table.  The shared one below is rewritten whenever
+    // another engine of the device updates its weights — a replayed step then rebuilt the OTHER engine's images (round 5:
+    // two trainers on one device diverged at the second replayed step).  Uploaded by the warm-up steps, before any capture.
+    hash = (hash ^ (uint64_t)n) * 1099511628211ull;
+    for (ng_ctx::WImage* w : sel) {      // the whole job (sources, destinations, parameters) defines the table
+      const unsigned char* jb = reinterpret_cast<const unsigned char*>(&w->job);
+      for (size_t i = 0; i < sizeof(PackJob); ++i) hash = (hash ^ jb[i]) * 1099511628211ull;
+    }
+    unsigned blocks = 0;
+    std::vector<char> host;
+    fill_host(host, &blocks);
+    auto it = ctx->wjobs_private.find(hash);
+    if (it == ctx->wjobs_private.end()) {
+      void* p = nullptr;
+      if (hipMalloc(&p, need) != hipSuccess) return fail(ctx, NG_ERR_NOMEM, "repack_all: private job table");
+      NG_HIP(ctx, hipMemcpy(p, host.data(), need, hipMemcpyHostToDevice));      // synchronous: `host` is a local
+      it = ctx->wjobs_private.emplace(hash, p).first;
+    }
+    table = it->second;
+    table_blocks = (int)blocks;
+  } else {
+  if (ctx->wjobs_dirty || ctx->wjobs_n != n || ctx->wjobs_hash != hash || ctx->wjobs_cap < need) {
+    if (ctx->wjobs_cap < need) {
+      if (ctx->wjobs_dev) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->wjobs_dev); ctx->wjobs_dev = nullptr; ctx->wjobs_cap = 0; }
+      if (hipMalloc(&ctx->wjobs_dev, need * 2) != hipSuccess) return fail(ctx, NG_ERR_NOMEM, "repack_all: job table");
+      ctx->wjobs_cap = need * 2;
+    }
+    unsigned blocks = 0;
+    fill_host(ctx->wjobs_host, &blocks);
+    NG_HIP(ctx, hipMemcpyAsync(ctx->wjobs_dev, ctx->wjobs_host.data(), need, hipMemcpyHostToDevice, st));
     ctx->wjobs_n = n;
     ctx->wjobs_blocks = (int)blocks;
     ctx->wjobs_dirty = false;
     ctx->wjobs_hash = hash;
   }
+  table = ctx->wjobs_dev;
+  table_blocks = ctx->wjobs_blocks;
+  }
   {
     ProfScope ps(ctx, st, "repack_all");
     const size_t jb = ((size_t)n * sizeof(PackJob) + 255) / 256 * 256;
-    hipLaunchKernelGGL(repack_all_kernel, dim3(ctx->wjobs_blocks), dim3(PKB), 0, st, (const PackJob*)ctx->wjobs_dev,
-                       (const unsigned*)((const char*)ctx->wjobs_dev + jb), n, pack_flag_version(ctx));
+    hipLaunchKernelGGL(repack_all_kernel, dim3(table_blocks), dim3(PKB), 0, st, (const PackJob*)table,
+                       (const unsigned*)((const char*)table + jb), n, pack_flag_version(ctx));
     NG_HIP(ctx, hipGetLastError());
   }
   for (ng_ctx::WImage* w : sel) w->ver = ctx->wver;
