@@ -24,6 +24,7 @@ static void load_switches() {
   s.edge_math_fp32 = env_is("NG_EDGE_MATH", "fp32");
   s.edge_bwd_math_fp32 = env_is("NG_EDGE_BWD_MATH", "fp32");
   s.edge_bwd_rs = env_is("NG_EDGE_BWD", "rs");
+  s.mp_pull_l2 = env_is("NG_MP_PULL", "l2");
   s.gemm_math_fp32 = env_is("NG_GEMM_MATH", "fp32");
   s.edge_layered = env_is("NG_EDGE_PATH", "layered");
   s.mp_layered = env_is("NG_MP_PATH", "layered");

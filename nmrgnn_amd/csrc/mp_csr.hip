@@ -364,11 +364,168 @@ int csr_edge_grad(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, c
   return NG_OK;
 }
 
+// ---- window pull (round 5): the backward scatter-sum of the default width with the dA rows in LDS ------------------------------
+//   out[t][l] = base[t][l] + sum over the incoming edges (i -> t) of sum_n e_n * dA[i][n][l]        (layers.py:33-40)
+// The kernel above pulls 3 KB of dA per incoming edge through L2 — 6.3 GB per layer of the bench batch, 0.37-0.38 ms, "0.23 of
+// the HBM roofline" for 0.7 GB of algorithmic traffic: the bound is the L2, every dA row is fetched ~16 times.  Edges never
+// leave a graph, so the sources of a run of consecutive targets lie in a short row range (the graph: 256 rows in the bench
+// batch; ng_ctx_set_graph_span tells the library), and here each of those rows crosses HBM -> LDS exactly once.
+// (First form, measured and replaced: column slabs of 32 with a 288-row window per slab — the targets' accumulators and the
+// records were re-read for each of the eight slabs: 0.32-0.35 ms per launch, its skeleton alone 0.16.)
+constexpr int PW_THREADS = 1024, PW_T = 256, PW_BR = 16, PW_REC = 4096, PW_SPAN = 288;
+struct PullWinArgs {
+  int64_t N;
+  int F;                      // 256
+  int64_t ntiles;
+  int tiles_per_wg;
+  const int32_t* csc_ptr;     // [N + 1]
+  const float4* rec;          // [entries] {source row (int bits), e0, e1, e2} in CSC order = ascending source per target
+  const float* dA;            // [N][E][F]
+  const float* base;          // [N][F]
+  float* out;                 // [N][F]
+};
+
+// A workgroup (one per CU, sixteen waves) takes tiles of 256 consecutive targets.  Per tile: every thread owns 4 float4 of
+// FOUR target rows (16 lanes per target, 64 targets per pass, 4 passes: 64 accumulator registers — the tile's whole
+// [256][256] gradient block lives in registers), the tile's records are staged in LDS once (64 KB), and the source rows
+// [lo, hi] of the tile are walked in blocks of 24 full rows x E (72 KB, the next block travelling in registers meanwhile).
+// The records of a target are in ascending source order (CSC order = ascending entry id = source-major), so each (thread,
+// pass) just advances a pointer through its target's list as the blocks go by.  dA, base and out cross HBM once, whole rows.
+// Measured (same box, ms per launch at 512 x 256 atoms, profiles/r05c_pull_win.txt): through L2 0.384 | this kernel 0.335 | its
+// parts: dA loads 0.02 (hidden), sums out of LDS 0.16 (29 % of the LDS read rate: chains of dependent LDS round trips, one
+// edge per pass and block), everything else 0.11.  Not kept: the four passes advancing together (348 B/lane of scratch); one
+// wave per target row with wave-uniform lists (0.63: sixteen waves, one edge each in flight).
+template <int EC>
+__global__ __launch_bounds__(PW_THREADS, 1) void pull_win_kernel(PullWinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pw_smem[];
+  constexpr int F4 = 64;                                                   // float4 per row (F = 256)
+  constexpr int WIN4 = PW_BR * EC * F4;                                     // float4 per block
+  constexpr int PF = (WIN4 + PW_THREADS - 1) / PW_THREADS;
+  float4* win4 = reinterpret_cast<float4*>(pw_smem);                      // [PW_BR][EC][64]
+  float4* srec = win4 + WIN4;                                             // [PW_REC]
+  int* red = reinterpret_cast<int*>(srec + PW_REC);                       // [2][16] wave partials, [32..33] lo / hi
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g16 = tid >> 4, l16 = tid & 15;
+  const float4* dA4 = reinterpret_cast<const float4*>(a.dA);
+#pragma unroll 1
+  for (int64_t tile = (int64_t)blockIdx.x * a.tiles_per_wg; tile < min(((int64_t)blockIdx.x + 1) * a.tiles_per_wg, a.ntiles); ++tile) {
+    const int64_t r0 = tile * PW_T, r1 = min(r0 + PW_T, a.N);
+    const int Q0 = a.csc_ptr[r0], Q1 = a.csc_ptr[r1];
+    const int nrec = Q1 - Q0;
+    __syncthreads();      // the tile before is done with srec / win4 / red
+    // records of the tile -> LDS (the first PW_REC; a longer list is finished from memory), their source range on the way
+    int lo = 0x7fffffff, hi = -1;
+    for (int q = tid; q < nrec; q += PW_THREADS) {
+      const float4 r = a.rec[Q0 + q];
+      if (q < PW_REC) srec[q] = r;
+      const int sidx = __float_as_int(r.x);
+      lo = min(lo, sidx); hi = max(hi, sidx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+      int l = red[0], h = red[16];
+      for (int w = 1; w < PW_THREADS / 64; ++w) { l = min(l, red[w]); h = max(h, red[16 + w]); }
+      red[32] = l; red[33] = h;
+    }
+    __syncthreads();
+    lo = red[32]; hi = red[33];
+    // accumulators = base rows; list pointers
+    float4 acc[4][4];
+    int qp[4], qe[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t tg = r0 + 64 * p + g16;
+      const bool live = tg < r1;
+      const int64_t tc = live ? tg : r0;
+      qp[p] = a.csc_ptr[tc] - Q0;
+      qe[p] = live ? a.csc_ptr[tc + 1] - Q0 : qp[p];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = reinterpret_cast<const float4*>(a.base)[tc * F4 + 16 * j + l16];
+    }
+    auto blk_load = [&](float4 (&pf)[PF], int b0) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int x = tid + k * PW_THREADS;
+        const int r = x / (EC * F4), rem = x % (EC * F4);
+        const int64_t g = min((int64_t)b0 + r, a.N - 1);      // rows past the end are never referenced
+        pf[k] = x < WIN4 ? dA4[g * (EC * F4) + rem] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    float4 pf[PF];
+    if (hi >= lo) blk_load(pf, lo);
+#pragma unroll 1
+    for (int b0 = lo; b0 <= hi; b0 += PW_BR) {
+      __syncthreads();      // readers of the block before are done
+#pragma unroll
+      for (int k = 0; k < PF; ++k)
+        if (tid + k * PW_THREADS < WIN4) win4[tid + k * PW_THREADS] = pf[k];
+      __syncthreads();
+      if (b0 + PW_BR <= hi) blk_load(pf, b0 + PW_BR);
+      const int b1 = b0 + PW_BR;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        while (qp[p] < qe[p]) {
+          const float4 r = qp[p] < PW_REC ? srec[qp[p]] : a.rec[Q0 + qp[p]];
+          const int sidx = __float_as_int(r.x);
+          if (sidx >= b1) break;
+          const float ev[3] = {r.y, r.z, r.w};
+          const float4* wr = win4 + (sidx - b0) * (EC * F4) + l16;
+#pragma unroll
+          for (int n = 0; n < EC; ++n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 v = wr[n * F4 + 16 * j];
+              acc[p][j].x = fmaf(ev[n], v.x, acc[p][j].x); acc[p][j].y = fmaf(ev[n], v.y, acc[p][j].y);
+              acc[p][j].z = fmaf(ev[n], v.z, acc[p][j].z); acc[p][j].w = fmaf(ev[n], v.w, acc[p][j].w);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (four row quarters in flight, not twelve)
+          }
+          ++qp[p];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t tg = r0 + 64 * p + g16;
+      if (tg < r1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reinterpret_cast<float4*>(a.out)[tg * F4 + 16 * j + l16] = acc[p][j];
+      }
+    }
+  }
+}
+
+bool pull_win_ok(ng_ctx* ctx, int64_t N, int F, int E, const float* rec) {
+  return rec != nullptr && E >= 1 && E <= 3 && F == 256 && N >= 4096 && ctx->graph_span > 0 && ctx->graph_span <= PW_SPAN &&
+         !sw().mp_pull_l2;
+}
+
+int pull_win(ng_ctx* ctx, hipStream_t st, int64_t N, int F, int E, const int32_t* csc_ptr, const float* rec, const float* dA,
+             const float* base, float* out) {
+  PullWinArgs a;
+  a.N = N; a.F = F; a.ntiles = cdiv(N, PW_T);
+  a.tiles_per_wg = (int)std::max<int64_t>(1, cdiv(a.ntiles, (int64_t)ctx->num_cu));
+  a.csc_ptr = csc_ptr; a.rec = reinterpret_cast<const float4*>(rec); a.dA = dA; a.base = base; a.out = out;
+  const int grid = (int)cdiv(a.ntiles, a.tiles_per_wg);
+  const size_t lds = (size_t)PW_BR * E * F * 4 + (size_t)PW_REC * 16 + 64 * 4;
+  switch (E) {
+    case 1: hipLaunchKernelGGL((pull_win_kernel<1>), dim3(grid), dim3(PW_THREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((pull_win_kernel<2>), dim3(grid), dim3(PW_THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL((pull_win_kernel<3>), dim3(grid), dim3(PW_THREADS), lds, st, a); break;
+  }
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
 int csr_scatter_pull(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const int32_t* row_of,
                      const int32_t* csc_ptr, const int32_t* csc_edge, const float* e, const float* rec, const float* dA,
                      const float* dh_out, float* dh_in) {
   if (N == 0) return NG_OK;
   ProfScope ps(ctx, st, "mp_scatter_pull");
+  if (pull_win_ok(ctx, N, F, E, rec)) return pull_win(ctx, st, N, F, E, csc_ptr, rec, dA, dh_out, dh_in);
   if ((F == 128 || F == 256) && E <= 4) {
     const int lpa = F / 16;
     const dim3 gridw((unsigned)cdiv(N, 256 / lpa));

@@ -113,6 +113,7 @@ namespace ng {
 //   NG_GEMM_MATH=fp32      generic GEMMs on f32-input MFMA (default: split operands where the shape allows)
 //   NG_EDGE_BWD=rs         split-operand edge backward with sixteen role-split waves (edge_bwd_rs.hip; default: eight waves, edge_bwd_h2.hip)
 //   NG_EDGE_PATH=layered   one launch per edge-MLP layer (any H / Le)
+//   NG_MP_PULL=l2          default-width backward scatter-sum through L2 (default: dA rows staged in LDS windows, pull_win_kernel)
 //   NG_MP_PATH=layered     aggregate -> A[N,E*F] -> GEMM for every width (default: window kernels at F == 64)
 //   NG_FC_PATH=layered     one launch per FC layer
 //   NG_DENSE_PATH=generic  no register-resident tall-skinny kernels
@@ -129,6 +130,7 @@ struct Switches {
   bool mp_w16 = true;                // NG_MP_W16=0: the eight-wave forward window kernel instead of the 16-wave one (mp_win16.hip)
   bool reduce_narrow = false;        // NG_REDUCE=narrow: second-stage reductions 64 elements per block at every size (reduce.cuh)
   bool knn_lanes = false;            // NG_KNN=lanes
+  bool mp_pull_l2 = false;           // NG_MP_PULL=l2: the default-width backward scatter-sum gathers dA rows through L2 (round 1-4) instead of the LDS window pull (mp_csr.hip: pull_win_kernel)
   bool edge_bwd_rs = false;          // NG_EDGE_BWD=rs: the role-split sixteen-wave split-operand edge backward (edge_bwd_rs.hip; measured, not faster) instead of the eight-wave one (edge_bwd_h2.hip)
   int64_t mp_gg_min_rows = 8192;     // NG_MP_GG_MIN_ROWS
 };
