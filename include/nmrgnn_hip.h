@@ -371,6 +371,24 @@ int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
                 const float* drop_mask, const float* Wout, const float* atoms,
                 const float* peak_std, const float* dpeaks, float* dg, float* dWout, float* dbout);
 
+/* ---- edge path through a table of the edge function (round 5; OPT-IN, not the default: csrc/edge_table.hip) -------------
+ * mask + RBFExpansion + EdgeFCBlock (nmrgnn/model.py:251-261) maps ONE scalar per edge to e[E]: e_ij = m_ij f_W(d_ij).  The
+ * caller evaluates f_W with ng_edge_mlp_fwd on T equidistant points that cover the step's distances and interpolates every
+ * edge (four-point cubic Lagrange, error ~ (h / 0.028)^4 < 1e-9 relative at T = 4096); the backward scatters de onto the table
+ * (the exact adjoint, 64-bit fixed-point sums: order-free) and runs ng_edge_mlp_bwd_tape on the T points.
+ *   ng_edge_table_range    range[0..1] = min / max of d_eff over the live slots (d_src > 0) when d_eff != NULL;
+ *                          range[2] = max |de| over the live slots when de != NULL.  range: 3 device floats.
+ *   ng_edge_table_points   d_tab[t] = lo + (t - 1) h, h = (hi - lo) / (T - 3);  ones[t] = 1 (the table's d_src: all live)
+ *   ng_edge_table_interp   e_out[i][c] = m_i sum_k w_k(d_eff[i]) e_tab[i0 + k][c]        (E <= 4, T * E <= 16384)
+ *   ng_edge_table_scatter  de_tab[t][c] = sum_i m_i w_k(d_eff[i]) de[i][c] over the stencils that contain t; writes range[2] */
+int ng_edge_table_range(ng_ctx*, void* stream, int64_t n, int E, const float* d_src, const float* d_eff, const float* de,
+                        float* range);
+int ng_edge_table_points(ng_ctx*, void* stream, int T, const float* range, float* d_tab, float* ones);
+int ng_edge_table_interp(ng_ctx*, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
+                         const float* range, const float* e_tab, float* e_out);
+int ng_edge_table_scatter(ng_ctx*, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
+                          float* range, const float* de, float* de_tab);
+
 /* ---- training: NameLoss (s = 1), nmrgnn/losses.py:30-39, batched over graphs -----------------
  *   loss = mean_g  sum_{i in g} w_i (y_i - pred_i)^2 / sum_{i in g} w_i   (divide_no_nan)
  *   dpred written for backward; loss_out is one device float. */

@@ -36,7 +36,7 @@ def rbf_grid(low, high, count):
 class Tape:
     """activations kept between forward(training=True) and backward()"""
     __slots__ = ("batch", "d_eff", "z_save", "z_layout", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
-                 "peaks", "live")
+                 "peaks", "live", "table")
 
 
 class Engine:
@@ -93,6 +93,11 @@ class Engine:
         # padded slots (edges == 0) are skipped by the fused edge kernels (include/nmrgnn_hip.h: ng_edge_mlp_fwd_live);
         # NG_EDGE_LIVE=0 runs every slot as rounds 1-3 did (A/B measurements, tests)
         self.use_live_edges = os.environ.get("NG_EDGE_LIVE", "1") != "0"
+        # OPT-IN (round 5, csrc/edge_table.hip): the edge MLP is a function of one scalar per edge — evaluate it with the fused
+        # kernels on EDGE_TABLE_POINTS equidistant distances and interpolate every edge (cubic, error < 1e-9 relative); the
+        # backward scatters de onto the table (exact adjoint) and runs the fused backward on the table.  Not the default: the
+        # reference evaluates the MLP per edge and the headline is measured that way.
+        self.edge_table = os.environ.get("NG_EDGE_TABLE", "0") == "1"
         Engine._ids += 1
         self._id = Engine._ids          # owner tag of the frozen-weight cache
 
@@ -158,7 +163,8 @@ class Engine:
         d_src = batch.edges.reshape(-1)
         d_eff = d_src
         # live-edge view: the fused edge kernels walk the compacted live slots only (same e bit for bit)
-        live = batch.live_edges() if (self.use_live_edges and lib.ng_edge_live_supported(H, E, self.Le, self.fc_act)) else None
+        use_table = self.edge_table and E <= 4 and ne > 0 and self.fc_act == 1 and H == 128 and self.Le == 4
+        live = batch.live_edges() if (not use_table and self.use_live_edges and lib.ng_edge_live_supported(H, E, self.Le, self.fc_act)) else None
         if live is not None:
             perm, pos, d_c, n_live = live
             d_src = d_eff = d_c
@@ -174,18 +180,27 @@ class Engine:
                 noise = noise.reshape(-1)
                 self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
                          "ng_add_scaled")
-        z_save = self._new(self.Le - 1, ne, H) if tape else None
+        table = self._edge_table_forward(batch, d_eff, tape) if use_table else None
+        if table is not None:
+            e, d_eff, z_save, z_layout = table["e"], table["d_eff"], None, 0
+            live = None
+        else:
+            e = None
+        z_save = (self._new(self.Le - 1, ne, H) if tape else None) if table is None else None
         # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
         # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
-        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if tape else 0
-        e = self._new(ne, E)
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if (tape and table is None) else 0
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
-        if live is not None:
+        if table is not None:
+            pass
+        elif live is not None:
+            e = self._new(ne, E)
             self._ck(lib.ng_edge_mlp_fwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff), ptr(perm),
                                               ptr(n_live), ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
                                               ptr(e), ptr(z_save)), "ng_edge_mlp_fwd_live")
         else:
+            e = self._new(ne, E)
             self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff),
                                          ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
                                          ptr(e), ptr(z_save)), "ng_edge_mlp_fwd")
@@ -259,9 +274,50 @@ class Engine:
             tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e
             tp.z_layout = z_layout
             tp.live = live
+            tp.table = table
             tp.h, tp.A, tp.S, tp.fx, tp.fs, tp.g, tp.drop_mask, tp.peaks = hs, As, Ss, fx, fs, g, mask, peaks
             self.tape = tp
         return peaks
+
+    # ------------------------------------------------------------------ edge function table (opt-in)
+    EDGE_TABLE_POINTS = 4096
+
+    def _edge_table_forward(self, batch, d_eff, tape):
+        """e[ne,E] by interpolation in a table of the edge function (csrc/edge_table.hip); keeps what the backward needs.
+        ``d_eff``: the distances fed to the RBF, slot order (noise already added when training)"""
+        lib, h, st = self.lib, self.ctx.handle, self._st()
+        P = self.params
+        ne, E, H, T = batch.n_edges, self.E, self.H, self.EDGE_TABLE_POINTS
+        d_src = batch.edges.reshape(-1)
+        rng = self._new(4)
+        self._ck(lib.ng_edge_table_range(h, st, ne, E, ptr(d_src), ptr(d_eff), None, ptr(rng)), "ng_edge_table_range")
+        d_tab, ones = self._new(T), self._new(T)
+        self._ck(lib.ng_edge_table_points(h, st, T, ptr(rng), ptr(d_tab), ptr(ones)), "ng_edge_table_points")
+        e_tab = self._new(T, E)
+        z_tab = self._new(self.Le - 1, T, H) if tape else None
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, T)) if tape else 0
+        W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
+        B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
+        self._ck(lib.ng_edge_mlp_fwd(h, st, T, H, E, self.Le, self.fc_act, ptr(ones), ptr(d_tab), ptr(self.centers), self.gap,
+                                     ptr_array(W), ptr_array(B), ptr(e_tab), ptr(z_tab)), "ng_edge_mlp_fwd")
+        e = self._new(ne, E)
+        self._ck(lib.ng_edge_table_interp(h, st, ne, E, T, ptr(d_src), ptr(d_eff), ptr(rng), ptr(e_tab), ptr(e)),
+                 "ng_edge_table_interp")
+        return {"e": e, "d_eff": d_eff, "rng": rng, "d_tab": d_tab, "ones": ones, "z_tab": z_tab, "z_layout": z_layout, "T": T}
+
+    def _edge_table_backward(self, tp, de):
+        lib, h, st = self.lib, self.ctx.handle, self._st()
+        P, tb, b = self.params, tp.table, tp.batch
+        ne, E, H, T = b.n_edges, self.E, self.H, tb["T"]
+        de_tab = self._new(T, E)
+        self._ck(lib.ng_edge_table_scatter(h, st, ne, E, T, ptr(b.edges), ptr(tp.d_eff), ptr(tb["rng"]), ptr(de), ptr(de_tab)),
+                 "ng_edge_table_scatter")
+        W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
+        dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
+        dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
+        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, T, H, E, self.Le, self.fc_act, ptr(tb["ones"]), ptr(tb["d_tab"]),
+                                          ptr(self.centers), self.gap, ptr_array(W), ptr(tb["z_tab"]), ptr(de_tab),
+                                          ptr_array(dW), ptr_array(dB), tb["z_layout"]), "ng_edge_mlp_bwd")
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpeaks, on_node_grads=None):
@@ -340,7 +396,9 @@ class Engine:
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
-        if tp.live is not None:
+        if getattr(tp, "table", None) is not None:
+            self._edge_table_backward(tp, de)
+        elif tp.live is not None:
             perm, _, d_c, n_live = tp.live
             self._ck(lib.ng_edge_mlp_bwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_c), ptr(tp.d_eff), ptr(perm),
                                               ptr(n_live), ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
