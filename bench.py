@@ -778,11 +778,16 @@ def one_graph_leg(dev, hp, n_graphs=64, steps=200):
 
     wall = timed(rstep)
     rev = event_timed(rstep, steps)
+    replay = {"ms_per_step": wall, "ms_per_step_hipevent_median": float(np.median(rev)),
+              "note": "HIP-graph replay (TrainStepReplay): 1 staging launch + 1 graph launch per step"}
+    eag = {"ms_per_step": eager, "ms_per_step_hipevent_median": float(np.median(ev)), "note": "~33 eager launches per step"}
+    # which of the two wins depends on the host: the GPU timeline of the step is ~0.30 ms either way (small-kernel latency,
+    # DESIGN 4.5); the replay takes the host's launch work out
+    best, path = (replay, "replay") if wall <= eager else (eag, "eager")
     return {"workload": f"1 graph x {ATOMS_PER_GRAPH} atoms per step (fwd+loss+bwd+Adam), a new graph tuple every step, F=64",
-            "ms_per_step": wall, "ms_per_step_hipevent_median": float(np.median(rev)), "value": ATOMS_PER_GRAPH / (wall * 1e-3),
-            "unit": "atoms/s", "steps": steps, "path": "HIP-graph replay (TrainStepReplay): 1 staging launch + 1 graph launch per step",
-            "eager": {"ms_per_step": eager, "ms_per_step_hipevent_median": float(np.median(ev)),
-                      "note": "the same step as ~33 eager launches (what rounds 1-4 reported here)"},
+            "ms_per_step": best["ms_per_step"], "ms_per_step_hipevent_median": best["ms_per_step_hipevent_median"],
+            "value": ATOMS_PER_GRAPH / (best["ms_per_step"] * 1e-3), "unit": "atoms/s", "steps": steps, "path": path,
+            "replay": replay, "eager": eag,
             "note": "wall clock per step includes the host's launch work (python + ctypes); the hipEvent median is the GPU timeline"}
 
 
@@ -829,9 +834,11 @@ def whole_protein_leg(dev):
     run_replay()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res["knn16_padded_1_frames_per_call_eager"] = res["knn16_padded_1_frames_per_call"]
-    res["knn16_padded_1_frames_per_call"] = {"value": 100 * n / dt, "ms_per_100_frames": dt * 1e3, "ms_per_frame": dt * 10.0,
-                                             "path": "HIP-graph replay (ForwardReplay)"}
+    rep = {"value": 100 * n / dt, "ms_per_100_frames": dt * 1e3, "ms_per_frame": dt * 10.0, "path": "HIP-graph replay (ForwardReplay)"}
+    res["knn16_padded_1_frames_per_call_replay"] = rep
+    if rep["ms_per_frame"] < res["knn16_padded_1_frames_per_call"]["ms_per_frame"]:      # the faster of the two is the leg's number
+        res["knn16_padded_1_frames_per_call_eager"] = res["knn16_padded_1_frames_per_call"]
+        res["knn16_padded_1_frames_per_call"] = rep
     gc = frames_to_batch_cutoff(at, pos[:1], 3.5, device=dev)
     deg = (gc.row_ptr[1:] - gc.row_ptr[:-1]).cpu().numpy()
     res["cutoff_degree"] = {"min": int(deg.min()), "median": float(np.median(deg)), "max": int(deg.max())}
