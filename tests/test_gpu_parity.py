@@ -318,8 +318,10 @@ def test_full_size_fused_equals_layered_and_batch_invariance(gpu_device, monkeyp
         assert np.max(np.abs(part - ref)) < PEAK_ATOL
 
 
-def test_full_size_gradients_match_oracle(gpu_device):
-    """BASELINE configs[2] at its full size (512 x 256 atoms, F=64): peaks AND every gradient tensor of
+@pytest.mark.parametrize("edge_table", [False, True])
+def test_full_size_gradients_match_oracle(gpu_device, edge_table):
+    """(edge_table=True: the opt-in edge function table of csrc/edge_table.hip — the same bounds, at the full size)
+    BASELINE configs[2] at its full size (512 x 256 atoms, F=64): peaks AND every gradient tensor of
     the fused training step against the float64 oracle run over ALL 512 graphs (graphs are independent,
     so the batch gradient is the sum of per-graph oracle gradients; tests/helpers.py runs them in worker
     processes), with the GPU's own noise / dropout draws fed to the oracle."""
@@ -331,6 +333,7 @@ def test_full_size_gradients_match_oracle(gpu_device):
     hp = make_hp(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=128)
     b = synth.make_batch(512, 256, 16, 10, 0.05, seed=42)
     eng = Engine(hp, 10, device=gpu_device, seed=1234)
+    eng.edge_table = edge_table
     sd = randomize_biases(eng, scale=0.05)
     gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"],
                     device=gpu_device)
@@ -339,6 +342,7 @@ def test_full_size_gradients_match_oracle(gpu_device):
     mask = eng.dropout_mask(N * 32, seed=8)
     # the loss gradient of the bench step: NameLoss s=1 on the batch's labels (1/G per graph)
     peaks = eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
+    assert (eng.tape.table is not None) == edge_table
     loss, dpe = eng.loss_l2(gb, torch.from_numpy(b["y"]).to(gpu_device), torch.from_numpy(b["w"]).to(gpu_device),
                             peaks)
     eng.backward(dpe)
