@@ -316,16 +316,24 @@ __global__ __launch_bounds__(GL_SMALL_THREADS) void gl_live_small_kernel(int n, 
   const int b0 = threadIdx.x * per, b1 = min(n, b0 + per);
   int32_t c = 0;
   for (int g = b0; g < b1; ++g) c += edges[g] > 0.f ? 1 : 0;
-  s[threadIdx.x] = c;
-  __syncthreads();
-  for (int off = 1; off < GL_SMALL_THREADS; off <<= 1) {
-    const int32_t add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-    __syncthreads();
-    s[threadIdx.x] += add;
-    __syncthreads();
+  // inclusive scan of the per-thread counts: shuffles inside a wave, one barrier for the wave totals (round 5; the
+  // Hillis-Steele form over LDS took twenty barriers)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int32_t incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
   }
-  const int32_t n_live = s[GL_SMALL_THREADS - 1];
-  int32_t rank = s[threadIdx.x] - c;
+  if (lane == 63) s[wv] = incl;
+  __syncthreads();
+  int32_t wbase = 0, n_live = 0;
+  for (int w = 0; w < GL_SMALL_THREADS / 64; ++w) {
+    const int32_t v = s[w];
+    if (w < wv) wbase += v;
+    n_live += v;
+  }
+  int32_t rank = wbase + incl - c;
   for (int g = b0; g < b1; ++g) {
     const float d = edges[g];
     if (d > 0.f) { perm[rank] = g; pos[g] = rank; d_c[rank] = d; ++rank; }
@@ -350,21 +358,29 @@ __global__ __launch_bounds__(GL_SMALL_THREADS) void gl_lists_small_kernel(int n_
     if (live) atomicAdd(&s_cnt[t], 1);
   }
   __syncthreads();
-  // exclusive scan over the N counts: thread t owns targets [2t, 2t + 2)
+  // exclusive scan over the N counts: thread t owns targets [2t, 2t + 2); wave scans by DPP-free shuffles, one barrier for the
+  // wave totals (round 5: the Hillis-Steele form took 2 log2(threads) barriers — a third of the kernel's 30 us)
   const int t0 = 2 * threadIdx.x;
   const int32_t c0 = t0 < N ? s_cnt[t0] : 0, c1 = t0 + 1 < N ? s_cnt[t0 + 1] : 0;
-  s_scan[threadIdx.x] = c0 + c1;
-  __syncthreads();
-  for (int off = 1; off < GL_SMALL_THREADS; off <<= 1) {
-    const int32_t add = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
-    __syncthreads();
-    s_scan[threadIdx.x] += add;
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int32_t incl = c0 + c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
   }
-  const int32_t p0 = s_scan[threadIdx.x] - c0 - c1;
+  if (lane == 63) s_scan[wv] = incl;
+  __syncthreads();
+  int32_t wbase = 0, total = 0;
+  for (int w = 0; w < GL_SMALL_THREADS / 64; ++w) {
+    const int32_t v = s_scan[w];
+    if (w < wv) wbase += v;
+    total += v;
+  }
+  const int32_t p0 = wbase + incl - c0 - c1;
   if (t0 < N) { csc_ptr[t0] = p0; s_cur[t0] = p0; }
   if (t0 + 1 < N) { csc_ptr[t0 + 1] = p0 + c0; s_cur[t0 + 1] = p0 + c0; }
-  if (threadIdx.x == 0) csc_ptr[N] = s_scan[GL_SMALL_THREADS - 1];
+  if (threadIdx.x == 0) csc_ptr[N] = total;
   __syncthreads();
   for (int eid = threadIdx.x; eid < n_entries; eid += GL_SMALL_THREADS) {
     const int32_t t = nlist[eid];
@@ -372,13 +388,20 @@ __global__ __launch_bounds__(GL_SMALL_THREADS) void gl_lists_small_kernel(int n_
     s_tmp[atomicAdd(&s_cur[t], 1)] = eid;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < N; t += GL_SMALL_THREADS) {
-    const int q1 = s_cur[t], q0 = q1 - s_cnt[t];
-    for (int a = q0; a < q1; ++a) {
-      const int32_t v = s_tmp[a];
+  // per-target rank sort back into ascending entry id, a 16-lane group per target (as gl_sort_kernel): one thread per target
+  // walked its d^2 comparisons alone
+  const int g = threadIdx.x >> 4, gl = threadIdx.x & 15;
+  for (int t = g; t < N; t += GL_SMALL_THREADS / 16) {
+    const int q1 = s_cur[t], len = s_cnt[t], q0 = q1 - len;
+    for (int a = 0; a < len; a += 16) {
+      const int32_t v = a + gl < len ? s_tmp[q0 + a + gl] : 0x7fffffff;
       int rank = 0;
-      for (int b = q0; b < q1; ++b) rank += s_tmp[b] < v ? 1 : 0;
-      csc_edge[q0 + rank] = v;
+      for (int b = 0; b < len; b += 16) {
+        const int32_t u = b + gl < len ? s_tmp[q0 + b + gl] : 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rank += __shfl(u, r, 16) < v ? 1 : 0;
+      }
+      if (a + gl < len) csc_edge[q0 + rank] = v;
     }
   }
 }
