@@ -164,7 +164,10 @@ class Engine:
         d_eff = d_src
         # live-edge view: the fused edge kernels walk the compacted live slots only (same e bit for bit)
         use_table = self.edge_table and E <= 4 and ne > 0 and self.fc_act == 1 and H == 128 and self.Le == 4
-        live = batch.live_edges() if (not use_table and self.use_live_edges and lib.ng_edge_live_supported(H, E, self.Le, self.fc_act)) else None
+        # (the live kernels index e with 32 bits: n_slots * E * 4 < 2^31, check_live in edge_fwd_h2.hip; larger batches take the
+        # every-slot kernels)
+        live = batch.live_edges() if (not use_table and self.use_live_edges and ne * E * 4 < (1 << 31)
+                                      and lib.ng_edge_live_supported(H, E, self.Le, self.fc_act)) else None
         if live is not None:
             perm, pos, d_c, n_live = live
             d_src = d_eff = d_c

@@ -11,10 +11,21 @@ from .parallel import GradBuckets, shard_grad_weight
 
 
 class Trainer:
-    def __init__(self, engine: Engine, lr=None, loss_balance=1.0):
+    """Owns the weight update of ``engine``.
+
+    Contract on the packed weight images (``cache_images``, default True): while a Trainer is attached, the engine
+    keeps the fp16-piece images of its weights across calls instead of packing them per call; ``Engine.adam_step``
+    (``ng_adam_step`` inside an ``ng_weights_frozen`` window) and ``load_state_dict`` rebuild them.  Anything ELSE that
+    writes into ``engine.params.flat`` in place between steps (weight surgery, finite-difference probes, a manual
+    broadcast, clipping) must call ``engine.weights_changed()`` afterwards, or the next forward multiplies with the
+    old images.  ``Trainer(..., cache_images=False)`` keeps per-call packing (always correct, one repack launch per
+    call slower); ``close()`` restores the engine's previous setting."""
+
+    def __init__(self, engine: Engine, lr=None, loss_balance=1.0, cache_images=True):
         self.engine = engine
         # the trainer owns the weight update: packed weight images are kept and refreshed in one launch behind Adam
-        engine.cache_images = True
+        self._prev_cache_images = engine.cache_images
+        engine.cache_images = bool(cache_images)
         self.lr = lr
         self.loss_balance = float(loss_balance)      # NameLoss s (build_GNNModel's loss_balance)
         P = engine.params
@@ -70,3 +81,9 @@ class Trainer:
         ms = [a.elapsed_time(b) for a, b in self._comm_events]
         self._comm_events = []
         return sum(ms) / len(ms)
+
+    def close(self):
+        """Detach from the engine: restore its previous ``cache_images`` setting (a bare Engine packs per call)."""
+        self.engine.cache_images = self._prev_cache_images
+        if not self.engine.cache_images:
+            self.engine.weights_changed()

@@ -20,7 +20,7 @@ peak_std, by this build or by the reference's own graph in float32.  The test as
     (Rounds 2-3 wrote "1.5 x" beside an `or err_std < 5e-6` clause that the padded case passed
     through; the clause is gone.)
 The measured per-element errors (C = 2, N = 3, H = 4) are printed; the unfiltered print-out of a run on
-MI355X is profiles/r04_savedmodel_errors.txt.
+MI355X is profiles/r05z_savedmodel_errors.txt (regenerated each round by tools/round_profiles.sh).
 """
 import numpy as np
 import pytest
@@ -30,7 +30,7 @@ from helpers import load_savedmodel_case, make_hp
 pytestmark = pytest.mark.gpu
 
 STD_ATOL = 5e-5
-REF32_FACTOR = 3.0
+REF32_FACTOR = {"padded": 3.0, "pdb108m": 1.5}     # pdb108m measures 0.7-0.9 x; only the small padded case needs 3 x
 
 
 def _engine(gpu_device, c):
@@ -63,8 +63,8 @@ def _check(tag, c, peaks, ref64, ref32, what):
               f"standardised {err_std:.3e}")
     for e, s, err, err32, err_std in rows:
         assert err_std < STD_ATOL, (tag, what, e, err_std)
-        # 1e-4 absolute, or 3 x what float32 costs the reference's own graph on these inputs (no other escape)
-        assert err <= max(1e-4, REF32_FACTOR * err32), (tag, what, e, err, err32)
+        # 1e-4 absolute, or a small multiple of what float32 costs the reference's own graph on these inputs (no other escape)
+        assert err <= max(1e-4, REF32_FACTOR[tag] * err32), (tag, what, e, err, err32)
         if s == 0:
             assert err == 0.0           # std = avg = 0 elements predict exactly 0 (model.py:272-273)
 
