@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void gg_produce(const GgArgs& a, char* ring, const fl
         const float4 e4 = entry(i, j + q);
         const int vo = (__builtin_bit_cast(int, e4.x) * a.F + 4 * c) * 4;
 #ifdef GG_ABL_NOGATHER
-        v[i][q] = gg_f4{(float)vo, (float)so, 1.f, 2.f};
+        v[i][q] = gg_f4{(float)(vo & 255) * 1e-3f, (float)(so & 255) * 1e-3f, 1e-3f, 2e-3f};
 #else
         v[i][q] = __builtin_bit_cast(gg_f4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, so, 0));
 #endif
@@ -1369,6 +1369,23 @@ __global__ __launch_bounds__(256) void mp_gg_repair_kernel(GgArgs a) {
   }
 }
 
+#include "mp_gw.cuh"
+
+static bool gw_ok(const GgArgs& a, int E) {
+  return sw().mp_gw && E == 3 && a.F % 32 == 0 && a.M * (int64_t)a.F * 4 < ((int64_t)1 << 31) && (a.ptr || a.Kpad <= 16);
+}
+
+// DEFAULT for the forward of a call that does not keep the aggregate (inference: `A_save == nullptr`) on a batch of small
+// graphs (ng_ctx_set_graph_span: every row's sources lie inside the 320-row window): the window gather-GEMM (mp_gw.cuh).
+// Measured on MI355X at the bench batch (profiles/r05e_gw_ab.txt): 0.30-0.33 ms per layer against 0.134 + 0.227 for
+// aggregate -> HBM -> GEMM.  Training calls (the aggregate is written for dw = A^T dP: its row-per-lane stores cost the
+// kernel more than the round trip it saves) and the backward's pull (pull_win_kernel wins) keep their kernels unless
+// NG_MP_GG=1 asks for this one.
+bool mp_gw_infer_ok(ng_ctx* ctx, int64_t N, int K, int F, int E, bool csr, bool keeps_aggregate) {
+  return sw().mp_gw && !sw().gemm_math_fp32 && !sw().mp_layered && !keeps_aggregate && F == 256 && E == 3 && (csr || K <= 16) &&
+         N >= sw().mp_gg_min_rows && N * (int64_t)F * 4 < ((int64_t)1 << 31) && ctx->graph_span > 0 && ctx->graph_span <= 256;
+}
+
 bool mp_gg_supported(int64_t N, int F, int E) {
   // OPT-IN (NG_MP_GG=1): measured on MI355X the kernel does not beat aggregate -> HBM -> GEMM yet (375-450 us per launch
   // against 134 + 240; the producer waves, four per CU, cannot keep enough gathers in flight — DESIGN section 4), so the
@@ -1401,7 +1418,26 @@ static int gg_launch(ng_ctx* ctx, hipStream_t st, GgArgs& a, int E, const char* 
   a.guard = range_guard_begin(ctx);
   if (!a.guard.word) return NG_ERR_NOMEM;
   const unsigned grid = (unsigned)cdiv(a.M, GX_BM);
-  {
+  if (gw_ok(a, E)) {
+    ProfScope ps(ctx, st, tag);
+    const unsigned wgrid = (unsigned)cdiv(a.M, GW_BM);
+    if (LK == GG_PADDED && a.Kpad <= 16)
+      hipLaunchKernelGGL((mp_gw_kernel<LK, 3, GRAD, 6>), dim3(wgrid), dim3(GW_THREADS), GW_LDS, st, a);
+    else
+      hipLaunchKernelGGL((mp_gw_kernel<LK, 3, GRAD, 8>), dim3(wgrid), dim3(GW_THREADS), GW_LDS, st, a);
+#ifdef GW_STAMP
+    if (getenv("NG_GW_STAMP")) {
+      unsigned long long h[64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(gw_stamps), sizeof(h));
+      fprintf(stderr, "gw %s: stage %llu setup %llu dma0 %llu gather0 %llu loop %llu epi %llu | steps", tag, h[1] - h[0], h[2] - h[1], h[3] - h[2],
+              h[4] - h[3], h[5] - h[4], h[6] - h[5]);
+      for (int i = 8; i < 23; ++i) fprintf(stderr, " %llu", h[i + 1] - h[i]);
+      fprintf(stderr, "\n");
+    }
+#endif
+    NG_HIP(ctx, hipGetLastError());
+  } else {
     ProfScope ps(ctx, st, tag);
     switch (E) {
       case 1: hipLaunchKernelGGL((mp_gg_kernel<LK, 1, GRAD>), dim3(grid), dim3(GG_THREADS), gg_lds(1), st, a); break;

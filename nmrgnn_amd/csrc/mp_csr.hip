@@ -583,7 +583,7 @@ int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
                    float* h_out, float* A_save, float* s_save) {
   const int64_t KF = (int64_t)E * F;
-  if (E <= 3 && mp_gg_supported(N, F, E))     // gather-GEMM (gemm_h2.hip): the aggregate only as a by-product when asked for
+  if (E <= 3 && (mp_gg_supported(N, F, E) || mp_gw_infer_ok(ctx, N, K, F, E, row_ptr != nullptr, A_save != nullptr)))     // gather-GEMM (gemm_h2.hip): the aggregate only as a by-product when asked for
     return mp_gg_fwd(ctx, st, N, K, F, E, act, residual, h, row_ptr, col, e, inv_degree, w, h_out, s_save, A_save);
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;

@@ -60,6 +60,7 @@ int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, c
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag, RangeGuard guard);
 // gather-GEMM forms of the MPLayer update and of the backward's node-side pull (gemm_h2.hip): no aggregate in HBM
 bool mp_gg_supported(int64_t N, int F, int E);
+bool mp_gw_infer_ok(ng_ctx* ctx, int64_t N, int K, int F, int E, bool csr, bool keeps_aggregate);   // gemm_h2.hip / mp_gw.cuh
 int mp_gg_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, int residual, const float* h,
               const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
               float* h_out, float* s_save, float* A_out = nullptr);
