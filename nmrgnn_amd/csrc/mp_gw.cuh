@@ -529,7 +529,10 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
           gw_f4 v;
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = acc[b][2 * c + j][4 * q + t] * rs;
-          if (a.act != NG_ACT_NONE) {
+          if (a.act == NG_ACT_SOFTPLUS) {           // the branch once per value group, the common activation without the switch
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = act_apply(NG_ACT_SOFTPLUS, v[t]);
+          } else if (a.act != NG_ACT_NONE) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = act_apply(a.act, v[t]);
           }

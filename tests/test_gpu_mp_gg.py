@@ -1,7 +1,10 @@
 """Gather-GEMM form of the default-width MPLayer (round 4; csrc/gemm_h2.hip: mp_gg_kernel — the neighbour aggregate is
 the GEMM's A-tile producer and never reaches HBM; the backward's node-side pull gathers dP rows the same way) against a
 float64 statement of nmrgnn/layers.py:26-46 + model.py:165-167 and against the aggregate -> HBM -> GEMM kernels it
-would replace.  The kernel is OPT-IN (NG_MP_GG=1): on MI355X it does not beat the two-kernel path yet."""
+would replace.  Round 5 added the window form (csrc/mp_gw.cuh: mp_gw_kernel, NG_MP_GW=0 switches back to round 4's
+producer / consumer kernel): the same entry points, 256-row tiles, the gathered operand formed in registers from an LDS
+window.  NG_MP_GG=1 routes every eligible call through the gather-GEMM; by default only the forward of a call that does
+not keep the aggregate (inference) on a batch of small graphs takes it."""
 import ctypes as C
 
 import numpy as np
@@ -249,3 +252,65 @@ def test_full_size_default_width_step_against_the_oracle_on_a_sample(gpu_device)
     errs = {k: rel_err(grads[k], g) for k, g in ref_g.items()}
     print("full-size F=256 gradient rel. errors:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 2e-4, errs
+
+
+def _graph_local_lists(rng, N, K, E, G=256, p_pad=0.15):
+    """padded lists whose neighbours lie in the row's own block of G rows (a batch of G-atom graphs)"""
+    i = np.arange(N)[:, None]
+    g0 = (i // G) * G
+    nl = np.minimum(g0 + rng.integers(0, G, (N, K)), N - 1).astype(np.int32)
+    real = rng.random((N, K)) > p_pad
+    e = (rng.standard_normal((N, K, E)) * 0.5 * real[..., None]).astype(np.float32)
+    nlc = np.where(real, nl, i).astype(np.int32)
+    inv = (1.0 / np.maximum(real.sum(1), 1)).astype(np.float32)
+    return nlc, e, inv
+
+
+@pytest.mark.parametrize("N", [8192 + 40, 8192 + 64, 9000])
+def test_window_form_is_the_default_for_inference_on_molecule_batches(gpu_device, monkeypatch, N):
+    """No switch set: with the batch's largest graph announced (ng_ctx_set_graph_span) and no aggregate kept, the forward runs
+    mp_gw_kernel.  The last tile has 40 / 64 / 232 rows: one of its four waves owns every valid row, the others race ahead
+    (the shapes that exposed a missing barrier between the first k-step's gather and the next window request)."""
+    rng = np.random.default_rng(N)
+    K, E = 16, 3
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    w = (rng.standard_normal((F, F, E)) * 0.05).astype(np.float32)
+    nl, e, inv = _graph_local_lists(rng, N, K, E)
+    ref, refS = ref_fwd(h, nl, e, inv, w)
+    ctx = _ctx()
+    monkeypatch.setenv("NG_MP_GG_MIN_ROWS", "1")
+    try:
+        ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, 256), "ng_ctx_set_graph_span")
+        y1, s1 = gpu_fwd(gpu_device, h, nl, e, inv, w)
+        monkeypatch.setenv("NG_MP_GW", "0")
+        y0, s0 = gpu_fwd(gpu_device, h, nl, e, inv, w)
+    finally:
+        ctx.lib.ng_ctx_set_graph_span(ctx.handle, 0)
+    assert not np.array_equal(y0, y1)                    # the default selected the window kernel
+    scale = np.abs(ref).max()
+    assert np.abs(y1 - ref).max() < 3e-6 * scale and np.abs(s1 - refS).max() < 3e-6 * scale
+    assert np.abs(y1 - ref).max() <= 2.0 * np.abs(y0 - ref).max() + 1e-7 * scale
+
+
+def test_window_form_with_lists_longer_than_its_staging_area(gpu_device, monkeypatch):
+    """CSR rows of up to 60 graph-local entries: the first tile's tails (entries 16..) exceed the 480 staged records, the rest
+    is read from memory inside the window form"""
+    rng = np.random.default_rng(11)
+    N, E, G = 1024, 3, 256
+    deg = rng.integers(0, 25, N)
+    deg[:200] = 60
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate([np.sort((r // G) * G + rng.integers(0, G, d)) for r, d in enumerate(deg)]).astype(np.int32)
+    ev = (rng.standard_normal((len(col), E)) * 0.3).astype(np.float32)
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    w = (rng.standard_normal((F, F, E)) * 0.05).astype(np.float32)
+    inv = (1.0 / np.maximum(deg, 1)).astype(np.float32)
+    A = np.zeros((N, E, F))
+    rows = np.repeat(np.arange(N), deg)
+    np.add.at(A, rows, ev.astype(np.float64)[:, :, None] * h.astype(np.float64)[col][:, None, :])
+    P = inv[:, None] * np.einsum('inl,lmn->im', A, w.astype(np.float64))
+    ref = softplus(P) + h
+    monkeypatch.setenv("NG_MP_GG_MIN_ROWS", "1")
+    monkeypatch.setenv("NG_MP_GG", "1")
+    y1, _ = gpu_fwd(gpu_device, h, None, None, inv, w, csr=(rp, col, ev))
+    assert np.abs(y1 - ref).max() < 3e-6 * np.abs(ref).max()
