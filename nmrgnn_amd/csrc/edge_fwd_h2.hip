@@ -74,12 +74,11 @@ struct EdgeH2Args {
 
 // one chunk = 32 wave-instructions of 1 KB; wave w moves KB w, w+8, w+16, w+24 (scalar resource + scalar offset + one
 // lane-offset VGPR)
-__device__ __forceinline__ void h2_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, int cid, char* slot, int wave, int lane) {
+__device__ __forceinline__ void h2_dma_chunk(dma_i4 rsrc, int cid, char* slot, int wave, int lane) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int kb = wave + 8 * j;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(slot + kb * 1024), 16,
-                                             lane * 16, cid * H2_CHUNK + kb * 1024, 0, 0);
+    lds_dma16(rsrc, slot + kb * 1024, lane * 16, cid * H2_CHUNK + kb * 1024);
   }
 }
 
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     }
   }
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, H2_NCHUNK * H2_CHUNK, 0x00020000);
+  const dma_i4 rsrc = dma_rsrc(a.img, (unsigned)(H2_NCHUNK * H2_CHUNK));
   // ring state: chunk id (0..6) and slot of the NEXT chunk to request / to consume
   int req_c = 0, req_s = 0, use_s = 0;
   h2_dma_chunk(rsrc, req_c, ring + req_s * SLOT, wave, lane);

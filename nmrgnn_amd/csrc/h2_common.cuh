@@ -73,4 +73,32 @@ __device__ __forceinline__ void mma3_2a(const u32x4 (&a0)[2], const u32x4 (&a1)[
   acc0 = mfma_f16(a0[0], b[0], acc0); acc1 = mfma_f16(a1[0], b[0], acc1);
 }
 
+
+// ---- LDS-DMA through an asm statement (round 5).  For a `__builtin_amdgcn_raw_ptr_buffer_load_lds` in flight hipcc puts
+// `s_waitcnt vmcnt(N)` in front of every later LDS read it cannot prove disjoint from the copy's destination — the round
+// trip that was meant to run beside a matrix interval comes back at that interval's first operand read
+// (profiles/r05e_gw_ab.txt, r05f_dma_ab.txt).  The statement writes M0 itself and restores it; completion is the KERNEL's
+// business: an explicit `s_waitcnt vmcnt(N)` and a barrier in front of the first read of the copied data.  hipcc's waits
+// for its own loads stay safe (vector memory operations complete in order: they can only wait for more than they need).
+// -DNG_DMA_BUILTIN keeps the builtin (A/B builds).
+typedef int dma_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_i4 dma_rsrc(const void* p, unsigned bytes) {
+  const uint64_t b = (uint64_t)p;
+  return dma_i4{__builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu)),
+                __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+}
+// one 1-KB piece: lane l's 16 bytes from (voff + soff) land at lds_dst + 16 l
+__device__ __forceinline__ void lds_dma16(dma_i4 rs, const void* lds_dst, int voff, int soff) {
+#ifdef NG_DMA_BUILTIN
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)(unsigned)rs[1] << 32) | (unsigned)rs[0]), 0, rs[2], rs[3]);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+  unsigned keep;
+  const int dst = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_dst);
+  const int so = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "v"(voff), "s"(rs), "s"(so) : "memory");
+#endif
+}
+
 }  // namespace ng

@@ -25,25 +25,10 @@
 // Ranges as in mp_gg_kernel: forward operands are split unscaled (|A| >= 65504 raises the guard); the pull's sums are
 // multiplied by S 2^-x (S of dP, 2^x >= max_n sum |e_n| of the row) and the epilogue multiplies the row by 2^x / S.  A
 // raised guard is answered by mp_gg_repair_kernel.
-// LDS-DMA through an asm statement, on purpose: for a `__builtin_amdgcn_raw_ptr_buffer_load_lds` in flight hipcc puts
-// `s_waitcnt vmcnt(0)` in front of EVERY later LDS read it cannot prove disjoint (here: each record and window read of the
-// gather) — the round trip of the W fragments requested two steps ahead came back at the first list entry of every step
-// (profiles/r05e_gw_ab.txt).  The statement writes M0 itself and restores it; completion is counted by the kernel's own
-// `s_waitcnt vmcnt(N)` in front of the barriers (vector memory operations complete in order, so hipcc's waits for its own
-// loads stay safe: they can only wait for more than they need).
-typedef int gw_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ gw_i4 gw_rsrc(const void* p, unsigned bytes) {
-  const uint64_t b = (uint64_t)p;
-  return gw_i4{__builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu)),
-               __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
-}
-__device__ __forceinline__ void gw_dma(gw_i4 rs, const void* lds_dst, int voff, int soff) {
-  unsigned keep;
-  const int dst = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_dst);
-  const int so = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(dst), "v"(voff), "s"(rs), "s"(so) : "memory");
-}
+// (LDS-DMA goes through h2_common.cuh's asm statement: lds_dma16)
+typedef dma_i4 gw_i4;
+__device__ __forceinline__ gw_i4 gw_rsrc(const void* p, unsigned bytes) { return dma_rsrc(p, bytes); }
+__device__ __forceinline__ void gw_dma(gw_i4 rs, const void* lds_dst, int voff, int soff) { lds_dma16(rs, lds_dst, voff, soff); }
 
 #ifdef GW_STAMP
 __device__ unsigned long long gw_stamps[64];

@@ -67,13 +67,11 @@ __device__ __forceinline__ bool win_decide(const int* __restrict__ ctl, int& wlo
 __device__ __forceinline__ void win_dma(float* __restrict__ win, const float* __restrict__ src, int wlo_v, int64_t N, int wave, int lane) {
   const int wlo = __builtin_amdgcn_readfirstlane(wlo_v);
   const int64_t rows = std::min<int64_t>(N - wlo, WROWS);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)wlo * WF), 0, (int)(rows * (WF * 4)), 0x00020000);
+  const dma_i4 rs = dma_rsrc(src + (int64_t)wlo * WF, (unsigned)(rows * (WF * 4)));
 #pragma unroll
   for (int j = 0; j < (WROWS * WF * 4 / 1024 + NW - 1) / NW; ++j) {
     const int kb = wave + NW * j;
-    if (kb < WROWS * WF * 4 / 1024)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
-                                               lane * 16, kb * 1024, 0, 0);
+    if (kb < WROWS * WF * 4 / 1024) lds_dma16(rs, reinterpret_cast<char*>(win) + kb * 1024, lane * 16, kb * 1024);
   }
 }
 

@@ -93,12 +93,11 @@ __device__ __forceinline__ void win_stage(float4* __restrict__ win4, const float
 // reads the old window any more and awaited (s_waitcnt vmcnt(0)) in front of the barrier before the next gather: the
 // HBM / L2 round trip runs beside the matrix interval.  Rows past the end read as zeros (buffer bounds).  32-bit byte
 // offsets: up to 16.7 M rows, beyond that the register staging above.
-__device__ __forceinline__ void win_dma(float* __restrict__ win, __amdgpu_buffer_rsrc_t rs, int wlo, int wave, int lane) {
+__device__ __forceinline__ void win_dma(float* __restrict__ win, dma_i4 rs, int wlo, int wave, int lane) {
 #pragma unroll
   for (int j = 0; j < WROWS * WF * 4 / 1024 / 8; ++j) {
     const int kb = wave + 8 * j;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(win) + kb * 1024), 16,
-                                             lane * 16, wlo * (WF * 4) + kb * 1024, 0, 0);
+    lds_dma16(rs, reinterpret_cast<char*>(win) + kb * 1024, lane * 16, wlo * (WF * 4) + kb * 1024);
   }
 }
 static_assert(WROWS * WF * 4 == 72 * 1024 && WTHREADS == 512, "win_dma: nine 1-KB instructions for each of eight waves");
@@ -227,7 +226,7 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
   float4* win4 = reinterpret_cast<float4*>(win);
   for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
   const bool dma_ok = a.N * (int64_t)(WF * 4) < ((int64_t)1 << 32);
-  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h, 0, dma_ok ? (int)(unsigned)(a.N * (WF * 4)) : 0, 0x00020000);
+  const dma_i4 hrsrc = dma_rsrc(a.h, dma_ok ? (unsigned)(a.N * (WF * 4)) : 0u);
 
   // weight fragments: this wave's NCT column tiles of dA (o = 16*ct + ...), contraction over m (4 k-steps)
   const int hh = wave >> 2, ct0 = (wave & 3) * NCT;
@@ -622,7 +621,7 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
   float4* win4 = reinterpret_cast<float4*>(win);
   for (int t = tid; t < WROWS * WC4; t += WTHREADS) win4[t] = f4zero();
   const bool dma_ok = a.N * (int64_t)(WF * 4) < ((int64_t)1 << 32);
-  const __amdgpu_buffer_rsrc_t psrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dP, 0, dma_ok ? (int)(unsigned)(a.N * (WF * 4)) : 0, 0x00020000);
+  const dma_i4 psrc = dma_rsrc(a.dP, dma_ok ? (unsigned)(a.N * (WF * 4)) : 0u);
 
   const int ct = wave & 3, hh = wave >> 2;      // dh: column tile, atom half;  dw: l-tile ct, column half hh
   float wf[H2 ? 1 : KF / 4];

@@ -48,7 +48,9 @@ def ref_fwd(h, nl, e, inv, w, act=True):
     return S + h, S
 
 
-def gpu_fwd(dev, h, nl, e, inv, w, act=1, csr=None):
+def gpu_fwd(dev, h, nl, e, inv, w, act=1, csr=None, span=0):
+    """span: the largest graph of the batch as ng_ctx_set_graph_span announces it (0 = unknown: the context is shared with the
+    other test modules, whose engines leave their last batch's value behind)"""
     import torch
     from nmrgnn_amd._lib import ptr
     t = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
@@ -58,6 +60,7 @@ def gpu_fwd(dev, h, nl, e, inv, w, act=1, csr=None):
     out = torch.full((N, F), 7.0, device=dev)
     S = torch.full((N, F), 7.0, device=dev)
     ctx = _ctx()
+    ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, span), "ng_ctx_set_graph_span")
     if csr is None:
         tn, te = t(nl, np.int32), t(e.reshape(-1, E))
         ctx.check(ctx.lib.ng_mp_layer_fwd(ctx.handle, _st(dev), N, K, F, E, act, 1, ptr(th), ptr(tn), ptr(te), ptr(tinv),
@@ -141,6 +144,7 @@ def _layer_bwd(dev, N, K, E, h, nl, e, inv, w, S, dH, accum_de=None):
     de = torch.full((N * K, E), 7.0, device=dev)
     dw = torch.full((F, F, E), 7.0, device=dev)
     ctx = _ctx()
+    ctx.lib.ng_ctx_set_graph_span(ctx.handle, 0)
     rec = torch.empty(N * K, 4, device=dev)
     ctx.check(ctx.lib.ng_mp_edge_records(ctx.handle, _st(dev), N, K, E, ptr(csc_ptr), ptr(csc_edge), ptr(te), ptr(rec)), "rec")
     ctx.check(ctx.lib.ng_mp_layer_bwd_rec(ctx.handle, _st(dev), N, K, F, E, 1, ptr(th), ptr(tn), ptr(te), ptr(tinv), ptr(tw),
@@ -277,15 +281,11 @@ def test_window_form_is_the_default_for_inference_on_molecule_batches(gpu_device
     w = (rng.standard_normal((F, F, E)) * 0.05).astype(np.float32)
     nl, e, inv = _graph_local_lists(rng, N, K, E)
     ref, refS = ref_fwd(h, nl, e, inv, w)
-    ctx = _ctx()
     monkeypatch.setenv("NG_MP_GG_MIN_ROWS", "1")
-    try:
-        ctx.check(ctx.lib.ng_ctx_set_graph_span(ctx.handle, 256), "ng_ctx_set_graph_span")
-        y1, s1 = gpu_fwd(gpu_device, h, nl, e, inv, w)
-        monkeypatch.setenv("NG_MP_GW", "0")
-        y0, s0 = gpu_fwd(gpu_device, h, nl, e, inv, w)
-    finally:
-        ctx.lib.ng_ctx_set_graph_span(ctx.handle, 0)
+    y1, s1 = gpu_fwd(gpu_device, h, nl, e, inv, w, span=256)
+    monkeypatch.setenv("NG_MP_GW", "0")
+    y0, s0 = gpu_fwd(gpu_device, h, nl, e, inv, w, span=256)
+    _ctx().lib.ng_ctx_set_graph_span(_ctx().handle, 0)
     assert not np.array_equal(y0, y1)                    # the default selected the window kernel
     scale = np.abs(ref).max()
     assert np.abs(y1 - ref).max() < 3e-6 * scale and np.abs(s1 - refS).max() < 3e-6 * scale
