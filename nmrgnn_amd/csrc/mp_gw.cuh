@@ -122,7 +122,7 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
     const int q = phys(tid, j, sob);
     if (q != GW_ZERO) {
       const int sidx = __builtin_bit_cast(int, srec[q].x);
-      srec[q].x = __builtin_bit_cast(float, winok ? (sidx - wlo) * 64 : sidx * (F * 4));
+      srec[q].x = __builtin_bit_cast(float, winok ? ((sidx - wlo) * 64) | ((((sidx - wlo) >> 2) & 3) << 4) : sidx * (F * 4));
     }
   }
   GW_T(1);
@@ -205,7 +205,9 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       const int i = wave * 5 + q;
-      const unsigned vo = (unsigned)(wlo + 16 * i + (lane >> 2)) * (unsigned)(F * 4) + (unsigned)((lane & 3) * 16 + kk * 64);
+      // 16-byte piece q of window row r sits at position q ^ ((r >> 2) & 3): rows 4 apart share their banks (64-byte rows), the
+      // swizzle spreads the same piece of such rows over four positions (the gather's row reads: 8-way -> 2-way conflicts)
+      const unsigned vo = (unsigned)(wlo + 16 * i + (lane >> 2)) * (unsigned)(F * 4) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3)) * 16) + kk * 64);
       gw_dma(dmaG, dst + i * 1024, (int)vo, 0);
     }
   };
@@ -255,14 +257,15 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
     // requests of slot t: value rows of entry t - 1, records of entry t
     auto slot_loads = [&](auto Tc, int t, int kk, bool on) __attribute__((always_inline)) {
       constexpr int T = decltype(Tc)::value;
-      const char* wb = win + (kk & 1) * GW_WINB + 32 * half;
+      const char* wb = win + (kk & 1) * GW_WINB;
       const int so = __builtin_amdgcn_readfirstlane(kk * 64);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int off = __builtin_bit_cast(int, rec[(T + 2) % 3][b].x);
-        if (WIN) {
-          val[T % 2][b][0] = *reinterpret_cast<const gw_f4*>(wb + off);
-          val[T % 2][b][1] = *reinterpret_cast<const gw_f4*>(wb + off + 16);
+        if (WIN) {      // pieces 2 half and 2 half + 1 of the row, at their swizzled positions
+          const int o0 = off ^ (half << 5);
+          val[T % 2][b][0] = *reinterpret_cast<const gw_f4*>(wb + o0);
+          val[T % 2][b][1] = *reinterpret_cast<const gw_f4*>(wb + (o0 ^ 16));
         } else {
           val[T % 2][b][0] = __builtin_bit_cast(gw_f4, __builtin_amdgcn_raw_buffer_load_b128(rsG, off + 32 * half, so, 0));
           val[T % 2][b][1] = __builtin_bit_cast(gw_f4, __builtin_amdgcn_raw_buffer_load_b128(rsG, off + 32 * half + 16, so, 0));
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
     };
     auto spill_entries = [&](int kk, int j0, int j1, float (&s)[2][E][8]) __attribute__((always_inline)) {
       if (!overflow) return;        // a tile whose rows' tails (entries 16..) exceed GW_CAPB: the rest from memory
-      const char* wb = win + (kk & 1) * GW_WINB + 32 * half;
+      const char* wbs = win + (kk & 1) * GW_WINB;
       const int so = __builtin_amdgcn_readfirstlane(kk * 64);
 #pragma unroll 1
       for (int j = max(j0, 16); j < j1; ++j)
@@ -314,8 +317,9 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
             const int sr = __builtin_bit_cast(int, e4.x);
             gw_f4 v0, v1;
             if (WIN) {
-              v0 = *reinterpret_cast<const gw_f4*>(wb + (sr - wlo) * 64);
-              v1 = *reinterpret_cast<const gw_f4*>(wb + (sr - wlo) * 64 + 16);
+              const int o0 = (((sr - wlo) * 64) | ((((sr - wlo) >> 2) & 3) << 4)) ^ (half << 5);
+              v0 = *reinterpret_cast<const gw_f4*>(wbs + o0);
+              v1 = *reinterpret_cast<const gw_f4*>(wbs + (o0 ^ 16));
             } else {
               v0 = __builtin_bit_cast(gw_f4, __builtin_amdgcn_raw_buffer_load_b128(rsG, sr * (F * 4) + 32 * half, so, 0));
               v1 = __builtin_bit_cast(gw_f4, __builtin_amdgcn_raw_buffer_load_b128(rsG, sr * (F * 4) + 32 * half + 16, so, 0));
