@@ -3,10 +3,12 @@
 TAG=${1:-r02b}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+# PMC passes first: the bench line below prints their traffic / pipe numbers only when they describe the current kernel sources
 bash tools/profile_bench.sh ${TAG} > gpurun_out/${TAG}_prof.log 2>&1
 bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1
 bash tools/pmc_mfma.sh > gpurun_out/${TAG}_pmc_mfma.log 2>&1
+cp gpurun_out/pmc_traffic.json gpurun_out/pmc_mfma.json profiles/
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 # the same step at the reference's default width: per-kernel table, rocprof stats, PMC
 python tools/f256_ab.py > gpurun_out/${TAG}_f256_table.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_f256 -o f256 -- python tools/f256_ab.py > /dev/null 2>&1
