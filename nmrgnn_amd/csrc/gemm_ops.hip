@@ -119,8 +119,14 @@ template <int BM, int BN, int WM, int WN, bool QKC, bool PKC, class LQ, class LP
 static void launch_gemm(hipStream_t st, int64_t M, int N, int64_t K, int64_t k_chunk, int nz,
                         LQ lq, LP lp, EP ep, RangeGuard guard = RangeGuard{nullptr, 0}) {
   dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN), (unsigned)nz);
+  if (guard.word) {      // range fallback: a small grid that walks the tiles only if the guard was raised (mfma_gemm.cuh)
+    const uint64_t ntile = (uint64_t)grid.x * grid.y * grid.z;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, 32, WM, WN, QKC, PKC, LQ, LP, EP>), dim3((unsigned)std::min<uint64_t>(ntile, 512)), dim3(256), 0,
+                       st, M, N, K, k_chunk, lq, lp, ep, guard.word, guard.epoch, grid.x, grid.y, grid.z);
+    return;
+  }
   hipLaunchKernelGGL((gemm_kernel<BM, BN, 32, WM, WN, QKC, PKC, LQ, LP, EP>), grid, dim3(256), 0,
-                     st, M, N, K, k_chunk, lq, lp, ep, guard.word, guard.epoch);
+                     st, M, N, K, k_chunk, lq, lp, ep, guard.word, guard.epoch, 0u, 0u, 0u);
 }
 
 int dense_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int act, const float* X,

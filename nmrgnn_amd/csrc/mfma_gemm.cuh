@@ -129,9 +129,21 @@ struct GemmTile {
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool Q_KC, bool P_KC, class LoadQ,
           class LoadP, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int N, int64_t K, int64_t k_chunk,
-                                                   LoadQ lq, LoadP lp, Epi epi, unsigned* guard_word, unsigned guard_epoch) {
-  // range fallback of a split-operand GEMM (ng_internal.h: RangeGuard): run only if that kernel raised the guard
+                                                   LoadQ lq, LoadP lp, Epi epi, unsigned* guard_word, unsigned guard_epoch,
+                                                   unsigned tgx, unsigned tgy, unsigned tgz) {
+  // range fallback of a split-operand GEMM (ng_internal.h: RangeGuard): run only if that kernel raised the guard.  Launched
+  // with a SMALL one-dimensional grid whose workgroups walk the (tgx, tgy, tgz) tile grid — a fallback that does not run
+  // should cost the dispatch of a few hundred workgroups, not of the product's thousands (6.4 us per launch, 24 per step at
+  // the default width).  tgx == 0: the ordinary launch, one workgroup per tile.
   if (guard_word && __hip_atomic_load(guard_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != guard_epoch) return;
+  const uint64_t ntile = tgx ? (uint64_t)tgx * tgy * tgz : 0;
+  uint64_t tile = blockIdx.x;
+  if (tgx && tile >= ntile) return;
+#pragma unroll 1
+  for (;;) {
+  const unsigned bix = tgx ? (unsigned)(tile % tgx) : blockIdx.x;
+  const unsigned biy = tgx ? (unsigned)((tile / tgx) % tgy) : blockIdx.y;
+  const unsigned biz = tgx ? (unsigned)(tile / ((uint64_t)tgx * tgy)) : blockIdx.z;
   using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, Q_KC, P_KC>;
   __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
   float* sQ = smem;
@@ -145,9 +157,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int N, int64_t K, 
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int64_t k_begin = (int64_t)blockIdx.z * k_chunk;
+  const int64_t m0 = (int64_t)bix * BM;
+  const int n0 = biy * BN;
+  const int64_t k_begin = (int64_t)biz * k_chunk;
   int64_t k_end = k_begin + k_chunk;
   if (k_end > K) k_end = K;
 
@@ -255,10 +267,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int N, int64_t K, 
         if (m < M && n < N) {
           epi(m, n, make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
                                 acc[i][j][4 * q + 3]),
-              (int)blockIdx.z);
+              (int)biz);
         }
       }
     }
+  }
+  if (!tgx) break;
+  tile += gridDim.x;
+  if (tile >= ntile) break;
+  __syncthreads();        // the next tile's operands overwrite this one's in LDS
   }
 }
 
