@@ -164,17 +164,37 @@ __global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, 
   long long* p = part + (size_t)blockIdx.x * T * EC;
   for (int t = threadIdx.x; t < T * EC; t += ET_BLOCK) p[t] = et_q[t];
 }
+// 64 table entries per workgroup, four groups of 64 threads each summing a quarter of the workgroups' partial tables (eight
+// loads in flight; one thread walking all 256 partials of its entry was a chain of dependent round trips: 62 us).  Integer
+// sums: any order gives the same bits.
 __global__ __launch_bounds__(ET_BLOCK) void et_scatter_final_kernel(int nb, int TE, const long long* __restrict__ part,
                                                                   const float* __restrict__ range, float* __restrict__ de_tab) {
-  const int t = blockIdx.x * ET_BLOCK + threadIdx.x;
-  if (t >= TE) return;
+  __shared__ long long red[ET_BLOCK];
+  const int tt = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tt;
   long long s = 0;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * TE + t];
-  const float mx = range[2];
-  int ex = 0;
-  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex);
-  de_tab[t] = (float)((double)s * ldexp(1.0, ex - 38));
+  if (t < TE) {
+    int b = g;
+    for (; b + 28 < nb; b += 32) {
+      long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * TE + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nb; b += 4) s += part[(size_t)b * TE + t];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && t < TE) {
+    s = red[tt] + red[64 + tt] + red[128 + tt] + red[192 + tt];
+    const float mx = range[2];
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex);
+    de_tab[t] = (float)((double)s * ldexp(1.0, ex - 38));
+  }
 }
+static_assert(ET_BLOCK == 256, "et_scatter_final_kernel: four groups of 64");
 
 static int et_blocks(ng_ctx* ctx, int64_t n) { return (int)std::min<int64_t>(cdiv(n, ET_BLOCK), (int64_t)ctx->num_cu * 4); }
 
@@ -242,7 +262,7 @@ extern "C" int ng_edge_table_scatter(ng_ctx* ctx, void* stream, int64_t n, int E
     case 3: hipLaunchKernelGGL((et_scatter_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, de, part); break;
     default: hipLaunchKernelGGL((et_scatter_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, de, part); break;
   }
-  hipLaunchKernelGGL(et_scatter_final_kernel, dim3((unsigned)cdiv(T * E, ET_BLOCK)), dim3(ET_BLOCK), 0, st, nb, T * E, part, range, de_tab);
+  hipLaunchKernelGGL(et_scatter_final_kernel, dim3((unsigned)cdiv(T * E, 64)), dim3(ET_BLOCK), 0, st, nb, T * E, part, range, de_tab);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
