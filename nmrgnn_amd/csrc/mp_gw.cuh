@@ -90,6 +90,27 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
     return j < 16 ? j * GW_BM + r : (ob + j - 16 < GW_CAPB ? GW_CAPA + ob + j - 16 : GW_ZERO);
   };
   int lo = 0x7fffffff, hi = -1;
+  if (LK == GG_PADDED && E == 3 && a.Kpad == 16) {
+    // the common padded form: a row's 16 sources (64 B) and 48 weights (192 B) as sixteen 16-byte loads instead of 64 scalar ones
+    if (sdeg > 0) {
+      int4 nl4[4];
+      float4 ew4[12];
+      const int4* pn = reinterpret_cast<const int4*>(a.idx + sp0);
+      const float4* pe = reinterpret_cast<const float4*>(a.ew + sp0 * 3);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nl4[u] = pn[u];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) ew4[u] = pe[u];
+      const int* nli = reinterpret_cast<const int*>(nl4);
+      const float* ewf = reinterpret_cast<const float*>(ew4);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int sidx = nli[j];
+        lo = min(lo, sidx); hi = max(hi, sidx);
+        srec[j * GW_BM + tid] = make_float4(__builtin_bit_cast(float, sidx), ewf[3 * j], ewf[3 * j + 1], ewf[3 * j + 2]);
+      }
+    }
+  } else
   for (int j0 = 0; j0 < sdeg; j0 += 4) {       // four entries in flight
     float4 e4[4];
 #pragma unroll
@@ -279,11 +300,23 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
       constexpr int T = decltype(Tc)::value;
       const float4& rc = rec[(T + 1) % 3][b];
       const float w1 = n == 0 ? rc.y : (n == 1 ? rc.z : rc.w);
+#ifdef GW_PK
+      const gw_f2 ww = {w1, w1};
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          gw_f2 p = {s[b][n][4 * hq + 2 * u], s[b][n][4 * hq + 2 * u + 1]};
+          p = __builtin_elementwise_fma(ww, gw_f2{val[(T + 1) % 2][b][hq][2 * u], val[(T + 1) % 2][b][hq][2 * u + 1]}, p);
+          s[b][n][4 * hq + 2 * u] = p[0]; s[b][n][4 * hq + 2 * u + 1] = p[1];
+        }
+#else
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         s[b][n][t] = fmaf(w1, val[(T + 1) % 2][b][0][t], s[b][n][t]);
         s[b][n][4 + t] = fmaf(w1, val[(T + 1) % 2][b][1][t], s[b][n][4 + t]);
       }
+#endif
     };
     auto slot = [&](auto Tc, int t, int kk, float (&s)[2][E][8], bool on = true) __attribute__((always_inline)) {
       slot_loads(Tc, t, kk, on);
