@@ -71,8 +71,11 @@ int ng_flush_reductions(ng_ctx* ctx, void* stream);
 /* Hint about the batch the following calls work on: the largest number of atoms of one member graph (the reference
  * concatenates molecules with offset neighbour indices, nmrgnn/library.py:106-117, so a neighbour index lies within its
  * own graph).  0 = unknown (default).  With 0 < span <= 272 the default-width neighbour aggregation (F % 128 == 0) keeps
- * slab windows of the gathered rows in LDS; larger or unknown spans (whole proteins) take the L2-gather kernel.  Results
- * do not depend on the hint. */
+ * slab windows of the gathered rows in LDS; larger or unknown spans (whole proteins) take the L2-gather kernel.  With
+ * 0 < span <= 256, F = 256, E = 3 and no aggregate kept (a_save == NULL: inference) ng_mp_layer_fwd(_csr) runs the window
+ * gather-GEMM (csrc/mp_gw.cuh: the aggregate never reaches HBM); the backward's scatter-sum takes its LDS row-block form for
+ * span <= 288.  Every kernel checks per tile that its window really holds the tile's sources and reads the others from
+ * memory: results do not depend on the hint, a wrong hint only costs time. */
 int ng_ctx_set_graph_span(ng_ctx* ctx, int64_t max_graph_atoms);
 /* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
 int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
