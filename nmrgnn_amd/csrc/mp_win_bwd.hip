@@ -591,6 +591,12 @@ __device__ __noinline__ void node_gather_global(int wave, int lane, const int* s
   node_gather<E, 1>(wave, lane, 0, s_ptr, recs, rec_base, tb, ld, nullptr, src4, pl, rs, sbv, wmin);
 }
 
+#ifdef WN_STAMP
+__device__ unsigned long long wn_stamps[64];
+#define WN_T(i) do { if (blockIdx.x == 100 && threadIdx.x == 0 && t == T0 + 2) wn_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WN_T(i) do { } while (0)
+#endif
 template <int E, bool H2>
 __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
   constexpr int KF = E * WF;
@@ -708,9 +714,11 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
       // requests for t+2.  Nothing freshly requested may be live across the gather: its out-of-line
       // global-memory variant is a call, and registers live across a call are saved to scratch — with a
       // vmcnt wait on the loads that fill them (measured: the prefetch latency came back every tile).
+      WN_T(0);
       *reinterpret_cast<float4*>(htile + (tid >> 4) * SDP_LD + 4 * (tid & 15)) = p_h;
       const float4 dHc = p_dH;
       if (t + 1 < T1) commit(t + 1);
+      WN_T(1);
       {
         const int* pp = s_ptr + (t & 1) * 36;
         const float4* rc = s_rec + (t & 1) * NREC_CAP;
@@ -722,9 +730,12 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
         else if (fits) node_gather_global<E>(wave, lane, pp, rc, rec_base, tile, LD, src4, pl, s_rs, s_sb, s_wmin);
         else node_gather_global<E>(wave, lane, pp, a.rec + rec_base, rec_base, tile, LD, src4, pl, s_rs, s_sb, s_wmin);
       }
+      WN_T(2);
       issue(t + 2 < T1 ? t + 2 : t);
       issue_rows(t + 1 < T1 ? t + 1 : t);
+      WN_T(3);
       NG_LDS_BARRIER();
+      WN_T(4);
       // the next tile's window, when it needs one: every gather of this tile is done and the range of t + 1 was published
       // before the barrier; nothing reads the window until the gather behind the interval's last barrier
       bool restage = false;
@@ -778,6 +789,7 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        WN_T(5);
         const int64_t row = t * WTA + 16 * hh + a16;
         const float4 v = make_float4(fmaf(acc0[0] + acc1[0], osc, dHc.x), fmaf(acc0[1] + acc1[1], osc, dHc.y),
                                      fmaf(acc0[2] + acc1[2], osc, dHc.z), fmaf(acc0[3] + acc1[3], osc, dHc.w));
@@ -857,8 +869,10 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
             accW[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb[ro * LD + 16 * u], accW[u], 0, 0, 0);
         }
       }
+      WN_T(6);
       if (restage && dma_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       NG_LDS_BARRIER();
+      WN_T(7);
     }
   }
   // ---- dw partial of this workgroup, layout [(n,m)][l]: lane holds l = 16ct + 4(lane>>4) + r, column = 16(NCT*hh+u) + (lane&15)
@@ -979,6 +993,15 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
     ProfScope ps(ctx, st, "mp_win_bwd_node");
     if (h2) { NODE(true) } else { NODE(false) }
     NG_HIP(ctx, hipGetLastError());
+#ifdef WN_STAMP
+    if (getenv("NG_WN_STAMP")) {
+      unsigned long long hs[64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(wn_stamps), sizeof(hs));
+      fprintf(stderr, "wn tiles/wg %d: store+commit %llu gather %llu issue %llu barrier %llu dh %llu dw %llu barrier %llu\n", a.tiles_per_wg,
+              hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[6] - hs[5], hs[7] - hs[6]);
+    }
+#endif
   }
 #undef NODE
   ProfScope ps(ctx, st, "reduce_partials");
