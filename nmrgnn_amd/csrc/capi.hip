@@ -37,6 +37,7 @@ static void load_switches() {
   s.knn_brute = env_is("NG_KNN", "brute");
   s.mp_gg_on = env_is("NG_MP_GG", "1");
   s.mp_gw = !env_is("NG_MP_GW", "0");
+  s.mp_gw_nowin = env_is("NG_MP_GW", "nowin");
   s.mp_w16 = !env_is("NG_MP_W16", "0");
   s.reduce_narrow = env_is("NG_REDUCE", "narrow");
   if (const char* v = getenv("NG_MP_GG_MIN_ROWS")) { const long long r = atoll(v); if (r >= 1) s.mp_gg_min_rows = r; }

@@ -1092,6 +1092,7 @@ struct GgArgs {
   int act;
   float* A_out;            // forward, training: the aggregate [M][E*F] as a by-product (the backward's dw = A^T dP reads it), or nullptr
   const float* gscale;     // GRAD: {S, 1/S} of the gathered operand
+  int no_window;           // mp_gw_kernel: take the memory path for every tile (NG_MP_GW=nowin)
   RangeGuard guard;
 };
 
@@ -1420,6 +1421,7 @@ static int gg_launch(ng_ctx* ctx, hipStream_t st, GgArgs& a, int E, const char* 
   const unsigned grid = (unsigned)cdiv(a.M, GX_BM);
   if (gw_ok(a, E)) {
     ProfScope ps(ctx, st, tag);
+    a.no_window = sw().mp_gw_nowin ? 1 : 0;
     const unsigned wgrid = (unsigned)cdiv(a.M, GW_BM);
     if (LK == GG_PADDED && a.Kpad <= 16)
       hipLaunchKernelGGL((mp_gw_kernel<LK, 3, GRAD, 6>), dim3(wgrid), dim3(GW_THREADS), GW_LDS, st, a);

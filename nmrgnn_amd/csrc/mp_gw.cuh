@@ -132,7 +132,7 @@ __global__ __launch_bounds__(GW_THREADS, 1) void mp_gw_kernel(GgArgs a) {
   tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
   const bool none = thi < tlo;
   const int wlo = none ? 0 : tlo;
-  const bool winok = none || thi - tlo < GW_WROWS;
+  const bool winok = !a.no_window && (none || thi - tlo < GW_WROWS);
   // the zero record (past a row's end): weights 0 and a source that reads as zeros whatever the array holds
   if (tid == 0) srec[GW_ZERO] = make_float4(__builtin_bit_cast(float, winok ? GW_WROWS * 64 : GW_OOB), 0.f, 0.f, 0.f);
   if (tid < 32) {

@@ -314,3 +314,28 @@ def test_window_form_with_lists_longer_than_its_staging_area(gpu_device, monkeyp
     monkeypatch.setenv("NG_MP_GG", "1")
     y1, _ = gpu_fwd(gpu_device, h, None, None, inv, w, csr=(rp, col, ev))
     assert np.abs(y1 - ref).max() < 3e-6 * np.abs(ref).max()
+
+
+def test_window_and_memory_paths_of_the_window_form_give_the_same_bits(gpu_device, monkeypatch):
+    """A tile whose sources do not fit the LDS window reads them from memory with the same code: same entries in the same
+    order, same arithmetic.  NG_MP_GW=nowin sends every tile down that path: forward and pull must not move by a bit; and a
+    second run of either is bit-identical (no atomics, no order left to the scheduler)."""
+    rng = np.random.default_rng(77)
+    N, K, E = 2048 + 100, 16, 3
+    h = rng.standard_normal((N, F)).astype(np.float32)
+    w = (rng.standard_normal((F, F, E)) * 0.05).astype(np.float32)
+    nl, e, inv = _graph_local_lists(rng, N, K, E)
+    monkeypatch.setenv("NG_MP_GG_MIN_ROWS", "1")
+    monkeypatch.setenv("NG_MP_GG", "1")
+    y_win, s_win = gpu_fwd(gpu_device, h, nl, e, inv, w)
+    y_again, _ = gpu_fwd(gpu_device, h, nl, e, inv, w)
+    dH = rng.standard_normal((N, F)).astype(np.float32)
+    S = s_win.astype(np.float32)
+    g_win = _layer_bwd(gpu_device, N, K, E, h, nl, e, inv, w, S, dH)
+    monkeypatch.setenv("NG_MP_GW", "nowin")
+    y_mem, s_mem = gpu_fwd(gpu_device, h, nl, e, inv, w)
+    g_mem = _layer_bwd(gpu_device, N, K, E, h, nl, e, inv, w, S, dH)
+    assert np.array_equal(y_win, y_again)
+    assert np.array_equal(y_win, y_mem) and np.array_equal(s_win, s_mem)
+    for a, b in zip(g_win, g_mem):
+        assert np.array_equal(a, b)
