@@ -39,6 +39,7 @@ static void load_switches() {
   s.mp_gw = !env_is("NG_MP_GW", "0");
   s.mp_gw_nowin = env_is("NG_MP_GW", "nowin");
   s.mp_w16 = !env_is("NG_MP_W16", "0");
+  s.mp_wave = env_is("NG_MP_WAVE", "1") ? 1 : (env_is("NG_MP_WAVE", "0") ? 0 : -1);
   s.reduce_narrow = env_is("NG_REDUCE", "narrow");
   if (const char* v = getenv("NG_MP_GG_MIN_ROWS")) { const long long r = atoll(v); if (r >= 1) s.mp_gg_min_rows = r; }
   g_sw = s;

@@ -1092,6 +1092,8 @@ int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, in
     if (int rc = pack_launch(ctx, st, j)) return rc;
     if (cached) cache_set_job(ctx, w, h2 ? 7 : 4, j);
   }
+  if (h2 && sw().mp_w16 && mp_wave_wanted(ctx, N, E, K))
+    return mp_wave_launch(ctx, st, N, K, act, residual, h, nlist, e, inv_degree, Wfrag, Wf32, wflag, guard, h_out, s_save);
   if (h2 && sw().mp_w16 && mp_win16_supported(E, K))
     return mp_win16_launch(ctx, st, N, K, E, act, residual, h, nlist, e, inv_degree, Wfrag, Wf32, wflag, guard, h_out, s_save);
   MpWinFwdArgs a{};

@@ -129,6 +129,7 @@ struct Switches {
   bool mp_gg_on = false;             // NG_MP_GG=1
   bool mp_gw_nowin = false;          // NG_MP_GW=nowin: the window form reads every tile's sources from memory (tests: same bits as the window)
   bool mp_gw = true;                 // NG_MP_GW=0: the gather-GEMM keeps round 4's producer / consumer kernel (mp_gg_kernel) instead of the window form (mp_gw.cuh)
+  int mp_wave = -1;                  // NG_MP_WAVE=1 / 0: the wave-autonomous forward window kernel (mp_wave.hip) for every supported call / for none (default: batches that fill the chip)
   bool mp_w16 = true;                // NG_MP_W16=0: the eight-wave forward window kernel instead of the 16-wave one (mp_win16.hip)
   bool reduce_narrow = false;        // NG_REDUCE=narrow: second-stage reductions 64 elements per block at every size (reduce.cuh)
   bool knn_lanes = false;            // NG_KNN=lanes

@@ -208,6 +208,12 @@ bool mp_win16_supported(int E, int K);
 int mp_win16_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
                     const int32_t* nlist, const float* e, const float* inv_degree, const float* Wfrag, const float* Wf32,
                     const unsigned* wflag, RangeGuard guard, float* h_out, float* s_save);
+// wave-autonomous form of the forward window kernel (mp_wave.hip; round 6; default for E == 3 on batches that fill the chip,
+// NG_MP_WAVE=1 / 0: always / never), launched by mp_win_fwd on the same images
+bool mp_wave_wanted(const ng_ctx* ctx, int64_t N, int E, int K);
+int mp_wave_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int act, int residual, const float* h, const int32_t* nlist,
+                   const float* e, const float* inv_degree, const float* Wfrag, const float* Wf32, const unsigned* wflag,
+                   RangeGuard guard, float* h_out, float* s_save);
 int mp_win_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, int residual, const float* h,
                const int32_t* nlist, const float* e, const float* inv_degree, const float* w, float* h_out,
                float* s_save);
