@@ -74,9 +74,11 @@ struct Args {
 // [group 0..1][micro-tile 0..1][wave][slot]
 #define WV_T(k) do { if (a.stamps && blockIdx.x == 3 && lane == 0) a.stamps[(((int)((g0 - A0) / GROUP) * 2 + i) * NWV + wave) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #define WV_G(k) do { if (a.stamps && blockIdx.x == 3 && lane == 0) a.stamps[4 * NWV * 8 + ((int)((g0 - A0) / GROUP) * NWV + wave) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define WV_GN(k) do { if (a.stamps && blockIdx.x == 3 && lane == 0 && g0 == A0) a.stamps[4 * NWV * 8 + (NWV + wave) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WV_T(k) do {} while (0)
 #define WV_G(k) do {} while (0)
+#define WV_GN(k) do {} while (0)
 #endif
 
 // the lists of micro-tile row0 .. row0+15 into the wave's strip; rows past N and pieces past K read as zeros
@@ -130,7 +132,11 @@ __device__ __forceinline__ void gather(const char* __restrict__ strip, const cha
     for (int s = 0; s < 4; ++s) {
       float4 hr[4];
       if (!GLOBAL) {
+#ifdef WV_ABL_SAMEROW      // timing experiment (wrong results): the sixteen lanes of a read group take sixteen consecutive rows — no bank conflicts
+        const int R = (at + 16 * s + (ci[s] & 0)) & 255;
+#else
         const int R = min(max(ci[s] - wlo, 0), WROWS - 1);
+#endif
         const int sw = (R & 15) << 4;
         const char* row = win + (R << 8);
         hr[0] = *reinterpret_cast<const float4*>(row + (kc0 ^ sw));
@@ -177,6 +183,9 @@ __device__ __forceinline__ void body(const Args& a) {
   const int64_t A1 = std::min<int64_t>(A0 + a.atoms_per_wg, a.N);
   if (A0 >= A1) return;
   const float resf = a.residual ? 1.f : 0.f;
+#ifdef WV_STAMP
+  if (a.stamps && tid == 0) a.stamps[1024 + blockIdx.x] = wall_clock64();
+#endif
 
   if (H2) {
     const dma_i4 rw = dma_rsrc(a.Wfrag, WIMG_BYTES);
@@ -189,24 +198,169 @@ __device__ __forceinline__ void body(const Args& a) {
   int64_t have = A0 + (int64_t)wave * MT;          // the micro-tile whose lists the strip holds (or is receiving)
   if (have < A1) lists_dma(a, strip, have, lane);
 
+  // matrix interval + epilogue of a gathered micro-tile: sums -> piece operands in place -> out^T over the six k-steps ->
+  // activation, residual, stores.  `re` = the residual rows if they were taken out of the window already (FROMWIN)
+  float acc[E][16];
+  f32x4 rew[4];
+  auto finish = [&](int64_t row0, bool fromwin, bool wait_lists, int g_i, int64_t g0) __attribute__((always_inline)) {
+    const int i = g_i;
+    (void)i; (void)g0;
+    const int64_t row = row0 + at;
+    const bool live = row < a.N;
+    const int64_t rowc = live ? row : a.N - 1;
+    const float rs = a.rowscale[rowc];
+    f32x4 o[4];
+    float rsx;
+    if (H2) {
+      // a row that reaches 2^15 is scaled by a power of two (never taken for ordinary activations)
+      float m = 0.f;
+#pragma unroll
+      for (int n = 0; n < E; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(acc[n][j]));
+      float rsv = 1.0f;
+      if (__builtin_amdgcn_ballot_w64(m >= 32768.0f) != 0) {
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
+        const bool big = ef >= 127 + 15 && ef != 255;
+        const float S = big ? __builtin_bit_cast(float, (268 - ef) << 23) : 1.0f;
+        rsv = big ? __builtin_bit_cast(float, (ef - 14) << 23) : 1.0f;
+#pragma unroll
+        for (int n = 0; n < E; ++n)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[n][j] *= S;
+      }
+      u32x4 xh[NT2], xl[NT2];
+#pragma unroll
+      for (int n = 0; n < E; ++n)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned hp, lp;
+            split2_pair(acc[n][8 * u + 2 * j], acc[n][8 * u + 2 * j + 1], hp, lp);
+            xh[2 * n + u][j] = hp; xl[2 * n + u][j] = lp;
+          }
+      WV_T(3);
+      // matrix interval: weights as the A operand out of LDS; per k-step the products of the four column tiles interleaved
+      // (consecutive MFMAs on different accumulators)
+      f32x4 acc0[4], acc1[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) { acc0[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const char* wl_base = wimg + (lane << 4);
+#pragma unroll
+      for (int T = 0; T < NT2; ++T) {
+        u32x4 wh[4], wl[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          wh[ct] = *reinterpret_cast<const u32x4*>(wl_base + ((ct * NT2 + T) * 2) * 1024);
+          wl[ct] = *reinterpret_cast<const u32x4*>(wl_base + ((ct * NT2 + T) * 2 + 1) * 1024);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[ct]), __builtin_bit_cast(f16x8, xh[T]), acc0[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[ct]), __builtin_bit_cast(f16x8, xh[T]), acc1[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[ct]), __builtin_bit_cast(f16x8, xl[T]), acc0[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) o[ct] = acc0[ct] + acc1[ct];
+      rsx = rs * (1.0f / 256.0f) * rsv;
+    } else {
+      // weights beyond the fp16 piece range: f32-input MFMA, one contraction index of the lane per instruction, the weight
+      // from the fp32 fragment image (correct, not fast; never run in practice)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < E; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = 64 * n + 32 * (j >> 3) + 8 * kg + (j & 7);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const float wv = a.Wfrag32[((ct * (E * WF / 16) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + at) * 4 + (k & 3)];
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, acc[n][j], o[ct], 0, 0, 0);
+          }
+        }
+      rsx = rs;
+    }
+    WV_T(4);
+    // epilogue: lane (atom, kg) holds out[atom][16 ct + 4 kg .. + 3]
+    f32x4 re[4];
+    if (a.residual && !fromwin) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) re[ct] = *reinterpret_cast<const f32x4*>(a.h + rowc * WF + 16 * ct + 4 * kg);
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) re[ct] = rew[ct];
+    }
+    float4 v[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      v[ct] = make_float4(o[ct][0] * rsx, o[ct][1] * rsx, o[ct][2] * rsx, o[ct][3] * rsx);
+      if (a.act == NG_ACT_SOFTPLUS) {
+        v[ct].x = softplus_f(v[ct].x); v[ct].y = softplus_f(v[ct].y); v[ct].z = softplus_f(v[ct].z); v[ct].w = softplus_f(v[ct].w);
+      } else if (a.act != NG_ACT_NONE) {
+        v[ct].x = act_apply(a.act, v[ct].x); v[ct].y = act_apply(a.act, v[ct].y);
+        v[ct].z = act_apply(a.act, v[ct].z); v[ct].w = act_apply(a.act, v[ct].w);
+      }
+    }
+    WV_T(5);
+    // the prefetched lists have landed long ago; waiting for them HERE (in front of the stores) keeps the stores' own
+    // completion out of the next micro-tile's first wait.  (Not for the micro-tile finished beside a window in flight.)
+    if (wait_lists) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WV_T(6);
+    if (live) {
+      typedef float nt4 __attribute__((ext_vector_type(4)));
+      float* po = a.out + row * WF + 4 * kg;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        *reinterpret_cast<float4*>(po + 16 * ct) = make_float4(v[ct].x + resf * re[ct][0], v[ct].y + resf * re[ct][1],
+                                                               v[ct].z + resf * re[ct][2], v[ct].w + resf * re[ct][3]);
+      if (a.S_save) {
+        // the activation copy is read a millisecond later by the backward: past the caches
+        float* ps = a.S_save + row * WF + 4 * kg;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          __builtin_nontemporal_store(nt4{v[ct].x, v[ct].y, v[ct].z, v[ct].w}, reinterpret_cast<nt4*>(ps + 16 * ct));
+      }
+    }
+    WV_T(7);
+  };
+
 #pragma unroll 1
   for (int64_t g0 = A0; g0 < A1; g0 += GROUP) {
-    // ---- workgroup event: the group's window.  Every wave is through with the old one behind the barrier.
+    // ---- workgroup event: the group's window
     const int64_t wlo64 = std::max<int64_t>(0, std::min<int64_t>(g0 - (WROWS - GROUP) / 2, a.N - WROWS));
     const int wlo = (int)wlo64;      // (window kernels are dispatched for N < 2^31)
-    WV_G(0);
-    if (g0 != A0) NG_LDS_BARRIER();
-    WV_G(1);
-    win_dma(win, a.h, wlo64, a.N, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WV_G(2);
-    NG_LDS_BARRIER();
-    WV_G(3);
+    const bool more = g0 + GROUP < A1;
+    if (g0 == A0) {
+      WV_G(0); WV_G(1);
+      win_dma(win, a.h, wlo64, a.N, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WV_G(2);
+      NG_LDS_BARRIER();
+      WV_G(3);
+    }
+    int64_t drow0 = -1;              // the micro-tile finished behind the group's barrier
+    bool dwin = false;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) rew[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
       const int64_t row0 = g0 + (int64_t)(wave + NWV * i) * MT;
       if (row0 >= A1) break;
+#ifndef WV_NOPRIO
+      // the two waves of a SIMD: the older one wins the issue arbitration; in its second micro-tile the younger one is given
+      // priority, so that both reach the group's barrier together
+      if (i == 1 && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
       if (have != row0) {            // (not reached with the prefetch below; kept so that the strip is right by construction)
         lists_dma(a, strip, row0, lane);
         have = row0;
@@ -226,7 +380,6 @@ __device__ __forceinline__ void body(const Args& a) {
         hi = -__builtin_amdgcn_readlane(w16c::wave_min_i32(-hi), 63);
         inwin = hi < lo || (lo >= wlo && hi < wlo + WROWS);
       }
-      float acc[E][16];
 #pragma unroll
       for (int n = 0; n < E; ++n)
 #pragma unroll
@@ -241,132 +394,47 @@ __device__ __forceinline__ void body(const Args& a) {
         const int64_t nx = row0 + (int64_t)NWV * MT;
         if (nx < A1) { lists_dma(a, strip, nx, lane); have = nx; }
       }
-      const int64_t row = row0 + at;
-      const bool live = row < a.N;
-      const int64_t rowc = live ? row : a.N - 1;
-      const float rs = a.rowscale[rowc];
-
-      f32x4 o[4];
-      float rsx;
-      if (H2) {
-        // ---- piece operands in place; a row that reaches 2^15 is scaled by a power of two (never taken for ordinary activations)
-        float m = 0.f;
+      // the residual rows come out of the window when the micro-tile's own rows are inside (they are, for a window placed
+      // around the group)
+      const bool ownwin = a.residual && row0 >= wlo && row0 + MT <= (int64_t)wlo + WROWS;
+      if (ownwin) {
+        const int R = (int)(row0 - wlo) + at;
+        const char* rp = win + (R << 8);
 #pragma unroll
-        for (int n = 0; n < E; ++n)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(acc[n][j]));
-        float rsv = 1.0f;
-        if (__builtin_amdgcn_ballot_w64(m >= 32768.0f) != 0) {
-          m = fmaxf(m, __shfl_xor(m, 16));
-          m = fmaxf(m, __shfl_xor(m, 32));
-          const int ef = (__builtin_bit_cast(int, m) >> 23) & 255;
-          const bool big = ef >= 127 + 15 && ef != 255;
-          const float S = big ? __builtin_bit_cast(float, (268 - ef) << 23) : 1.0f;
-          rsv = big ? __builtin_bit_cast(float, (ef - 14) << 23) : 1.0f;
-#pragma unroll
-          for (int n = 0; n < E; ++n)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[n][j] *= S;
-        }
-        u32x4 xh[NT2], xl[NT2];
-#pragma unroll
-        for (int n = 0; n < E; ++n)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              unsigned hp, lp;
-              split2_pair(acc[n][8 * u + 2 * j], acc[n][8 * u + 2 * j + 1], hp, lp);
-              xh[2 * n + u][j] = hp; xl[2 * n + u][j] = lp;
-            }
-        WV_T(3);
-        // ---- matrix interval: out^T[16 ct + m][atom] over the six k-steps, weights as the A operand out of LDS
-        f32x4 acc0[4], acc1[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { acc0[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const char* wl_base = wimg + (lane << 4);
-#pragma unroll
-        for (int T = 0; T < NT2; ++T) {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            const u32x4 wh = *reinterpret_cast<const u32x4*>(wl_base + ((ct * NT2 + T) * 2) * 1024);
-            const u32x4 wl = *reinterpret_cast<const u32x4*>(wl_base + ((ct * NT2 + T) * 2 + 1) * 1024);
-            acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl), __builtin_bit_cast(f16x8, xh[T]), acc0[ct], 0, 0, 0);
-            acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh[T]), acc1[ct], 0, 0, 0);
-            acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xl[T]), acc0[ct], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) o[ct] = acc0[ct] + acc1[ct];
-        rsx = rs * (1.0f / 256.0f) * rsv;
-      } else {
-        // weights beyond the fp16 piece range: f32-input MFMA, one contraction index of the lane per instruction, the weight
-        // from the fp32 fragment image (correct, not fast; never run in practice)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < E; ++n)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int k = 64 * n + 32 * (j >> 3) + 8 * kg + (j & 7);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              const float wv = a.Wfrag32[((ct * (E * WF / 16) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + at) * 4 + (k & 3)];
-              o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, acc[n][j], o[ct], 0, 0, 0);
-            }
-          }
-        rsx = rs;
+        for (int ct = 0; ct < 4; ++ct) rew[ct] = *reinterpret_cast<const f32x4*>(rp + (((4 * ct + kg) ^ (R & 15)) << 4));
       }
-      WV_T(4);
-      // ---- epilogue: lane (atom, kg) holds out[atom][16 ct + 4 kg .. + 3]; the residual row comes out of the window when
-      // the micro-tile's own rows are inside (they are, for a window placed around the group)
-      const bool ownwin = row0 >= wlo && row0 + MT <= (int64_t)wlo + WROWS;
-      float4 re[4];
-      if (a.residual) {
-        if (ownwin) {
-          const int R = (int)(row0 - wlo) + at;
-          const char* rp = win + (R << 8);
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) re[ct] = *reinterpret_cast<const float4*>(rp + (((4 * ct + kg) ^ (R & 15)) << 4));
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) re[ct] = *reinterpret_cast<const float4*>(a.h + rowc * WF + 16 * ct + 4 * kg);
-        }
-      } else {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) re[ct] = f4zero();
+      const bool last_here = i == 1 || row0 + (int64_t)NWV * MT >= std::min<int64_t>(g0 + GROUP, A1);
+      if (more && last_here) {       // finished beside the next group's window load
+        drow0 = row0;
+        dwin = ownwin;
+        break;
       }
-      float4 v[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        v[ct] = make_float4(o[ct][0] * rsx, o[ct][1] * rsx, o[ct][2] * rsx, o[ct][3] * rsx);
-        if (a.act == NG_ACT_SOFTPLUS) {
-          v[ct].x = softplus_f(v[ct].x); v[ct].y = softplus_f(v[ct].y); v[ct].z = softplus_f(v[ct].z); v[ct].w = softplus_f(v[ct].w);
-        } else if (a.act != NG_ACT_NONE) {
-          v[ct].x = act_apply(a.act, v[ct].x); v[ct].y = act_apply(a.act, v[ct].y);
-          v[ct].z = act_apply(a.act, v[ct].z); v[ct].w = act_apply(a.act, v[ct].w);
-        }
+      finish(row0, ownwin, true, i, g0);
+    }
+    if (more) {
+      // every wave is through with this window; the next one is requested, and the last micro-tile's matrix interval,
+      // activation and stores run while it travels
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WV_GN(0);
+      NG_LDS_BARRIER();
+      WV_GN(1);
+      const int64_t g1 = g0 + GROUP;
+      const int64_t nlo = std::max<int64_t>(0, std::min<int64_t>(g1 - (WROWS - GROUP) / 2, a.N - WROWS));
+      win_dma(win, a.h, nlo, a.N, wave, lane);
+      if (drow0 >= 0) {
+        const int i = 1;
+        (void)i;
+        finish(drow0, dwin, false, 1, g0);
       }
-      // the prefetched lists have landed long ago; waiting for them HERE (in front of the stores) keeps the stores' own
-      // completion out of the next micro-tile's first wait
-      WV_T(5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      WV_T(6);
-      if (live) {
-        float* po = a.out + row * WF + 4 * kg;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          *reinterpret_cast<float4*>(po + 16 * ct) = make_float4(v[ct].x + resf * re[ct].x, v[ct].y + resf * re[ct].y,
-                                                                 v[ct].z + resf * re[ct].z, v[ct].w + resf * re[ct].w);
-        if (a.S_save) {
-          float* ps = a.S_save + row * WF + 4 * kg;
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<float4*>(ps + 16 * ct) = v[ct];
-        }
-      }
-      WV_T(7);
+      WV_GN(2);
+      NG_LDS_BARRIER();
+      WV_GN(3);
     }
   }
+#ifdef WV_STAMP
+  if (a.stamps && lane == 0) a.stamps[2048 + blockIdx.x * NWV + wave] = wall_clock64();
+#endif
 }
 
 __global__ __launch_bounds__(WTHREADS) void mp_wave_fwd_kernel(Args a) {
@@ -403,7 +471,7 @@ int mp_wave_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int act, int r
   static unsigned long long* dbg = nullptr;
   static int calls = 0;
   constexpr int NST = 4 * NWV * 8 + 2 * NWV * 4;
-  if (!dbg) { (void)hipMalloc(&dbg, NST * 8); (void)hipMemset(dbg, 0, NST * 8); }
+  if (!dbg) { (void)hipMalloc(&dbg, 8192 * 8); (void)hipMemset(dbg, 0, 8192 * 8); }
   a.stamps = dbg;
 #endif
   ProfScope ps(ctx, st, "mp_win_fwd");
@@ -411,6 +479,23 @@ int mp_wave_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int act, int r
   NG_HIP(ctx, hipGetLastError());
 #ifdef WV_STAMP
   if (++calls == 40) {
+    {
+      static unsigned long long wb[8192];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(wb, dbg, sizeof(wb), hipMemcpyDeviceToHost);
+      unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+      for (int b = 0; b < grid && b < 512; ++b) {
+        s0 = std::min(s0, wb[1024 + b]); s1 = std::max(s1, wb[1024 + b]);
+        for (int w = 0; w < NWV; ++w) { e0 = std::min(e0, wb[2048 + b * NWV + w]); e1 = std::max(e1, wb[2048 + b * NWV + w]); }
+      }
+      fprintf(stderr, "WV wall (100 MHz ticks): first start 0, last start %llu, first end %llu, last end %llu; block 3: start %llu end %llu\n",
+              s1 - s0, e0 - s0, e1 - s0, wb[1024 + 3] - s0, wb[2048 + 3 * NWV] - s0);
+      int hist[16] = {0};
+      for (int b = 0; b < grid && b < 512; ++b) { unsigned long long m = 0; for (int w = 0; w < NWV; ++w) m = std::max(m, wb[2048 + b * NWV + w]); const int k = (int)((m - s0) / 500); hist[k < 15 ? k : 15]++; }
+      fprintf(stderr, "WV end-time histogram (5 us bins):");
+      for (int k = 0; k < 16; ++k) fprintf(stderr, " %d", hist[k]);
+      fprintf(stderr, "\n");
+    }
     unsigned long long hb[NST];
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
