@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 7
+#define NG_ABI_VERSION 8
 
 enum {
   NG_OK = 0,
@@ -80,7 +80,7 @@ int ng_ctx_set_graph_span(ng_ctx* ctx, int64_t max_graph_atoms);
 /* pre-size the scratch workspace (so that later calls never hipMalloc, e.g. under graph capture) */
 int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
 
-/* ---- graph replay of small calls (ABI 7) -----------------------------------------------------------------------------
+/* ---- graph replay of small calls (ABI 7; ng_replay_token / ng_replay_commit: ABI 8) -----------------------------------------------------------------------------
  * The reference trains on ONE graph per step (nmrgnn/library.py:88-89, nmrgnn/main.py:74-80) and predicts one structure per
  * call (main.py:236-245): ~33 / ~8 launches of a few microseconds each, bound by the host's launch rate.  Every entry point of
  * this library is asynchronous on the stream it is given and allocates nothing once its scratch is sized (a warm-up call, or
@@ -95,10 +95,20 @@ int ng_ctx_reserve(ng_ctx* ctx, uint64_t bytes);
  *                    (the expression of ng_adam_step: same bits), clears the operand-range guard word, and copies up to 8
  *                    buffers (whole 32-bit words, device to device) — the step's inputs into the static buffers the captured
  *                    chain reads.  Inference replays need it only for the copies (seed / step are then ignored: pass step 1).
+ * A replayed TRAINING step changes the weights on the device while none of the library's host code runs: ng_adam_step's
+ * bookkeeping of the packed-weight-image cache (the weight version, which images its launch rebuilt) happened once, at capture.
+ *   ng_replay_token   after the capture: identifies the set of cached images the captured ng_adam_step rebuilds (0: none).
+ *   ng_replay_commit  after EVERY replay of a captured training step: advances the context's weight version as one
+ *                     ng_adam_step does and marks exactly the images of `token` as current; every other cached image —
+ *                     built by an eager call of another shape, by a big validation batch, by another captured step — is
+ *                     rebuilt at its next use instead of being served with the weights of N steps ago.  An unknown token
+ *                     marks nothing.  Inference replays (no weight change) do not call it.
  * nmrgnn_amd/replay.py holds the Python side (TrainStepReplay, ForwardReplay). */
 int ng_replay_arm(ng_ctx* ctx, int on);
 int ng_replay_stage(ng_ctx* ctx, void* stream, uint64_t seed, float lr, float beta1, float beta2, int64_t step, int n_copies,
                     const void* const* src, void* const* dst, const uint64_t* bytes);
+int ng_replay_token(ng_ctx* ctx, uint64_t* token);
+int ng_replay_commit(ng_ctx* ctx, uint64_t token);
 
 /* per-kernel hipEvent bracketing for bench.py's roofline leg */
 int ng_prof_enable(ng_ctx* ctx, int on);
@@ -230,7 +240,10 @@ int ng_mp_layer_bwd(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int a
  * features are the same for every MPLayer of a backward pass, so the records are built once and shared. */
 int ng_mp_edge_records(ng_ctx*, void* stream, int64_t N, int K, int E, const int32_t* csc_ptr,
                        const int32_t* csc_edge, const float* e, float* rec);
-/* ng_mp_layer_bwd with the records supplied (csc_rec may be NULL: they are then rebuilt per call) */
+/* ng_mp_layer_bwd with the records supplied (csc_rec may be NULL: they are then rebuilt per call).  The lists of
+ * ng_build_incoming_lists hold every target's entries in ascending order of the SOURCE atom; the default-width scatter-sum
+ * stages source rows block by block in that order.  Caller-built lists in another order give the same sums — entries behind
+ * the staged block are read from memory — at a lower rate. */
 int ng_mp_layer_bwd_rec(ng_ctx*, void* stream, int64_t N, int K, int F, int E, int act,
                     const float* h, const int32_t* nlist, const float* e, const float* inv_degree,
                     const float* w, const float* A_save, const float* s_save,

@@ -33,6 +33,8 @@ SIGNATURES = {
     "ng_ctx_reserve": (_int, [_vp, _u64]),
     "ng_replay_arm": (_int, [_vp, _int]),
     "ng_replay_stage": (_int, [_vp, _vp, _u64, _f, _f, _f, _i64, _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64)]),
+    "ng_replay_token": (_int, [_vp, C.POINTER(_u64)]),
+    "ng_replay_commit": (_int, [_vp, _u64]),
     "ng_reload_env": (_int, []),
     "ng_weights_frozen": (_int, [_vp, _int]),
     "ng_weights_changed": (_int, [_vp]),
@@ -138,7 +140,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 7:
+        if lib.ng_abi_version() != 8:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -401,6 +401,23 @@ extern "C" int ng_replay_stage(ng_ctx* ctx, void* stream, uint64_t seed, float l
   return NG_OK;
 }
 
+extern "C" int ng_replay_token(ng_ctx* ctx, uint64_t* token) {
+  if (!ctx || !token) return NG_ERR_INVALID;
+  *token = ctx->replay_token;
+  return NG_OK;
+}
+
+// host bookkeeping of ONE replayed ng_adam_step: the weights moved, the captured repack launch rebuilt the images of `token`
+extern "C" int ng_replay_commit(ng_ctx* ctx, uint64_t token) {
+  if (!ctx) return NG_ERR_INVALID;
+  ctx->wver++;
+  auto it = ctx->wjobs_private_sel.find(token);
+  if (token != 0 && it != ctx->wjobs_private_sel.end())
+    for (ng_ctx::WImage* w : it->second)
+      if (w->buf && w->has_job) w->ver = ctx->wver;
+  return NG_OK;
+}
+
 extern "C" int ng_reload_env(void) {
   ng::load_switches();
   return NG_OK;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs a) {
   char* planes = reinterpret_cast<char*>(X0 + FC_TM * FC_LD);   // [2 buffers][2 planes][64][72] fp16   (fp32 body: X1)
   float* sB = reinterpret_cast<float*>(planes + 4 * FC_PLANE);  // [NL][64]
   int* s_bad = reinterpret_cast<int*>(sB + NL * FC_F);
-  if (H2 && !(a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))))
+  if (H2 && !(a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))))
     fc_fwd_body_h2<NL>(a, X0, planes, sB, s_bad);
   else
     fc_fwd_body_f32<NL>(a, X0, reinterpret_cast<float*>(planes), sB);
@@ -822,7 +822,7 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs& a) {
 // gradient operands of the piece body carry per-row scales, its x operand a per-column one — range-safe by construction
 template <int NL, bool H2>
 __global__ __launch_bounds__(512, 1) void fc_bwd_kernel(FcBwdArgs a) {
-  if (H2 && !(a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))))
+  if (H2 && !(a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))))
     fc_bwd_body<NL, true>(a);
   else
     fc_bwd_body<NL, false>(a);

@@ -472,6 +472,22 @@ __global__ __launch_bounds__(PW_THREADS, 1) void pull_win_kernel(PullWinArgs a) 
           const int sidx = __float_as_int(r.x);
           if (sidx >= b1) break;
           const float ev[3] = {r.y, r.z, r.w};
+          if (sidx < b0) {
+            // a record behind the block: the target's records do not ascend by source (lists of ng_build_incoming_lists
+            // do; ng_mp_layer_bwd_rec also takes caller-built ones).  Its row comes from memory — same products, and no
+            // read in front of the staged block (round-5 advisor finding).
+            const float4* gr = dA4 + (int64_t)sidx * (EC * F4) + l16;
+#pragma unroll
+            for (int n = 0; n < EC; ++n)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float4 v = gr[n * F4 + 16 * j];
+                acc[p][j].x = fmaf(ev[n], v.x, acc[p][j].x); acc[p][j].y = fmaf(ev[n], v.y, acc[p][j].y);
+                acc[p][j].z = fmaf(ev[n], v.z, acc[p][j].z); acc[p][j].w = fmaf(ev[n], v.w, acc[p][j].w);
+              }
+            ++qp[p];
+            continue;
+          }
           const float4* wr = win4 + (sidx - b0) * (EC * F4) + l16;
 #pragma unroll
           for (int n = 0; n < EC; ++n) {

@@ -438,7 +438,7 @@ __device__ __forceinline__ void body(const Args& a) {
 }
 
 __global__ __launch_bounds__(WTHREADS) void mp_wave_fwd_kernel(Args a) {
-  if (a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) body<false>(a);
+  if (a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))) body<false>(a);
   else body<true>(a);
 }
 

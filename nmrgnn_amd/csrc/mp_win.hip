@@ -620,7 +620,7 @@ __device__ __forceinline__ void mp_win_fwd_body(const MpWinFwdArgs& a) {
 // in the one kernel; the choice is uniform over the launch and costs no second launch.
 template <int E, bool K4, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_fwd_kernel(MpWinFwdArgs a) {
-  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))) {
     a.Wfrag = a.Wfrag32;
     mp_win_fwd_body<E, K4, false>(a);
   } else {

@@ -369,7 +369,7 @@ __device__ __forceinline__ void body(const Args& a) {
 
 template <int E>
 __global__ __launch_bounds__(WTHREADS) void mp_win16_fwd_kernel(Args a) {
-  if (a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) body<E, false>(a);
+  if (a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))) body<E, false>(a);
   else body<E, true>(a);
 }
 

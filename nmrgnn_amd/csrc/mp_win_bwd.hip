@@ -422,7 +422,7 @@ __device__ __forceinline__ void mp_win_bwd_edge_body(const MpWinEdgeArgs& a) {
 // no second launch on the timeline (an empty one costs ~4.6 us on this part, profiles/r03b).
 template <int E, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_edge_kernel(MpWinEdgeArgs a) {
-  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))) {
     a.WfragT = a.WfragT32;
     mp_win_bwd_edge_body<E, false>(a);
   } else {
@@ -891,7 +891,7 @@ __device__ __forceinline__ void mp_win_bwd_node_body(const MpWinNodeArgs& a) {
 // construction, a weight image out of range is known at the first instruction and selects the fp32-input body.
 template <int E, bool H2>
 __global__ __launch_bounds__(WTHREADS, 1) void mp_win_bwd_node_kernel(MpWinNodeArgs a) {
-  if (H2 && a.guard.word && (range_guard_raised(a.guard) || (a.wflag && *a.wflag == a.wflag_ver))) {
+  if (H2 && a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))) {
     a.WfragN = a.WfragN32;
     mp_win_bwd_node_body<E, false>(a);
   } else {

@@ -102,6 +102,11 @@ struct ng_ctx {
   // job tables of repack launches recorded while armed: one per job set, never rewritten or freed before ng_ctx_destroy — a
   // captured launch reads its table at every replay, whatever other engines of the device have registered since
   std::map<uint64_t, void*> wjobs_private;
+  // the images each private table rebuilds (map nodes of wimg: stable addresses) and the table of the last armed repack launch:
+  // ng_replay_token / ng_replay_commit re-stamp exactly these after a replayed step (round-5 advisor finding: a replay changes
+  // the weights but runs no host bookkeeping, so every OTHER cached image kept reading as valid with weights of N steps ago)
+  std::map<uint64_t, std::vector<WImage*>> wjobs_private_sel;
+  uint64_t replay_token = 0;
 };
 
 namespace ng {

@@ -24,6 +24,9 @@ __device__ __forceinline__ void range_guard_raise(RangeGuard g, bool bad) {
 __device__ __forceinline__ bool range_guard_raised(RangeGuard g) {
   return __hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
 }
+// flag word pair of a cached weight image (pack_bodies.cuh: pack_job_block): raised while the image was built from weights
+// outside the fp16 piece range
+__device__ __forceinline__ bool wimage_flag_raised(const unsigned* wflag) { return wflag && wflag[0] == wflag[1]; }
 __device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) < INFINITY); }
 
 // ---- live-edge view of a padded edge list (round 4: ng_build_live_edges / ng_edge_mlp_*_live) -----------------------

@@ -364,6 +364,12 @@ __device__ __forceinline__ void pack_job_block(const PackJob& j, int bid, int ti
       break;
     default: break;
   }
+  // flag word pair of an image kept over calls: [0] = the version at which a weight was last found outside the piece range,
+  // [1] = the version of the image itself (written by the job's first block, every time).  A consumer takes its fp32 body
+  // when the two are equal (ng_internal.h: wimage_flag_raised) — both words come from memory, so a launch recorded in a HIP
+  // graph (whose `ver` argument is frozen at capture) and its recorded consumers still agree at every replay (round-5
+  // advisor finding: the consumers compared against a version passed as a kernel argument).
+  if (j.flag && bid == 0 && tid == 0) j.flag[1] = ver;
   if (bad) {
     if (j.flag) *j.flag = ver;
     if (j.guard.word) range_guard_raise(j.guard, true);

@@ -102,6 +102,8 @@ int repack_all(ng_ctx* ctx, hipStream_t st, const void* lo, const void* hi) {
     }
     table = it->second;
     table_blocks = (int)blocks;
+    ctx->wjobs_private_sel[hash] = sel;
+    ctx->replay_token = hash;
   } else {
   if (ctx->wjobs_dirty || ctx->wjobs_n != n || ctx->wjobs_hash != hash || ctx->wjobs_cap < need) {
     if (ctx->wjobs_cap < need) {

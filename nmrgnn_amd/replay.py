@@ -11,7 +11,9 @@ and allocates nothing once the context's scratch is sized — a warm-up step bef
 engine allocates per call come from the graph's private pool of the caching allocator.  What changes from step to step
 are three launch arguments (noise seed, dropout seed, Adam's bias-corrected rate) and the inputs: ``ng_replay_stage``, ONE
 eager launch per step, writes the former into a device block the armed context's kernels read, and copies the latter into
-the static buffers the captured chain was recorded on.
+the static buffers the captured chain was recorded on.  After every replayed training step ``ng_replay_commit`` does the host
+side of the captured ``ng_adam_step`` (weight version, which packed images are current): eager calls in between replays —
+a validation batch, a step of another shape — see the weights of NOW.
 
 Results are the bits of the eager chain (tests/test_gpu_replay.py: parameter trajectories and peaks ``torch.equal``)."""
 from __future__ import annotations
@@ -59,8 +61,8 @@ class TrainStepReplay:
         eng = trainer.engine
         if trainer.buckets.world() != 1:
             raise ValueError("TrainStepReplay: single-process training only")
-        if trainer.loss_balance != 1.0 and trainer.loss_balance is None:
-            raise ValueError("loss_balance")
+        if getattr(trainer, "measure_comm", False):
+            raise ValueError("TrainStepReplay: measure_comm records timing events, which a captured step cannot hold")
         self.trainer, self.eng = trainer, eng
         dev = eng.device
         atoms, nlist, edges, inv = example
@@ -82,6 +84,9 @@ class TrainStepReplay:
     def _one_step(self):
         gb = GraphBatch(self.s_atoms, self.s_nlist, self.s_edges, self.s_inv, graph_ptr=self.graph_ptr, device=self.eng.device,
                         validate=False)
+        # the captured chain reads gb's device-side graph boundaries (and whatever else the batch allocated outside the
+        # graph's pool) at every replay: the batch lives as long as the replay object, not as long as a cache entry
+        self._gb = gb
         return self.trainer.step(gb, self.s_y, self.s_w)
 
     def _capture(self):
@@ -104,6 +109,9 @@ class TrainStepReplay:
                 torch.cuda.synchronize(eng.device)
                 with torch.cuda.graph(self._graph, stream=self._stream):
                     self.loss = self._one_step()
+                tok = C.c_uint64(0)
+                eng._ck(eng.lib.ng_replay_token(eng.ctx.handle, C.byref(tok)), "ng_replay_token")
+                self._token = int(tok.value)
             finally:
                 eng.lib.ng_replay_arm(eng.ctx.handle, 0)
             eng.adam_m.copy_(keep[0]); eng.adam_v.copy_(keep[1])
@@ -122,6 +130,9 @@ class TrainStepReplay:
         try:
             _stage(eng, seed, self.lr, eng.adam_t + 1, pairs)
             self._graph.replay()
+            # the host bookkeeping of the replayed ng_adam_step: new weight version, and only the images the captured launch
+            # rebuilds are current (a cached image of any other call must not be served with the weights of N steps ago)
+            eng._ck(eng.lib.ng_replay_commit(eng.ctx.handle, C.c_uint64(self._token)), "ng_replay_commit")
         finally:
             eng.lib.ng_replay_arm(eng.ctx.handle, 0)
         eng.adam_t += 1
@@ -154,7 +165,8 @@ class ForwardReplay:
         cur.wait_stream(self._stream)
 
     def _one(self):
-        return self.eng.forward(frames_to_batch(self.atoms, self.s_pos, self.K, device=self.eng.device))
+        self._gb = frames_to_batch(self.atoms, self.s_pos, self.K, device=self.eng.device)   # kept alive: the chain reads its buffers
+        return self.eng.forward(self._gb)
 
     def __call__(self, positions):
         p = _like(self.s_pos, positions)

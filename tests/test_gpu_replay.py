@@ -1,4 +1,4 @@
-"""Graph replay of small calls (nmrgnn_amd/replay.py, ABI 7: ng_replay_arm / ng_replay_stage): the replayed chain gives the
+"""Graph replay of small calls (nmrgnn_amd/replay.py; ng_replay_arm / ng_replay_stage, ABI 8: ng_replay_token / ng_replay_commit): the replayed chain gives the
 bits of the eager chain — parameter trajectories of one-graph training steps, peaks of one-frame forwards."""
 import os
 
@@ -72,3 +72,91 @@ def test_forward_replay_is_the_eager_forward(gpu_device):
         got = rp(f)
         torch.cuda.synchronize()
         assert torch.equal(ref, got)
+
+
+def _hp(F):
+    from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
+    return declare_gnn_space(HyperParameters(atom_feature_size=F, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
+                                             fc_layers=4, edge_fc_layers=4))
+
+
+def _scenario(dev, F, replayed):
+    """steps on one-graph batches (replayed or eager), an eager big validation forward before and after them, then an eager
+    step of ANOTHER batch shape: the state an engine must end in whether or not the middle steps were replays"""
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from nmrgnn_amd.replay import TrainStepReplay
+    from nmrgnn_amd.train import Trainer
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a)).to(device=dev, dtype=dt)
+    eng = Engine(_hp(F), 10, device=dev, seed=91)
+    tr = Trainer(eng, lr=2e-3)
+    gs = _graphs(4)
+    big = synth.make_batch(40, 256, 16, 10, 0.05, seed=9)          # 10,240 atoms: the window gather-GEMM's image at F = 256
+    gbig = GraphBatch(big["atoms"], big["nlist"], big["edges"], big["inv_degree"], graph_ptr=big["graph_ptr"], device=dev)
+    other = synth.make_batch(3, 100, 16, 10, 0.05, seed=10)
+    out = [eng.forward(gbig).clone()]
+    raw0, gp0, y0, w0 = gs[0]
+    rp = TrainStepReplay(tr, raw0, y0, w0, graph_ptr=gp0) if replayed else None
+    for step in range(3):
+        raw, gp, y, w = gs[step]
+        if replayed:
+            rp.step(raw, y, w)
+        else:
+            tr.step(GraphBatch(*raw, graph_ptr=gp, device=dev), t(y), t(w))
+    out.append(eng.forward(gbig).clone())                           # must see the weights of NOW
+    go = GraphBatch(other["atoms"], other["nlist"], other["edges"], other["inv_degree"], graph_ptr=other["graph_ptr"], device=dev)
+    out.append(tr.step(go, t(other["y"]), t(other["w"])).clone())   # an eager step of another shape: its images too
+    out.append(eng.forward(gbig).clone())
+    torch.cuda.synchronize()
+    return out, eng.params.flat.clone()
+
+
+@pytest.mark.parametrize("F", [64, 256])
+def test_eager_calls_between_replays_see_the_current_weights(gpu_device, F):
+    """round-5 advisor finding: a replayed step moves the weights but ran no host bookkeeping, so cached weight images the
+    captured launch does not rebuild (a big-batch forward's, another shape's) kept reading as valid.  ONE engine per scenario."""
+    a, pa = _scenario(gpu_device, F, replayed=True)
+    b, pb = _scenario(gpu_device, F, replayed=False)
+    assert not torch.equal(a[0], a[1])                              # the steps did change the prediction
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(pa, pb)
+
+
+def test_replayed_steps_take_the_fp32_bodies_when_weights_leave_the_piece_range(gpu_device):
+    """round-5 advisor finding: the flag version a recorded consumer compared against was a kernel argument frozen at capture.
+    After the capture a few MPLayer / FC weights are set beyond 2^8 |w| < 65504 (and one eager step rebuilds every packed
+    image from them): every later step must run the f32-input bodies of the window and FC kernels, replayed or not."""
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from nmrgnn_amd.replay import TrainStepReplay
+    from nmrgnn_amd.train import Trainer
+    dev = gpu_device
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a)).to(device=dev, dtype=dt)
+    gs = _graphs(5)
+    res = []
+    for replayed in (False, True):
+        eng = Engine(_hp(64), 10, device=dev, seed=92)
+        tr = Trainer(eng, lr=1e-3)
+        raw0, gp0, y0, w0 = gs[0]
+        rp = TrainStepReplay(tr, raw0, y0, w0, graph_ptr=gp0) if replayed else None
+        sd = eng.params.state_dict()
+        sd["mp/1/w"][3, 5, 0] = 400.0
+        sd["mp/2/w"][40, 63, 2] = -300.0
+        sd["fc/1/kernel"][7, 9] = 350.0
+        eng.params.load_state_dict(sd)
+        losses = []
+        for step in range(5):
+            raw, gp, y, w = gs[step]
+            if replayed and step > 0:
+                l = rp.step(raw, y, w)
+            else:
+                l = tr.step(GraphBatch(*raw, graph_ptr=gp, device=dev), t(y), t(w))
+            losses.append(l.clone())
+        torch.cuda.synchronize()
+        res.append((losses, eng.params.flat.clone()))
+    assert torch.isfinite(res[0][1]).all() and float(res[0][1].abs().max()) > 256.0
+    for la, lb in zip(res[0][0], res[1][0]):
+        assert torch.equal(la, lb)
+    assert torch.equal(res[0][1], res[1][1])
