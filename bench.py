@@ -122,6 +122,43 @@ def kernel_work(N, K, F, E, H, Le, L, Lf, C, live_edges=None):
     return w
 
 
+def step_flops_per_atom(K, F, E, H, Le, L, Lf):
+    """SURVEY.md 8(d): algorithmic flops per atom of the forward (edge MLP + L MPLayers + FC block + head column), MAC = 2 flop;
+    forward + backward = 3 x the forward."""
+    fwd = 2.0 * K * ((Le - 1) * H * H + H * E) + L * 2.0 * (K * F * E + F * F * E) + 2.0 * ((Lf - 1) * F * F + F * F / 2) + 2.0 * (F / 2)
+    return fwd, 3.0 * fwd
+
+
+def survey_8d_block(rows, N, K, F, E, H, Le, L, Lf, ms_per_step, n_live):
+    """the accounting of SURVEY.md 8(d), beside the per-kernel rows (whose byte counts are the kernels' own operand lists):
+      step      whole-step algorithmic flops / measured step time / the fp16-pipe fp32-equivalent peak (2516.6 / 3 TF)
+      mp_layer  the MPLayer's 8(d) bytes per atom — forward 4 (2F + K + KE + 1), backward 4 (3F + K + 2KE + 1) — over the time
+                of the launches that do that work (backward: edge-side + node-side kernels summed), against 8 TB/s
+      tape      what the edge MLP's saved activations move through HBM per step (written by the forward, read by the backward)"""
+    t = {r["kernel"]: r for r in rows}
+    fwd_fl, all_fl = step_flops_per_atom(K, F, E, H, Le, L, Lf)
+    peak = PEAK_MFMA_F16_TFLOPS / 3.0
+    out = {"step": {"flops_per_atom": all_fl, "tflop_per_step": all_fl * N / 1e12, "ms_per_step": ms_per_step,
+                    "achieved_tflops": all_fl * N / (ms_per_step * 1e-3) / 1e12, "peak_tflops": peak,
+                    "frac": all_fl * N / (ms_per_step * 1e-3) / 1e12 / peak}}
+    fb, bb = 4.0 * (2 * F + K + K * E + 1), 4.0 * (3 * F + K + 2 * K * E + 1)
+    mp = {"fwd_bytes_per_atom": fb, "bwd_bytes_per_atom": bb, "peak_gbs": PEAK_HBM_GBS}
+    fwd_k = [k for k in ("mp_win_fwd",) if k in t] or [k for k in ("mp_aggregate", "mp_update_fwd", "mp_fused_fwd") if k in t]
+    bwd_k = [k for k in ("mp_win_bwd_edge", "mp_win_bwd_node") if k in t] or \
+            [k for k in ("mp_dP", "mp_dA", "mp_edge_grad", "mp_scatter_pull", "mp_dw", "mp_bwd_edge", "mp_bwd_node") if k in t]
+    if fwd_k:
+        ms = sum(t[k]["ms_per_step"] for k in fwd_k) / L
+        mp.update(fwd_kernels=fwd_k, fwd_ms_per_layer=ms, fwd_gbs=fb * N / (ms * 1e-3) / 1e9, fwd_frac=fb * N / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
+    if bwd_k:
+        ms = sum(t[k]["ms_per_step"] for k in bwd_k) / L
+        mp.update(bwd_kernels=bwd_k, bwd_ms_per_layer=ms, bwd_gbs=bb * N / (ms * 1e-3) / 1e9, bwd_frac=bb * N / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
+    out["mp_layer"] = mp
+    if n_live is not None:
+        out["tape"] = {"bytes_per_step": 2.0 * (Le - 1) * n_live * H * 4.0, "note": "(Le-1) x live edges x H fp32 values, written by "
+                       "edge_fwd_h2 and read by edge_bwd_h2: ~97 % of either kernel's HBM bytes"}
+    return out
+
+
 def usable_cores():
     """cores this process may actually run on: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -611,6 +648,10 @@ def main():
                                    "edges_priced": n_live if n_live is not None else gb.n_edges,
                                    "edge_slots": gb.n_edges}
             out["profiled_ms_per_step"] = sum(r["ms_per_step"] for r in rows)
+            out["survey_8d"] = survey_8d_block(rows, gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, out["ms_per_step"],
+                                               n_live if n_live is not None else gb.n_edges)
+            if "roofline" in out:
+                out["roofline"]["step"] = out["survey_8d"]["step"]
 
     extras = rank == 0 and world == 1 and not args.no_extras
     # ---- configs[1]: the same batch, inference only (no noise / dropout / tape), reported beside the headline
@@ -697,6 +738,10 @@ def main():
                 dom2 = next((r for r in rows2 if "bound" in r), None)
                 if dom2 is not None:
                     blk["roofline"] = {k: dom2[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms")}
+                blk["survey_8d"] = survey_8d_block(rows2, gb.N, K_NEIGH, 256, 3, 128, 4, 4, 4, blk["ms_per_step"],
+                                                   int((b["edges"] > 0).sum()))
+                if "roofline" in blk:
+                    blk["roofline"]["step"] = blk["survey_8d"]["step"]
             ms = event_timed(lambda: eng2.forward(gb), 5)
             blk["inference_ms_per_step"] = float(np.median(ms))
             blk["inference_value"] = gb.N / (np.median(ms) * 1e-3)

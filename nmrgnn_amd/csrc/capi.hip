@@ -23,8 +23,6 @@ static void load_switches() {
   Switches s;
   s.edge_math_fp32 = env_is("NG_EDGE_MATH", "fp32");
   s.edge_bwd_math_fp32 = env_is("NG_EDGE_BWD_MATH", "fp32");
-  s.edge_bwd_rs = env_is("NG_EDGE_BWD", "rs");
-  s.mp_pull_l2 = env_is("NG_MP_PULL", "l2");
   s.gemm_math_fp32 = env_is("NG_GEMM_MATH", "fp32");
   s.edge_layered = env_is("NG_EDGE_PATH", "layered");
   s.mp_layered = env_is("NG_MP_PATH", "layered");
@@ -36,7 +34,6 @@ static void load_switches() {
   s.knn_cells = env_is("NG_KNN", "cells");
   s.knn_brute = env_is("NG_KNN", "brute");
   s.mp_gg_on = env_is("NG_MP_GG", "1");
-  s.mp_gw = !env_is("NG_MP_GW", "0");
   s.mp_gw_nowin = env_is("NG_MP_GW", "nowin");
   s.mp_w16 = !env_is("NG_MP_W16", "0");
   s.mp_wave = env_is("NG_MP_WAVE", "1") ? 1 : (env_is("NG_MP_WAVE", "0") ? 0 : -1);

@@ -238,6 +238,5 @@ __device__ __forceinline__ void hx_sprime2(float& x0, float& x1, float z0, float
 }
 
 // the sixteen-wave role-split kernel (edge_bwd_rs.hip): same arguments, same partial layout
-void edge_bwd_rs_run(hipStream_t st, int grid, const EdgeBwdH2Args& a, bool live);
 
 }  // namespace ng

@@ -499,9 +499,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
     a.stamps = dbg;
 #endif
     ProfScope ps(ctx, st, "edge_bwd_h2");
-    if (sw().edge_bwd_rs)
-      edge_bwd_rs_run(st, grid, a, live.perm != nullptr);
-    else if (live.perm)
+    if (live.perm)
       hipLaunchKernelGGL(edge_bwd_h2_kernel<true>, dim3(grid), dim3(HX_THREADS), HX_LDS_BYTES, st, a);
     else
       hipLaunchKernelGGL(edge_bwd_h2_kernel<false>, dim3(grid), dim3(HX_THREADS), HX_LDS_BYTES, st, a);
@@ -514,7 +512,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
         unsigned long long h[256];
         hipStreamSynchronize(st);
         hipMemcpy(h, a.stamps, 2048, hipMemcpyDeviceToHost);
-        const int ngrp = sw().edge_bwd_rs ? 4 : 2;      // stamped waves: 0, 4 (eight-wave kernel) / 0, 4 (Z), 8, 12 (M)
+        const int ngrp = 2;      // stamped waves: 0, 4
         for (int w = 0; w < ngrp; ++w)
           for (int t = 0; t < 4; ++t) {
             printf("wave %d tile %d:", 4 * w, t);

@@ -1051,28 +1051,16 @@ int gemm_h2_dw(ng_ctx* ctx, hipStream_t st, int64_t M, int Kin, int Nout, int ac
 //     forward   h' = act(v * sum_n A_n W_n) + h,     A[i][(n, l)]  = sum_j   e[i,j,n] h[nlist[i,j]][l]
 //     backward  dh = dH + sum_n B_n Wn_n,            B[t][(n, m)]  = sum_in  e[i,j,n] dP[i][m]     (edges (i,j) with nlist[i,j] = t)
 // Until round 3 both ran as aggregate -> [N, 768] in HBM (402 MB written, then read) -> GEMM, and the backward pull read
-// 3 KB of dA per incoming edge through L2 (mp_scatter_pull: 0.37 ms per layer, 0.23 of the HBM roofline).  Here the
-// GEMM's A-tile PRODUCER is the gather: a 512-thread workgroup per 128-row tile, one per CU;
-//   waves 4-7 (producers): thread = (row, 16-column half).  Per 32-column slab of the gathered operand (a "super-step")
-//     it walks the row's list ONCE — entries staged in LDS as 16-byte records {source, e_0..e_2}, four in flight, 64 B of
-//     each source row from L2 — accumulating the E partial rows in registers, then splits them into fp16 pieces and writes
-//     the X piece planes of the E k-steps (n = 0..E-1) of that slab into an LDS ring;
-//   waves 0-3 (consumers): the 128 x 256 product exactly as gemm_h2_fwdr (wave w: output columns [64 w, 64 w + 64) for all
-//     rows, W^T piece fragments from the fragment-ordered image in L2 one k-half ahead), E k-steps per barrier.
-// The two roles meet at ONE barrier per super-step; while the consumers multiply slab u the producers gather slab u + 1
-// (the matrix pipe and the vector / memory pipes of a SIMD belong to different waves).  L2 gather volume equals the
-// aggregation kernel's (2.1 GB per launch), the aggregate never exists.  The k-step order (slab-major, n inside) is the
-// weight image's (pack_bodies.cuh: PK_GG), built from w[l][m][n] directly — no Wp copy.
+// 3 KB of dA per incoming edge through L2.  The kernel of this path is the window gather-GEMM of mp_gw.cuh (round 5: 256-row
+// tiles, one wave per SIMD, the gathered operand formed in registers out of an LDS window).  Round 4's producer / consumer
+// kernel (four producer waves walking the lists, four consumer waves multiplying; 375-450 us per launch against 300-330) was
+// removed in round 6 — DESIGN_HISTORY.md has its measurements.  The k-step order (slab-major, n inside) is the weight
+// image's (pack_bodies.cuh: PK_GG), built from w[l][m][n] directly — no Wp copy.
 // Ranges.  Forward operands are activations (split unscaled; an |A| >= 65504 raises the guard).  The pull's operand is a
 // gradient: the sums are multiplied by S * 2^-x before the split, S the power of two of dP (gemm_grad_scale) and 2^x >=
-// max_n sum_in |e_n| of the row (known from the staged records before the first gather), so no piece can overflow; the
-// epilogue multiplies the row by 2^x / S.  A raised guard is answered by mp_gg_repair_kernel: the same rows in plain
-// fp32 on the vector ALU (slow, exact, an empty launch otherwise).
-constexpr int GG_THREADS = 512;
-constexpr int GG_STAGE = 2 * GX_XPLANE;           // the two X piece planes of one k-step: 20,480 B
-constexpr int GG_CAP = 2304;                      // list entries of a tile staged in LDS (the rest is read from global memory)
+// max_n sum_in |e_n| of the row, so no piece can overflow; the epilogue multiplies the row by 2^x / S.  A raised guard is
+// answered by mp_gg_repair_kernel: the same rows in plain fp32 on the vector ALU (slow, exact, an empty launch otherwise).
 enum { GG_PADDED = 0, GG_CSR = 1, GG_REC = 2 };
-constexpr int gg_lds(int E) { return 2 * E * GG_STAGE + GG_CAP * 16 + GX_BM * 4; }     // E = 3: 160,256 of 163,840 B
 
 struct GgArgs {
   int64_t M;               // rows (atoms)
@@ -1105,235 +1093,6 @@ __device__ __forceinline__ float4 gg_entry(const GgArgs& a, int64_t t) {
   r.z = E > 1 ? a.ew[t * E + 1] : 0.f;
   r.w = E > 2 ? a.ew[t * E + 2] : 0.f;
   return r;
-}
-
-// the producer waves of mp_gg_kernel (see there)
-#ifndef GG_TRIP
-#define GG_TRIP 2      // list entries (per row) per trip of the producer; two trips are in flight
-#endif
-// The producer waves of mp_gg_kernel.  Thread (g, c) = (pt >> 3, pt & 7) owns rows g, g + 32, g + 64, g + 96 of the tile and
-// columns 4c .. 4c + 3 of the current 32-column slab: the EIGHT lanes of a (row, entry) read one whole 128-byte line of the
-// source row.  (First form: thread = (row, 16-column half), each lane 4 x 16 B of its own source row — a wave load touched 32
-// rows at 16 B each and the texture addresser, not the latency, set the pace: 375 us per launch, the same as aggregate +
-// GEMM; deeper prefetch made it slower.  profiles/r04f_gg_ab.txt)
-// STAGED: every entry of the tile sits in LDS (the common case; uniform over the workgroup — decided per entry inside one
-// loop, the two sources cost 450 B of scratch per lane).
-template <int LK, int E, bool GRAD, bool STAGED>
-__device__ __forceinline__ void gg_produce(const GgArgs& a, char* ring, const float4* srec, float* sfac, int64_t m0, int64_t base0,
-                                           int64_t last_entry, int NU, int tid) {
-  const int pt = tid - 256, g = pt >> 3, c = pt & 7;
-  int rowi[4], rb[4], deg[4];
-  bool rv[4];
-  int dmax = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = g + 32 * i;
-    rv[i] = m0 + r < a.M;
-    const int64_t row = rv[i] ? m0 + r : a.M - 1;
-    rowi[i] = (int)row;
-    if (LK == GG_PADDED) { rb[i] = r * a.Kpad; deg[i] = rv[i] ? a.Kpad : 0; }
-    else { const int64_t p0 = a.ptr[row]; rb[i] = (int)(p0 - base0); deg[i] = rv[i] ? (int)(a.ptr[row + 1] - p0) : 0; }
-    dmax = std::max(dmax, deg[i]);
-  }
-  // j-th entry of row i; past its end: weight 0 on the row itself (an in-bounds address, no branch around the loads)
-  auto entry = [&](int i, int j) -> float4 {
-    float4 e4 = STAGED ? srec[std::min(rb[i] + j, GG_CAP - 1)] : gg_entry<LK, E>(a, std::min<int64_t>(base0 + rb[i] + j, last_entry));
-    if (j >= deg[i]) e4 = make_float4(__builtin_bit_cast(float, rowi[i]), 0.f, 0.f, 0.f);
-    return e4;
-  };
-  float pscale[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-  if (GRAD) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float se0 = 0.f, se1 = 0.f, se2 = 0.f;
-      for (int j = 0; j < deg[i]; ++j) { const float4 e4 = entry(i, j); se0 += fabsf(e4.y); se1 += fabsf(e4.z); se2 += fabsf(e4.w); }
-      const float sm = fmaxf(se0, fmaxf(se1, se2));
-      int ex = 0;
-      if (sm > 1.0f && sm < 3.0e38f) (void)frexpf(sm, &ex);        // sm = f * 2^ex, f in [0.5, 1)
-      pscale[i] = a.gscale[0] * ldexpf(1.0f, -ex);
-      if (c == 0) sfac[g + 32 * i] = ldexpf(1.0f, ex);
-    }
-  }
-  // buffer loads: one 32-bit lane offset per entry (row * F * 4 + this lane's 16 bytes), the slab as the scalar offset
-  // (M * F * 4 < 2^32: checked by the host)
-  const __amdgpu_buffer_rsrc_t rsG =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G), 0, (unsigned)(a.M * a.F * 4), 0x00020000);
-  typedef float gg_f4 __attribute__((ext_vector_type(4)));
-  // One trip = GG_TRIP entries of each of the four rows, requested together; two trips are in flight: while the sums of trip
-  // t are formed, trip t + 1 — the first trip of the NEXT slab at a slab's end — is on its way.  The weights are read again
-  // from the staged records when the sums are formed (no registers for them).
-  gg_f4 vA[4][GG_TRIP], vB[4][GG_TRIP];
-  auto issue = [&](gg_f4 (&v)[4][GG_TRIP], int u, int j) {
-    const int so = __builtin_amdgcn_readfirstlane(128 * u);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int q = 0; q < GG_TRIP; ++q) {
-        const float4 e4 = entry(i, j + q);
-        const int vo = (__builtin_bit_cast(int, e4.x) * a.F + 4 * c) * 4;
-#ifdef GG_ABL_NOGATHER
-        v[i][q] = gg_f4{(float)(vo & 255) * 1e-3f, (float)(so & 255) * 1e-3f, 1e-3f, 2e-3f};
-#else
-        v[i][q] = __builtin_bit_cast(gg_f4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, so, 0));
-#endif
-      }
-  };
-  auto fma4 = [&](float (&acc)[4][E][4], int j, const gg_f4 (&v)[4][GG_TRIP]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int q = 0; q < GG_TRIP; ++q) {
-        const float4 e4 = entry(i, j + q);
-        const float wn[3] = {e4.y, e4.z, e4.w};
-#pragma unroll
-        for (int n = 0; n < E; ++n)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[i][n][t] = fmaf(wn[n], v[i][q][t], acc[i][n][t]);
-      }
-  };
-  // slab u; its first trip is already in the A buffers
-  auto produce = [&](int u) {
-    float acc[4][E][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int n = 0; n < E; ++n)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[i][n][t] = 0.f;
-    for (int j = 0; j < dmax; j += 2 * GG_TRIP) {
-      if (j + GG_TRIP < dmax) issue(vB, u, j + GG_TRIP);
-      fma4(acc, j, vA);
-      if (j + 2 * GG_TRIP < dmax) issue(vA, u, j + 2 * GG_TRIP);
-      else if (u + 1 < NU) issue(vA, u + 1, 0);
-      if (j + GG_TRIP < dmax) fma4(acc, j + GG_TRIP, vB);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = g + 32 * i;
-      if (!GRAD && a.A_out && rv[i]) {      // write-once stream: non-temporal; the eight lanes of a row store 128 contiguous bytes
-        float* ao = a.A_out + (int64_t)rowi[i] * ((int64_t)E * a.F) + 32 * u + 4 * c;
-#pragma unroll
-        for (int n = 0; n < E; ++n)
-          __builtin_nontemporal_store(gg_f4{acc[i][n][0], acc[i][n][1], acc[i][n][2], acc[i][n][3]},
-                                      reinterpret_cast<gg_f4*>(ao + (int64_t)n * a.F));
-      }
-#pragma unroll
-      for (int n = 0; n < E; ++n) {
-        const float ps = GRAD ? pscale[i] : 1.0f;
-        unsigned h0, l0, h1, l1;
-        split2_pair(GRAD ? ps * acc[i][n][0] : acc[i][n][0], GRAD ? ps * acc[i][n][1] : acc[i][n][1], h0, l0);
-        split2_pair(GRAD ? ps * acc[i][n][2] : acc[i][n][2], GRAD ? ps * acc[i][n][3] : acc[i][n][3], h1, l1);
-        char* d = ring + ((u & 1) * E + n) * GG_STAGE + r * GX_XROW + 8 * c;
-        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(d + GX_XPLANE) = u32x2{l0, l1};
-      }
-    }
-  };
-  if (dmax > 0) issue(vA, 0, 0);
-  produce(0);
-  NG_LDS_BARRIER();
-#pragma unroll 1
-  for (int u = 0; u < NU; ++u) {
-    if (u + 1 < NU) produce(u + 1);
-    NG_LDS_BARRIER();
-  }
-}
-
-template <int LK, int E, bool GRAD>
-__global__ __launch_bounds__(GG_THREADS, 1) void mp_gg_kernel(GgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_gg[];
-  char* ring = smem_gg;                                                              // [2 slabs][E k-steps][GG_STAGE]
-  float4* srec = reinterpret_cast<float4*>(smem_gg + 2 * E * GG_STAGE);              // [GG_CAP]
-  float* sfac = reinterpret_cast<float*>(smem_gg + 2 * E * GG_STAGE + GG_CAP * 16);  // [128] 2^x of the row (GRAD)
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t m0 = (int64_t)blockIdx.x * GX_BM;
-  const int64_t m1 = std::min<int64_t>(m0 + GX_BM, a.M);
-  const int NU = a.F / 32;
-  int64_t base0, base1;
-  if (LK == GG_PADDED) { base0 = m0 * a.Kpad; base1 = m1 * a.Kpad; }
-  else { base0 = a.ptr[m0]; base1 = a.ptr[m1]; }
-  {
-    const int nstage = (int)std::min<int64_t>(base1 - base0, GG_CAP);
-    for (int t = tid; t < nstage; t += GG_THREADS) srec[t] = gg_entry<LK, E>(a, base0 + t);
-  }
-  NG_LDS_BARRIER();
-
-  if (wave >= 4) {
-    // ------------------------------------------------------------------------------------------------ producers
-    const int64_t last_entry = std::max<int64_t>(base1 - 1, 0);
-    if (base1 - base0 <= GG_CAP) gg_produce<LK, E, GRAD, true>(a, ring, srec, sfac, m0, base0, last_entry, NU, tid);
-    else gg_produce<LK, E, GRAD, false>(a, ring, srec, sfac, m0, base0, last_entry, NU, tid);
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------- consumers
-  const int nq = wave;
-  constexpr int WCHUNK = gx_wchunk(4);
-  const int nsteps = NU * E;
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.Wimg), 0, (unsigned)((int64_t)nsteps * WCHUNK), 0x00020000);
-  auto w_request = [&](u32x4 (&wa)[2][2], int s, int ks) {
-    const int sc = std::min(s, nsteps - 1);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, sc * WCHUNK + (((2 * nq + j) * 2 + ks) * 2 + p) * 1024, 0);
-        wa[j][p] = __builtin_bit_cast(u32x4, raw);
-      }
-  };
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-  auto multiply = [&](const char* sX, const u32x4 (&wa)[2][2], int ks) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u32x4 xb[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        xb[p] = *reinterpret_cast<const u32x4*>(sX + p * GX_XPLANE + (32 * i + l31) * GX_XROW + (16 * ks + 8 * half) * 2);
-      mma3_2a(wa[0], wa[1], xb, acc[0][i], acc[1][i]);
-    }
-  };
-  u32x4 w0[2][2], w1[2][2];
-  w_request(w0, 0, 0);
-  NG_LDS_BARRIER();          // slab 0 is in the ring
-#pragma unroll 1
-  for (int u = 0; u < NU; ++u) {
-#pragma unroll
-    for (int n = 0; n < E; ++n) {
-      const int s = u * E + n;
-      const char* cur = ring + ((u & 1) * E + n) * GG_STAGE;
-#ifndef GG_ABL_NOMFMA
-      w_request(w1, s, 1);
-      multiply(cur, w0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      w_request(w0, s + 1, 0);
-      multiply(cur, w1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-#else
-      (void)s; (void)cur;
-#endif
-    }
-    NG_LDS_BARRIER();
-  }
-  // epilogue: lane holds, for row m = m0 + 32 i + l31, columns n = 32 (2 nq + j) + 8 q + 4 half + (0..3)
-  GxArgs g{};
-  g.M = a.M; g.K = E * a.F; g.N = a.F; g.R = a.R; g.Y = a.Y; g.S = a.S; g.act = a.act; g.guard = a.guard;
-  const float oscale = GX_WINV * (GRAD ? a.gscale[1] : 1.0f);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + 32 * i + l31;
-    if (m >= a.M) continue;
-    const float rs = oscale * (a.rowscale ? a.rowscale[m] : 1.0f) * (GRAD ? sfac[32 * i + l31] : 1.0f);
-    const f32x16 blk[2] = {acc[0][i], acc[1][i]};
-    gx_epilogue_block<2>(g, blk, m, 64 * nq + 4 * half, rs);
-  }
 }
 
 // The rows of the same call in plain fp32 (one workgroup per row at a time, thread = column), executed only when the
@@ -1372,8 +1131,9 @@ __global__ __launch_bounds__(256) void mp_gg_repair_kernel(GgArgs a) {
 
 #include "mp_gw.cuh"
 
-static bool gw_ok(const GgArgs& a, int E) {
-  return sw().mp_gw && E == 3 && a.F % 32 == 0 && a.M * (int64_t)a.F * 4 < ((int64_t)1 << 31) && (a.ptr || a.Kpad <= 16);
+// what the window gather-GEMM takes (everything else keeps the aggregate -> HBM -> GEMM path: mp_gg_supported)
+static bool gw_shape_ok(int64_t M, int F, int E, bool has_ptr, int Kpad) {
+  return E == 3 && F % 32 == 0 && M * (int64_t)F * 4 < ((int64_t)1 << 31) && (has_ptr || Kpad <= 16);
 }
 
 // DEFAULT for the forward of a call that does not keep the aggregate (inference: `A_save == nullptr`) on a batch of small
@@ -1383,16 +1143,17 @@ static bool gw_ok(const GgArgs& a, int E) {
 // kernel more than the round trip it saves) and the backward's pull (pull_win_kernel wins) keep their kernels unless
 // NG_MP_GG=1 asks for this one.
 bool mp_gw_infer_ok(ng_ctx* ctx, int64_t N, int K, int F, int E, bool csr, bool keeps_aggregate) {
-  return sw().mp_gw && !sw().gemm_math_fp32 && !sw().mp_layered && !keeps_aggregate && F == 256 && E == 3 && (csr || K <= 16) &&
+  return !sw().gemm_math_fp32 && !sw().mp_layered && !keeps_aggregate && F == 256 && E == 3 && (csr || K <= 16) &&
          N >= sw().mp_gg_min_rows && N * (int64_t)F * 4 < ((int64_t)1 << 31) && ctx->graph_span > 0 && ctx->graph_span <= 256;
 }
 
-bool mp_gg_supported(int64_t N, int F, int E) {
+bool mp_gg_supported(int64_t N, int F, int E, int Kpad) {      // Kpad: slots per row of a padded list, 0 for CSR / record lists
   // OPT-IN (NG_MP_GG=1): measured on MI355X the kernel does not beat aggregate -> HBM -> GEMM yet (375-450 us per launch
   // against 134 + 240; the producer waves, four per CU, cannot keep enough gathers in flight — DESIGN section 4), so the
   // default stays the two-kernel path.  Below NG_MP_GG_MIN_ROWS rows (default 8192 = 64 tiles) a call has too few
   // 128-row tiles for 256 CUs either way.  Both are read with the other switches (ng_reload_env).
-  return sw().mp_gg_on && !sw().gemm_math_fp32 && !sw().mp_layered && F == 256 && E >= 1 && E <= 3 && N >= sw().mp_gg_min_rows;
+  return sw().mp_gg_on && !sw().gemm_math_fp32 && !sw().mp_layered && F == 256 && N >= sw().mp_gg_min_rows &&
+         gw_shape_ok(N, F, E, Kpad == 0, Kpad);
 }
 
 // the PK_GG image of w for `mode` (cached / refreshed behind Adam when the image cache is on, else in the aux scratch)
@@ -1418,8 +1179,8 @@ template <int LK, bool GRAD>
 static int gg_launch(ng_ctx* ctx, hipStream_t st, GgArgs& a, int E, const char* tag) {
   a.guard = range_guard_begin(ctx);
   if (!a.guard.word) return NG_ERR_NOMEM;
-  const unsigned grid = (unsigned)cdiv(a.M, GX_BM);
-  if (gw_ok(a, E)) {
+  if (!gw_shape_ok(a.M, a.F, E, a.ptr != nullptr, a.Kpad)) return fail(ctx, NG_ERR_INVALID, "gather-GEMM: shape outside the window form");
+  {
     ProfScope ps(ctx, st, tag);
     a.no_window = sw().mp_gw_nowin ? 1 : 0;
     const unsigned wgrid = (unsigned)cdiv(a.M, GW_BM);
@@ -1438,14 +1199,6 @@ static int gg_launch(ng_ctx* ctx, hipStream_t st, GgArgs& a, int E, const char* 
       fprintf(stderr, "\n");
     }
 #endif
-    NG_HIP(ctx, hipGetLastError());
-  } else {
-    ProfScope ps(ctx, st, tag);
-    switch (E) {
-      case 1: hipLaunchKernelGGL((mp_gg_kernel<LK, 1, GRAD>), dim3(grid), dim3(GG_THREADS), gg_lds(1), st, a); break;
-      case 2: hipLaunchKernelGGL((mp_gg_kernel<LK, 2, GRAD>), dim3(grid), dim3(GG_THREADS), gg_lds(2), st, a); break;
-      default: hipLaunchKernelGGL((mp_gg_kernel<LK, 3, GRAD>), dim3(grid), dim3(GG_THREADS), gg_lds(3), st, a); break;
-    }
     NG_HIP(ctx, hipGetLastError());
   }
   ProfScope ps(ctx, st, "mp_gg_range_fallback");

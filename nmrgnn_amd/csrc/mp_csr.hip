@@ -515,8 +515,7 @@ __global__ __launch_bounds__(PW_THREADS, 1) void pull_win_kernel(PullWinArgs a) 
 }
 
 bool pull_win_ok(ng_ctx* ctx, int64_t N, int F, int E, const float* rec) {
-  return rec != nullptr && E >= 1 && E <= 3 && F == 256 && N >= 4096 && ctx->graph_span > 0 && ctx->graph_span <= PW_SPAN &&
-         !sw().mp_pull_l2;
+  return rec != nullptr && E >= 1 && E <= 3 && F == 256 && N >= 4096 && ctx->graph_span > 0 && ctx->graph_span <= PW_SPAN;
 }
 
 int pull_win(ng_ctx* ctx, hipStream_t st, int64_t N, int F, int E, const int32_t* csc_ptr, const float* rec, const float* dA,
@@ -599,7 +598,7 @@ int mp_generic_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
                    const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
                    float* h_out, float* A_save, float* s_save) {
   const int64_t KF = (int64_t)E * F;
-  if (E <= 3 && (mp_gg_supported(N, F, E) || mp_gw_infer_ok(ctx, N, K, F, E, row_ptr != nullptr, A_save != nullptr)))     // gather-GEMM (gemm_h2.hip): the aggregate only as a by-product when asked for
+  if (E <= 3 && (mp_gg_supported(N, F, E, row_ptr ? 0 : K) || mp_gw_infer_ok(ctx, N, K, F, E, row_ptr != nullptr, A_save != nullptr)))     // gather-GEMM (gemm_h2.hip): the aggregate only as a by-product when asked for
     return mp_gg_fwd(ctx, st, N, K, F, E, act, residual, h, row_ptr, col, e, inv_degree, w, h_out, s_save, A_save);
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + (A_save ? 0 : N * KF)) * 4);
   if (!ws) return NG_ERR_NOMEM;
@@ -621,7 +620,7 @@ int mp_generic_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, 
   const int64_t KF = (int64_t)E * F;
   const size_t dw_scr = dense_dw_scratch_floats(ctx, N, (int)KF, F, false);
   // node side as a gather-GEMM over dP rows (gemm_h2.hip) needs the incoming-edge records; built here when the caller has none
-  const bool gg = E <= 3 && N > 0 && mp_gg_supported(N, F, E);
+  const bool gg = E <= 3 && N > 0 && mp_gg_supported(N, F, E, 0);
   const int64_t n_ent = row_ptr ? nnz : N * K;
   const size_t rec_floats = gg && !csc_rec ? (size_t)std::max<int64_t>(n_ent, 1) * 4 : 0;
   float* ws = (float*)workspace(ctx, (size_t)(KF * F + N * KF + N * F + dw_scr + (A_save ? 0 : N * KF) + rec_floats) * 4);

@@ -966,14 +966,6 @@ int mp_win_bwd_node(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* 
                     const int32_t* csc_ptr, const float* rec, const float* WfragN, const float* dh_out,
                     float* dh_in, float* dw, float* scratch, float* dummy, RangeGuard guard, const float* WfragN32,
                     const unsigned* wflag, unsigned wflag_ver) {
-  if (mp_win_bwd_h2() && guard.word && sw().mp_w16 && getenv("NG_MP_W16_NODE") && mp_win16_bwd_node_supported(E)) {
-    int grid16 = 0;
-    if (int rc = mp_win16_bwd_node_launch(ctx, st, N, E, h, dP, csc_ptr, rec, WfragN, dh_out, dh_in, scratch, dummy, guard, WfragN32,
-                                          wflag, wflag_ver, &grid16))
-      return rc;
-    ProfScope ps(ctx, st, "reduce_partials");
-    return reduce_or_defer(ctx, st, scratch, grid16, (int64_t)E * WF * WF, dw, 2, WF, E, WF, (int64_t)E * WF * WF);
-  }
   MpWinNodeArgs a{};
   a.N = N; a.ntiles = cdiv(N, WTA);
   const int64_t per = win_tiles_per_wg(a.ntiles, ctx->num_cu);

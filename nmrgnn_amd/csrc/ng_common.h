@@ -116,30 +116,29 @@ namespace ng {
 //   NG_EDGE_MATH=fp32      edge MLP forward+backward on f32-input MFMA (default: two-piece fp16 split operands)
 //   NG_EDGE_BWD_MATH=fp32  only the edge backward on f32-input MFMA
 //   NG_GEMM_MATH=fp32      generic GEMMs on f32-input MFMA (default: split operands where the shape allows)
-//   NG_EDGE_BWD=rs         split-operand edge backward with sixteen role-split waves (edge_bwd_rs.hip; default: eight waves, edge_bwd_h2.hip)
 //   NG_EDGE_PATH=layered   one launch per edge-MLP layer (any H / Le)
-//   NG_MP_PULL=l2          default-width backward scatter-sum through L2 (default: dA rows staged in LDS windows, pull_win_kernel)
 //   NG_MP_PATH=layered     aggregate -> A[N,E*F] -> GEMM for every width (default: window kernels at F == 64)
 //   NG_FC_PATH=layered     one launch per FC layer
 //   NG_DENSE_PATH=generic  no register-resident tall-skinny kernels
 //   NG_HEAD_PATH=generic   the first head / embedding-gradient kernels
 //   NG_KNN=serial / lanes  one lane / 8-16 lanes per query atom in the kNN graph kernel (default: one wave per query)
 //   NG_KNN=cells / brute   the cell-grid neighbour search for every frame size / for none (default: frames >= 16384 atoms)
-//   NG_MP_GG=1             default-width MPLayer as a gather-GEMM (gemm_h2.hip: mp_gg_kernel; default: aggregate -> HBM -> GEMM)
+//   NG_MP_GG=1             default-width MPLayer as the window gather-GEMM (mp_gw.cuh) for every eligible call, training included (default: inference of molecule batches only)
 //   NG_MP_GG_MIN_ROWS=n    smallest call (rows) that takes the gather-GEMM (default 8192)
+//   NG_MP_GW=nowin         the window gather-GEMM reads every tile's sources from memory (test: same bits as the window)
+//   NG_MP_W16=0            the eight-wave window kernels at F == 64 (default: sixteen waves, mp_win16*.hip)
+//   NG_MP_WAVE=1 / 0       the wave-autonomous forward window kernel (mp_wave.hip) for every supported call / none (default: batches that fill the chip)
+//   NG_REDUCE=narrow       second-stage reductions 64 elements per block at every size (test of the wide form's bits)
 struct Switches {
   bool edge_math_fp32 = false, edge_bwd_math_fp32 = false, gemm_math_fp32 = false;
   bool edge_layered = false, mp_layered = false, fc_layered = false;
   bool dense_generic = false, head_generic = false, knn_serial = false, knn_cells = false, knn_brute = false;
   bool mp_gg_on = false;             // NG_MP_GG=1
   bool mp_gw_nowin = false;          // NG_MP_GW=nowin: the window form reads every tile's sources from memory (tests: same bits as the window)
-  bool mp_gw = true;                 // NG_MP_GW=0: the gather-GEMM keeps round 4's producer / consumer kernel (mp_gg_kernel) instead of the window form (mp_gw.cuh)
   int mp_wave = -1;                  // NG_MP_WAVE=1 / 0: the wave-autonomous forward window kernel (mp_wave.hip) for every supported call / for none (default: batches that fill the chip)
   bool mp_w16 = true;                // NG_MP_W16=0: the eight-wave forward window kernel instead of the 16-wave one (mp_win16.hip)
   bool reduce_narrow = false;        // NG_REDUCE=narrow: second-stage reductions 64 elements per block at every size (reduce.cuh)
   bool knn_lanes = false;            // NG_KNN=lanes
-  bool mp_pull_l2 = false;           // NG_MP_PULL=l2: the default-width backward scatter-sum gathers dA rows through L2 (round 1-4) instead of the LDS window pull (mp_csr.hip: pull_win_kernel)
-  bool edge_bwd_rs = false;          // NG_EDGE_BWD=rs: the role-split sixteen-wave split-operand edge backward (edge_bwd_rs.hip; measured, not faster) instead of the eight-wave one (edge_bwd_h2.hip)
   int64_t mp_gg_min_rows = 8192;     // NG_MP_GG_MIN_ROWS
 };
 const Switches& sw();

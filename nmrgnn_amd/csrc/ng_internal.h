@@ -62,7 +62,7 @@ bool gemm_h2_fwd_ok(int64_t M, int K, int N);
 int gemm_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t M, int K, int N, int act, const float* X, const float* W,
                 const float* b, const float* rowscale, const float* R, float* Y, float* S, const char* tag, RangeGuard guard);
 // gather-GEMM forms of the MPLayer update and of the backward's node-side pull (gemm_h2.hip): no aggregate in HBM
-bool mp_gg_supported(int64_t N, int F, int E);
+bool mp_gg_supported(int64_t N, int F, int E, int Kpad);
 bool mp_gw_infer_ok(ng_ctx* ctx, int64_t N, int K, int F, int E, bool csr, bool keeps_aggregate);   // gemm_h2.hip / mp_gw.cuh
 int mp_gg_fwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, int act, int residual, const float* h,
               const int32_t* row_ptr, const int32_t* col, const float* e, const float* inv_degree, const float* w,
@@ -195,11 +195,6 @@ int agg_win(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int F, int E, const f
 // backward images, the dA image as fp16 piece fragments (mp_win.hip)
 // f32T / f32N (optional): the fp32 fragment images of the same launch, for the guarded fallback kernels
 PackJob mpw_bwd_job(int E, const float* w, float* outT, float* outN, float* f32T, float* f32N, unsigned* flag, RangeGuard guard);
-// 16-wave form of the node-side backward window kernel (mp_win16_node.hip), launched by mp_win_bwd_node on its images
-bool mp_win16_bwd_node_supported(int E);
-int mp_win16_bwd_node_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int E, const float* h, const float* dP, const int32_t* csc_ptr,
-                             const float* rec, const float* WfragN, const float* dh_out, float* dh_in, float* scratch, float* dummy,
-                             RangeGuard guard, const float* WfragN32, const unsigned* wflag, unsigned wflag_ver, int* grid_out);
 // 16-wave form of the edge-side backward window kernel (mp_win16_bwd.hip), launched by mp_win_bwd_edge on its images
 bool mp_win16_bwd_edge_supported(int E, int K);
 int mp_win16_bwd_edge_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, const float* h, const int32_t* nlist,

@@ -851,7 +851,7 @@ extern "C" int ng_mp_layer_fwd(ng_ctx* ctx, void* stream, int64_t N, int K, int 
     return mp_generic_fwd(ctx, st, N, K, F, E, act, residual, h, nullptr, nlist, e, inv_degree, w, h_out, A_save, s_save);
   // the reference's default width: gather-GEMM, the aggregate never reaches HBM (gemm_h2.hip: mp_gg_kernel)
   // (a caller that keeps the aggregate for the backward's dw = A^T dP gets it as a by-product of the producer waves)
-  if (mp_gg_supported(N, F, E) || mp_gw_infer_ok(ctx, N, K, F, E, false, A_save != nullptr))
+  if (mp_gg_supported(N, F, E, K) || mp_gw_infer_ok(ctx, N, K, F, E, false, A_save != nullptr))
     return mp_gg_fwd(ctx, st, N, K, F, E, act, residual, h, nullptr, nlist, e, inv_degree, w, h_out, s_save, A_save);
   const int64_t KF = (int64_t)E * F;
   // scratch: Wp [KF*F] (+ A [N*KF] when the caller does not keep it)
