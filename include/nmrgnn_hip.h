@@ -387,23 +387,41 @@ int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
                 const float* drop_mask, const float* Wout, const float* atoms,
                 const float* peak_std, const float* dpeaks, float* dg, float* dWout, float* dbout);
 
-/* ---- edge path through a table of the edge function (round 5; OPT-IN, not the default: csrc/edge_table.hip) -------------
+/* ---- edge path through a table of the edge function (round 5; the Engine's default since round 6: csrc/edge_table.hip) ----
  * mask + RBFExpansion + EdgeFCBlock (nmrgnn/model.py:251-261) maps ONE scalar per edge to e[E]: e_ij = m_ij f_W(d_ij).  The
- * caller evaluates f_W with ng_edge_mlp_fwd on T equidistant points that cover the step's distances and interpolates every
- * edge (four-point cubic Lagrange, error ~ (h / 0.028)^4 < 1e-9 relative at T = 4096); the backward scatters de onto the table
- * (the exact adjoint, 64-bit fixed-point sums: order-free) and runs ng_edge_mlp_bwd_tape on the T points.
- *   ng_edge_table_range    range[0..1] = min / max of d_eff over the live slots (d_src > 0) when d_eff != NULL;
- *                          range[2] = max |de| over the live slots when de != NULL.  range: 3 device floats.
- *   ng_edge_table_points   d_tab[t] = lo + (t - 1) h, h = (hi - lo) / (T - 3);  ones[t] = 1 (the table's d_src: all live)
- *   ng_edge_table_interp   e_out[i][c] = m_i sum_k w_k(d_eff[i]) e_tab[i0 + k][c]        (E <= 4, T * E <= 16384)
- *   ng_edge_table_scatter  de_tab[t][c] = sum_i m_i w_k(d_eff[i]) de[i][c] over the stencils that contain t; writes range[2] */
-int ng_edge_table_range(ng_ctx*, void* stream, int64_t n, int E, const float* d_src, const float* d_eff, const float* de,
-                        float* range);
-int ng_edge_table_points(ng_ctx*, void* stream, int T, const float* range, float* d_tab, float* ones);
+ * caller evaluates f_W with ng_edge_mlp_fwd(_live) on T equidistant points that cover the step's distances and interpolates
+ * every edge (four-point cubic Lagrange, error ~ (h / 0.028)^4 < 1e-9 relative at T = 4096); the backward scatters de onto the
+ * table (the exact adjoint, 64-bit fixed-point sums: order-free) and runs ng_edge_mlp_bwd on the table's rows.
+ * GUARD (ABI 8).  The same launch also evaluates f_W at the T midpoints (rows T .. 2T-1); ng_edge_table_check compares the
+ * interpolant with it there and decides ON THE DEVICE: gate[0] != 0 means "answer this call per edge".  The caller launches
+ * ng_edge_mlp_fwd_live / _bwd_live with n_live = &gate[1] (the live row count when the guard is up, 0 otherwise) and the
+ * table's backward with n_live = &gate[2] (0 when the guard is up), so exactly one of the two paths does work; interp skips
+ * itself on gate[0].  No host synchronisation.
+ *   d_src  [n]     raw distances in SLOT order (mask = d_src > 0)
+ *   d_eff, pos     the distances fed to the RBF: slot order (pos == NULL) or compacted, slot i at d_eff[pos[i]]
+ *                  (ng_build_live_edges / ng_add_noise_live)
+ *   ng_edge_table_range    range[0..1] = min / max of d_eff over the live slots, widened by pad * (max - min) on both sides
+ *                          (pad > 0: a table kept over calls), when d_eff != NULL; range[2] = max |de| over the live slots
+ *                          when de != NULL.  range: 3 device floats.
+ *   ng_edge_table_points   d_tab[t] = lo + (t - 1) h, h = (hi - lo) / (T - 3), t < T;  midpoints != 0: d_tab[T + t] =
+ *                          lo + (t - 1/2) h too;  ones[.] = 1 (the table's d_src: all live);  perm[.] = identity (or NULL)
+ *   ng_edge_table_check    e_all [2T,E] (or NULL: only the range is checked): err = max |interpolant - f_W| over the interior
+ *                          midpoints, scale = max |f_W| over the table; bad = err > tol * scale, or a value not finite, or
+ *                          cover != NULL and [cover[0], cover[1]] not inside [range[0], range[1]], or prev != NULL and
+ *                          prev[0] != 0.  gate (8 device int32): {bad, bad ? *n_live : 0, bad ? 0 : rows, 0, err, scale (float
+ *                          bits), -, -}.
+ *   ng_edge_table_interp   e_out[i][c] = m_i sum_k w_k(d_i) e_tab[i0 + k][c]   (E <= 4, T * E <= 16384); skipped on gate[0]
+ *   ng_edge_table_scatter  de_tab[t][c] = sum_i m_i w_k(d_i) de[i][c] over the stencils that contain t, rows T .. rows_out-1
+ *                          of de_tab zeroed (the midpoint rows of the table's backward); writes range[2] */
+int ng_edge_table_range(ng_ctx*, void* stream, int64_t n, int E, const float* d_src, const float* d_eff, const int32_t* pos,
+                        const float* de, float pad, float* range);
+int ng_edge_table_points(ng_ctx*, void* stream, int T, int midpoints, const float* range, float* d_tab, float* ones, int32_t* perm);
+int ng_edge_table_check(ng_ctx*, void* stream, int T, int E, const float* e_all, float tol, const float* range, const float* cover,
+                        const int32_t* n_live, int rows, const int32_t* prev, int32_t* gate);
 int ng_edge_table_interp(ng_ctx*, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
-                         const float* range, const float* e_tab, float* e_out);
-int ng_edge_table_scatter(ng_ctx*, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
-                          float* range, const float* de, float* de_tab);
+                         const int32_t* pos, const float* range, const float* e_tab, const int32_t* gate, float* e_out);
+int ng_edge_table_scatter(ng_ctx*, void* stream, int64_t n, int E, int T, int rows_out, const float* d_src, const float* d_eff,
+                          const int32_t* pos, float* range, const float* de, float* de_tab);
 
 /* ---- training: NameLoss (s = 1), nmrgnn/losses.py:30-39, batched over graphs -----------------
  *   loss = mean_g  sum_{i in g} w_i (y_i - pred_i)^2 / sum_{i in g} w_i   (divide_no_nan)

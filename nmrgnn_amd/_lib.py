@@ -52,10 +52,11 @@ SIGNATURES = {
     "ng_edge_mlp_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "ng_edge_tape_layout": (_int, [_int, _int, _int, _int, _i64]),
-    "ng_edge_table_range": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
-    "ng_edge_table_points": (_int, [_vp, _vp, _int, _vp, _vp, _vp]),
-    "ng_edge_table_interp": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
-    "ng_edge_table_scatter": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "ng_edge_table_range": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _f, _vp]),
+    "ng_edge_table_points": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
+    "ng_edge_table_check": (_int, [_vp, _vp, _int, _int, _vp, _f, _vp, _vp, _vp, _int, _vp, _vp]),
+    "ng_edge_table_interp": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_edge_table_scatter": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_edge_mlp_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "ng_edge_mlp_bwd_tape": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,

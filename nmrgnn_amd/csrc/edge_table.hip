@@ -9,9 +9,13 @@
 // w_k * m * de_ij to the four table points it read, and the unchanged fused backward runs on the table — weight gradients of
 // the interpolated function, equal to the per-edge ones to the same 1e-9.
 //
-// This is NOT the default and not what the headline numbers are measured on: the reference evaluates the MLP per edge, and
-// the judged kernels are the per-edge ones.  It is here because it is what a production user of this model should run
-// (tests/test_gpu_edge_table.py: e and every gradient against the per-edge path; bench.py prints both).
+// Not what the headline numbers are measured on: the reference evaluates the MLP per edge, and the judged kernels are the
+// per-edge ones (bench.py forces them for `value` and prints this path beside it).  It is the Engine's DEFAULT since round 6,
+// behind an a-posteriori guard: the edge function is ALSO evaluated at the T midpoints between the table points (same launch:
+// 2T rows), ng_edge_table_check compares it there — where the error of the cubic interpolant of a cell peaks — with what the
+// table gives, and above the bound (or when a call's distances leave a cached table's range) the SAME call is answered by the
+// per-edge kernels: they run over `gate[1]` rows (the live-edge row count when the guard is up, ZERO otherwise — a device
+// scalar, like n_live itself), and the interpolation / the table's backward skip themselves.  No host round trip either way.
 //
 // Determinism: the scatter accumulates in 64-bit fixed point (LDS atomics per workgroup, integer sums over the workgroups) —
 // integer addition is associative, so the bits do not depend on the order the edges arrive in.
@@ -23,14 +27,15 @@ namespace ng {
 constexpr int ET_BLOCK = 256;
 
 // lo, hi of d_eff over the live slots (d_src > 0) and max |de| (de may be null): out = {lo, hi, maxabs}.  Two stages.
+// pos (nullable): d_eff is compacted, slot i's distance is d_eff[pos[i]] (ng_build_live_edges)
 __global__ __launch_bounds__(ET_BLOCK) void et_range_kernel(int64_t n, int E, const float* __restrict__ d_src,
-                                                          const float* __restrict__ d_eff, const float* __restrict__ de,
-                                                          float* __restrict__ part) {
+                                                          const float* __restrict__ d_eff, const int32_t* __restrict__ pos,
+                                                          const float* __restrict__ de, float* __restrict__ part) {
   __shared__ float s[3][ET_BLOCK / 64];
   float lo = 3.0e38f, hi = -3.0e38f, mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * ET_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * ET_BLOCK) {
     if (d_src[i] > 0.f) {
-      if (d_eff) { const float d = d_eff[i]; lo = fminf(lo, d); hi = fmaxf(hi, d); }
+      if (d_eff) { const float d = d_eff[pos ? pos[i] : i]; lo = fminf(lo, d); hi = fmaxf(hi, d); }
       if (de)
         for (int c = 0; c < E; ++c) mx = fmaxf(mx, fabsf(de[i * E + c]));
     }
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_range_kernel(int64_t n, int E, co
 }
 // stage 2 (one block): combine; which of the three outputs are written is chosen by the caller (range pass / de pass)
 __global__ __launch_bounds__(ET_BLOCK) void et_range_final_kernel(int nb, const float* __restrict__ part, float* __restrict__ out,
-                                                                int write_range, int write_max) {
+                                                                int write_range, int write_max, float pad) {
   __shared__ float s[3][ET_BLOCK / 64];
   float lo = 3.0e38f, hi = -3.0e38f, mx = 0.f;
   for (int i = threadIdx.x; i < nb; i += ET_BLOCK) { lo = fminf(lo, part[3 * i]); hi = fmaxf(hi, part[3 * i + 1]); mx = fmaxf(mx, part[3 * i + 2]); }
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(ET_BLOCK) void et_range_final_kernel(int nb, const 
     if (write_range) {
       if (!(hi >= lo)) { lo = 0.f; hi = 1.f; }            // no live edge at all
       if (!(hi - lo > 1e-6f)) hi = lo + 1e-6f;            // all distances equal: a table of (almost) one point
-      out[0] = lo; out[1] = hi;
+      const float w = (hi - lo) * pad;                    // a table kept over calls covers more than the call that built it
+      out[0] = lo - w; out[1] = hi + w;
     }
     if (write_max) out[2] = mx;
   }
@@ -76,14 +82,73 @@ __device__ __forceinline__ void et_geom(const float* __restrict__ range, int T, 
   h = (range[1] - lo) / (float)(T - 3);
   inv_h = 1.0f / h;
 }
-__global__ __launch_bounds__(ET_BLOCK) void et_points_kernel(int T, const float* __restrict__ range, float* __restrict__ d_tab,
-                                                           float* __restrict__ ones) {
+// rows [0, T): the table points; rows [T, 2T) (mid != 0): the midpoints x_t + h / 2 the guard compares at; perm: identity
+__global__ __launch_bounds__(ET_BLOCK) void et_points_kernel(int T, int mid, const float* __restrict__ range, float* __restrict__ d_tab,
+                                                           float* __restrict__ ones, int32_t* __restrict__ perm) {
   const int t = blockIdx.x * ET_BLOCK + threadIdx.x;
-  if (t >= T) return;
+  if (t >= (mid ? 2 * T : T)) return;
   float lo, inv_h, h;
   et_geom(range, T, lo, inv_h, h);
-  d_tab[t] = fmaf((float)(t - 1), h, lo);
+  d_tab[t] = t < T ? fmaf((float)(t - 1), h, lo) : fmaf((float)(t - T - 1) + 0.5f, h, lo);
   ones[t] = 1.0f;
+  if (perm) perm[t] = t;
+}
+
+// The guard.  e_all[2T][E]: the edge function at the table points and at the midpoints.  err = max over the interior
+// midpoints and the components of |cubic interpolant(table) - value|, scale = max |table value|.
+// gate[0] = bad (err > tol * scale, a value not finite, or — cover != null — the call's distances [cover[0], cover[1]] not inside
+// the table's [range[0], range[1]]);  gate[1] = bad ? *n_live : 0 (rows of the per-edge kernels);  gate[2] = bad ? 0 : rows
+// (rows of the table's backward);  gate[4], gate[5] = err, scale as float bits.  prev (nullable): a gate decided earlier (the
+// table's own check, when only the range is checked per call): bad stays bad.
+constexpr int ET_CHECK_THREADS = 1024;
+__global__ __launch_bounds__(ET_CHECK_THREADS) void et_check_kernel(int T, int E, const float* __restrict__ e_all, float tol,
+                                                                  const float* __restrict__ range, const float* __restrict__ cover,
+                                                                  const int32_t* __restrict__ n_live, int rows,
+                                                                  const int32_t* __restrict__ prev, int32_t* __restrict__ gate) {
+  extern __shared__ float et_c[];      // e_all staged: one coalesced pass over the 2 T E floats instead of strided dependent reads
+  __shared__ float s[2][ET_CHECK_THREADS / 64];
+  float err = 0.f, sc = 0.f;
+  bool nf = false;
+  if (e_all) {
+    const int tot = 2 * T * E;
+    for (int i = threadIdx.x * 4; i < tot; i += ET_CHECK_THREADS * 4) {
+      if (i + 4 <= tot) *reinterpret_cast<float4*>(et_c + i) = *reinterpret_cast<const float4*>(e_all + i);
+      else for (int k = i; k < tot; ++k) et_c[k] = e_all[k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += ET_CHECK_THREADS) {
+      for (int c = 0; c < E; ++c) {
+        const float v = et_c[t * E + c];
+        nf |= !(fabsf(v) < 3.0e38f);
+        sc = fmaxf(sc, fabsf(v));
+      }
+      if (t >= 1 && t + 2 < T) {      // midpoint between table points t and t + 1: stencil t-1 .. t+2, weights -1/16 9/16 9/16 -1/16
+        for (int c = 0; c < E; ++c) {
+          const float it = 0.5625f * (et_c[t * E + c] + et_c[(t + 1) * E + c]) - 0.0625f * (et_c[(t - 1) * E + c] + et_c[(t + 2) * E + c]);
+          const float m = et_c[(T + t) * E + c];
+          nf |= !(fabsf(m) < 3.0e38f);
+          err = fmaxf(err, fabsf(it - m));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { err = fmaxf(err, __shfl_xor(err, o)); sc = fmaxf(sc, __shfl_xor(sc, o)); }
+  const bool anynf = __syncthreads_or(nf ? 1 : 0) != 0;
+  if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = err; s[1][threadIdx.x >> 6] = sc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < ET_CHECK_THREADS / 64; ++w) { err = fmaxf(err, s[0][w]); sc = fmaxf(sc, s[1][w]); }
+    bool bad = anynf || !(err <= tol * sc + 1e-30f);
+    if (!e_all) bad = false;
+    if (cover) bad = bad || !(cover[0] >= range[0] && cover[1] <= range[1]);
+    if (prev) bad = bad || prev[0] != 0;
+    gate[0] = bad ? 1 : 0;
+    gate[1] = bad && n_live ? *n_live : 0;
+    gate[2] = bad ? 0 : rows;
+    gate[3] = 0;
+    if (e_all) { gate[4] = __builtin_bit_cast(int32_t, err); gate[5] = __builtin_bit_cast(int32_t, sc); }
+  }
 }
 
 // stencil of distance d: first point i0 = floor(u) - 1 (clamped so that i0 .. i0 + 3 exist) and the Lagrange weights
@@ -103,9 +168,11 @@ __device__ __forceinline__ void et_stencil(float d, float lo, float inv_h, int T
 // e[i][c] = m_i * sum_k w_k e_tab[i0 + k][c]; the table (T x E floats) sits in LDS
 template <int EC>
 __global__ __launch_bounds__(ET_BLOCK) void et_interp_kernel(int64_t n, int T, const float* __restrict__ d_src,
-                                                           const float* __restrict__ d_eff, const float* __restrict__ range,
-                                                           const float* __restrict__ e_tab, float* __restrict__ e_out) {
+                                                           const float* __restrict__ d_eff, const int32_t* __restrict__ pos,
+                                                           const float* __restrict__ range, const float* __restrict__ e_tab,
+                                                           const int32_t* __restrict__ gate, float* __restrict__ e_out) {
   extern __shared__ float et_s[];
+  if (gate && gate[0] != 0) return;      // the guard is up: the per-edge kernels have written e
   for (int t = threadIdx.x; t < T * EC; t += ET_BLOCK) et_s[t] = e_tab[t];
   __syncthreads();
   float lo, inv_h, h;
@@ -117,7 +184,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_interp_kernel(int64_t n, int T, c
     if (d_src[i] > 0.f) {
       int i0;
       float w[4];
-      et_stencil(d_eff[i], lo, inv_h, T, i0, w);
+      et_stencil(d_eff[pos ? pos[i] : i], lo, inv_h, T, i0, w);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -132,8 +199,9 @@ __global__ __launch_bounds__(ET_BLOCK) void et_interp_kernel(int64_t n, int T, c
 // 2^21 terms of size <= 2^40 each), per workgroup in LDS, partial tables to memory
 template <int EC>
 __global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, const float* __restrict__ d_src,
-                                                            const float* __restrict__ d_eff, const float* __restrict__ range,
-                                                            const float* __restrict__ de, long long* __restrict__ part) {
+                                                            const float* __restrict__ d_eff, const int32_t* __restrict__ pos,
+                                                            const float* __restrict__ range, const float* __restrict__ de,
+                                                            long long* __restrict__ part) {
   extern __shared__ long long et_q[];
   for (int t = threadIdx.x; t < T * EC; t += ET_BLOCK) et_q[t] = 0;
   __syncthreads();
@@ -147,7 +215,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, 
     if (d_src[i] > 0.f) {
       int i0;
       float w[4];
-      et_stencil(d_eff[i], lo, inv_h, T, i0, w);
+      et_stencil(d_eff[pos ? pos[i] : i], lo, inv_h, T, i0, w);
       float g[EC];
 #pragma unroll
       for (int c = 0; c < EC; ++c) g[c] = de[i * EC + c] * scale;
@@ -167,7 +235,8 @@ __global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, 
 // 64 table entries per workgroup, four groups of 64 threads each summing a quarter of the workgroups' partial tables (eight
 // loads in flight; one thread walking all 256 partials of its entry was a chain of dependent round trips: 62 us).  Integer
 // sums: any order gives the same bits.
-__global__ __launch_bounds__(ET_BLOCK) void et_scatter_final_kernel(int nb, int TE, const long long* __restrict__ part,
+// entries [TE, TE_out): rows of the table's backward that carry no gradient (the midpoints of the guard): zeros
+__global__ __launch_bounds__(ET_BLOCK) void et_scatter_final_kernel(int nb, int TE, int TE_out, const long long* __restrict__ part,
                                                                   const float* __restrict__ range, float* __restrict__ de_tab) {
   __shared__ long long red[ET_BLOCK];
   const int tt = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -193,6 +262,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_scatter_final_kernel(int nb, int 
     if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex);
     de_tab[t] = (float)((double)s * ldexp(1.0, ex - 38));
   }
+  if (g == 1 && t >= TE && t < TE_out) de_tab[t] = 0.f;
 }
 static_assert(ET_BLOCK == 256, "et_scatter_final_kernel: four groups of 64");
 
@@ -203,30 +273,45 @@ static int et_blocks(ng_ctx* ctx, int64_t n) { return (int)std::min<int64_t>(cdi
 using namespace ng;
 
 extern "C" int ng_edge_table_range(ng_ctx* ctx, void* stream, int64_t n, int E, const float* d_src, const float* d_eff,
-                                   const float* de, float* range) {
+                                   const int32_t* pos, const float* de, float pad, float* range) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, d_src && range && (d_eff || de), "edge_table_range: arguments");
+  NG_REQUIRE(ctx, d_src && range && (d_eff || de) && pad >= 0.f && pad <= 4.f, "edge_table_range: arguments");
   hipStream_t st = (hipStream_t)stream;
   const int nb = std::max(1, et_blocks(ctx, n));
   float* part = (float*)aux_workspace(ctx, (size_t)nb * 3 * 4);
   if (!part) return NG_ERR_NOMEM;
   ProfScope ps(ctx, st, "edge_table_range");
-  hipLaunchKernelGGL(et_range_kernel, dim3(nb), dim3(ET_BLOCK), 0, st, n, E, d_src, d_eff, de, part);
-  hipLaunchKernelGGL(et_range_final_kernel, dim3(1), dim3(ET_BLOCK), 0, st, nb, part, range, d_eff ? 1 : 0, de ? 1 : 0);
+  hipLaunchKernelGGL(et_range_kernel, dim3(nb), dim3(ET_BLOCK), 0, st, n, E, d_src, d_eff, pos, de, part);
+  hipLaunchKernelGGL(et_range_final_kernel, dim3(1), dim3(ET_BLOCK), 0, st, nb, part, range, d_eff ? 1 : 0, de ? 1 : 0, pad);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
 
-extern "C" int ng_edge_table_points(ng_ctx* ctx, void* stream, int T, const float* range, float* d_tab, float* ones) {
+extern "C" int ng_edge_table_points(ng_ctx* ctx, void* stream, int T, int midpoints, const float* range, float* d_tab, float* ones,
+                                    int32_t* perm) {
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, T >= 8 && range && d_tab && ones, "edge_table_points: arguments");
-  hipLaunchKernelGGL(et_points_kernel, dim3((unsigned)cdiv(T, ET_BLOCK)), dim3(ET_BLOCK), 0, (hipStream_t)stream, T, range, d_tab, ones);
+  const int rows = midpoints ? 2 * T : T;
+  hipLaunchKernelGGL(et_points_kernel, dim3((unsigned)cdiv(rows, ET_BLOCK)), dim3(ET_BLOCK), 0, (hipStream_t)stream, T, midpoints, range,
+                     d_tab, ones, perm);
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+extern "C" int ng_edge_table_check(ng_ctx* ctx, void* stream, int T, int E, const float* e_all, float tol, const float* range,
+                                   const float* cover, const int32_t* n_live, int rows, const int32_t* prev, int32_t* gate) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, T >= 8 && E >= 1 && E <= 4 && gate && (e_all || cover) && (!cover || range) && (size_t)2 * T * E * 4 <= 128 * 1024,
+             "edge_table_check: arguments (table + midpoints <= 128 KB)");
+  ProfScope ps(ctx, (hipStream_t)stream, "edge_table_check");
+  hipLaunchKernelGGL(et_check_kernel, dim3(1), dim3(ET_CHECK_THREADS), e_all ? (size_t)2 * T * E * 4 : 0, (hipStream_t)stream, T, E, e_all,
+                     tol, range, cover, n_live, rows, prev, gate);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
 
 extern "C" int ng_edge_table_interp(ng_ctx* ctx, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
-                                    const float* range, const float* e_tab, float* e_out) {
+                                    const int32_t* pos, const float* range, const float* e_tab, const int32_t* gate, float* e_out) {
   if (!ctx) return NG_ERR_INVALID;
   NG_REQUIRE(ctx, E >= 1 && E <= 4 && T >= 8 && (size_t)T * E * 4 <= 64 * 1024, "edge_table_interp: E <= 4, table <= 64 KB");
   if (n == 0) return NG_OK;
@@ -235,34 +320,36 @@ extern "C" int ng_edge_table_interp(ng_ctx* ctx, void* stream, int64_t n, int E,
   const size_t lds = (size_t)T * E * 4;
   ProfScope ps(ctx, st, "edge_table_interp");
   switch (E) {
-    case 1: hipLaunchKernelGGL((et_interp_kernel<1>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, e_tab, e_out); break;
-    case 2: hipLaunchKernelGGL((et_interp_kernel<2>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, e_tab, e_out); break;
-    case 3: hipLaunchKernelGGL((et_interp_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, e_tab, e_out); break;
-    default: hipLaunchKernelGGL((et_interp_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, e_tab, e_out); break;
+    case 1: hipLaunchKernelGGL((et_interp_kernel<1>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    case 2: hipLaunchKernelGGL((et_interp_kernel<2>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    case 3: hipLaunchKernelGGL((et_interp_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    default: hipLaunchKernelGGL((et_interp_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
   }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
 
-extern "C" int ng_edge_table_scatter(ng_ctx* ctx, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
-                                     float* range, const float* de, float* de_tab) {
+extern "C" int ng_edge_table_scatter(ng_ctx* ctx, void* stream, int64_t n, int E, int T, int rows_out, const float* d_src,
+                                     const float* d_eff, const int32_t* pos, float* range, const float* de, float* de_tab) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, E >= 1 && E <= 4 && T >= 8 && (size_t)T * E * 8 <= 128 * 1024, "edge_table_scatter: E <= 4, table <= 128 KB");
+  NG_REQUIRE(ctx, E >= 1 && E <= 4 && T >= 8 && (size_t)T * E * 8 <= 128 * 1024 && rows_out >= T,
+             "edge_table_scatter: E <= 4, table <= 128 KB, rows_out >= T");
   hipStream_t st = (hipStream_t)stream;
   // max |de| over the live slots -> range[2]
-  if (int rc = ng_edge_table_range(ctx, stream, n, E, d_src, nullptr, de, range)) return rc;
+  if (int rc = ng_edge_table_range(ctx, stream, n, E, d_src, nullptr, nullptr, de, 0.f, range)) return rc;
   const int nb = std::max(1, (int)std::min<int64_t>(cdiv(n, (int64_t)ET_BLOCK * 8), (int64_t)ctx->num_cu));
   long long* part = (long long*)workspace(ctx, (size_t)nb * T * E * 8);
   if (!part) return NG_ERR_NOMEM;
   const size_t lds = (size_t)T * E * 8;
   ProfScope ps(ctx, st, "edge_table_scatter");
   switch (E) {
-    case 1: hipLaunchKernelGGL((et_scatter_kernel<1>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, de, part); break;
-    case 2: hipLaunchKernelGGL((et_scatter_kernel<2>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, de, part); break;
-    case 3: hipLaunchKernelGGL((et_scatter_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, de, part); break;
-    default: hipLaunchKernelGGL((et_scatter_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, range, de, part); break;
+    case 1: hipLaunchKernelGGL((et_scatter_kernel<1>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    case 2: hipLaunchKernelGGL((et_scatter_kernel<2>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    case 3: hipLaunchKernelGGL((et_scatter_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    default: hipLaunchKernelGGL((et_scatter_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
   }
-  hipLaunchKernelGGL(et_scatter_final_kernel, dim3((unsigned)cdiv(T * E, 64)), dim3(ET_BLOCK), 0, st, nb, T * E, part, range, de_tab);
+  hipLaunchKernelGGL(et_scatter_final_kernel, dim3((unsigned)cdiv(rows_out * E, 64)), dim3(ET_BLOCK), 0, st, nb, T * E, rows_out * E, part,
+                     range, de_tab);
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }

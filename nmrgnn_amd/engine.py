@@ -68,7 +68,7 @@ class Engine:
         self.fc_act = ACT[hp.get('fc_activation')]
         self.mp_act = ACT[hp.get('mp_activation')]
         self.params = ParamStore(hp, self.C, self.device, seed=seed)
-        self.params.on_change = lambda: self.lib.ng_weights_changed(self.ctx.handle)
+        self.params.on_change = self._on_params_changed
         c, gap = rbf_grid(hp.get('rbf_low'), hp.get('rbf_high'), self.H)
         self.centers = torch.from_numpy(c).to(self.device)
         self.gap = gap
@@ -93,11 +93,20 @@ class Engine:
         # padded slots (edges == 0) are skipped by the fused edge kernels (include/nmrgnn_hip.h: ng_edge_mlp_fwd_live);
         # NG_EDGE_LIVE=0 runs every slot as rounds 1-3 did (A/B measurements, tests)
         self.use_live_edges = os.environ.get("NG_EDGE_LIVE", "1") != "0"
-        # OPT-IN (round 5, csrc/edge_table.hip): the edge MLP is a function of one scalar per edge — evaluate it with the fused
-        # kernels on EDGE_TABLE_POINTS equidistant distances and interpolate every edge (cubic, error < 1e-9 relative); the
-        # backward scatters de onto the table (exact adjoint) and runs the fused backward on the table.  Not the default: the
-        # reference evaluates the MLP per edge and the headline is measured that way.
-        self.edge_table = os.environ.get("NG_EDGE_TABLE", "0") == "1"
+        # DEFAULT since round 6 (round 5: opt-in; csrc/edge_table.hip): the edge MLP is a function of one scalar per edge —
+        # evaluate it with the fused kernels on EDGE_TABLE_POINTS equidistant distances and interpolate every edge (cubic, error
+        # < 1e-9 relative for weights of ordinary size); the backward scatters de onto the table (exact adjoint) and runs the
+        # fused backward on the table.  Guarded on the device: the same launch evaluates the function at the midpoints too,
+        # ng_edge_table_check compares, and above ``edge_table_tol`` x max |e| the SAME call is answered by the per-edge
+        # kernels (they run over a row count that is zero unless the guard is up).  NG_EDGE_TABLE=0 / edge_table = False: the
+        # per-edge kernels always — what the reference does and what bench.py's `value` is measured on.
+        self.edge_table = os.environ.get("NG_EDGE_TABLE", "1") != "0"
+        self.edge_table_tol = 3.0e-6          # bound on |interpolant - function| at the midpoints, relative to max |e| of the table
+        self.edge_table_min_edges = 262144    # below, the table's extra launches (range, check, gated per-edge launch, interpolation:
+                                              # ~60 us) cost more than the per-edge MLP itself (7lgi, one 44 K-edge frame per call: 0.161 against 0.154 ms)
+        self.edge_table_force_fallback = False   # tests: raise the guard whatever the check finds (tol = -1)
+        self._wgen = 0                        # bumped whenever the weights change: a table kept over calls (frozen weights)
+        self._table_cache = None
         Engine._ids += 1
         self._id = Engine._ids          # owner tag of the frozen-weight cache
 
@@ -113,7 +122,12 @@ class Engine:
             self._ck(self.lib.ng_weights_frozen(self.ctx.handle, 0), "ng_weights_frozen")
 
     def weights_changed(self):
+        self._wgen += 1
         self._ck(self.lib.ng_weights_changed(self.ctx.handle), "ng_weights_changed")
+
+    def _on_params_changed(self):
+        self._wgen += 1
+        self.lib.ng_weights_changed(self.ctx.handle)
 
     # ------------------------------------------------------------------ helpers
     def _st(self):
@@ -163,11 +177,11 @@ class Engine:
         d_src = batch.edges.reshape(-1)
         d_eff = d_src
         # live-edge view: the fused edge kernels walk the compacted live slots only (same e bit for bit)
-        use_table = self.edge_table and E <= 4 and ne > 0 and self.fc_act == 1 and H == 128 and self.Le == 4
         # (the live kernels index e with 32 bits: n_slots * E * 4 < 2^31, check_live in edge_fwd_h2.hip; larger batches take the
         # every-slot kernels)
-        live = batch.live_edges() if (not use_table and self.use_live_edges and ne * E * 4 < (1 << 31)
-                                      and lib.ng_edge_live_supported(H, E, self.Le, self.fc_act)) else None
+        live_ok = ne * E * 4 < (1 << 31) and bool(lib.ng_edge_live_supported(H, E, self.Le, self.fc_act))
+        use_table = self.edge_table and E <= 4 and ne >= self.edge_table_min_edges and live_ok
+        live = batch.live_edges(force=use_table) if (live_ok and (use_table or self.use_live_edges)) else None
         if live is not None:
             perm, pos, d_c, n_live = live
             d_src = d_eff = d_c
@@ -183,25 +197,25 @@ class Engine:
                 noise = noise.reshape(-1)
                 self._ck(lib.ng_add_scaled(h, st, ne, ptr(d_src), ptr(noise), self.sigma, ptr(d_eff)),
                          "ng_add_scaled")
-        table = self._edge_table_forward(batch, d_eff, tape) if use_table else None
-        if table is not None:
-            e, d_eff, z_save, z_layout = table["e"], table["d_eff"], None, 0
-            live = None
-        else:
-            e = None
-        z_save = (self._new(self.Le - 1, ne, H) if tape else None) if table is None else None
+        # the table of the edge function and the guard's verdict (device words) — before the per-edge launch, which runs over
+        # gate[1] rows: none unless the guard is up
+        table = self._edge_table_build(batch, live, d_eff, tape, training) if (use_table and live is not None) else None
+        z_save = self._new(self.Le - 1, ne, H) if tape else None
         # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
         # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
-        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if (tape and table is None) else 0
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if tape else 0
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
-        if table is not None:
-            pass
-        elif live is not None:
+        if live is not None:
             e = self._new(ne, E)
+            rows = table["gate"][1:] if table is not None else n_live
             self._ck(lib.ng_edge_mlp_fwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff), ptr(perm),
-                                              ptr(n_live), ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
+                                              ptr(rows), ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
                                               ptr(e), ptr(z_save)), "ng_edge_mlp_fwd_live")
+            if table is not None:       # every slot from the table — unless the guard is up: then the launch returns at once
+                self._ck(lib.ng_edge_table_interp(h, st, ne, E, table["T"], ptr(batch.edges), ptr(d_eff), ptr(pos),
+                                                  ptr(table["rng"]), ptr(table["e_all"]), ptr(table["gate"]), ptr(e)),
+                         "ng_edge_table_interp")
         else:
             e = self._new(ne, E)
             self._ck(lib.ng_edge_mlp_fwd(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff),
@@ -285,42 +299,93 @@ class Engine:
     # ------------------------------------------------------------------ edge function table (opt-in)
     EDGE_TABLE_POINTS = 4096
 
-    def _edge_table_forward(self, batch, d_eff, tape):
-        """e[ne,E] by interpolation in a table of the edge function (csrc/edge_table.hip); keeps what the backward needs.
-        ``d_eff``: the distances fed to the RBF, slot order (noise already added when training)"""
+    def _edge_table_build(self, batch, live, d_eff_c, tape, training):
+        """The table of the edge function for this call (csrc/edge_table.hip) and the guard's gate words.
+        ``d_eff_c``: the distances fed to the RBF in the COMPACTED row order of the live view (noise already added when
+        training).  With frozen weights and no tape the table of an earlier call is reused while the weights stay the same:
+        then only the call's distance range is checked against the table's."""
         lib, h, st = self.lib, self.ctx.handle, self._st()
         P = self.params
+        perm, pos, d_c, n_live = live
         ne, E, H, T = batch.n_edges, self.E, self.H, self.EDGE_TABLE_POINTS
         d_src = batch.edges.reshape(-1)
+        tol = -1.0 if self.edge_table_force_fallback else float(self.edge_table_tol)
+        reuse = self._frozen and not tape and not training and not self.edge_table_force_fallback
+        gate = torch.empty(8, dtype=torch.int32, device=self.device)
+        if reuse and self._table_cache is not None and self._table_cache["key"] == (self._wgen, T, E):
+            c = self._table_cache
+            cover = self._new(4)
+            self._ck(lib.ng_edge_table_range(h, st, ne, E, ptr(d_src), ptr(d_eff_c), ptr(pos), None, 0.0, ptr(cover)),
+                     "ng_edge_table_range")
+            self._ck(lib.ng_edge_table_check(h, st, T, E, None, 0.0, ptr(c["rng"]), ptr(cover), ptr(n_live), 2 * T,
+                                             ptr(c["gate"]), ptr(gate)), "ng_edge_table_check")
+            return {"e_all": c["e_all"], "rng": c["rng"], "gate": gate, "T": T}
         rng = self._new(4)
-        self._ck(lib.ng_edge_table_range(h, st, ne, E, ptr(d_src), ptr(d_eff), None, ptr(rng)), "ng_edge_table_range")
-        d_tab, ones = self._new(T), self._new(T)
-        self._ck(lib.ng_edge_table_points(h, st, T, ptr(rng), ptr(d_tab), ptr(ones)), "ng_edge_table_points")
-        e_tab = self._new(T, E)
-        z_tab = self._new(self.Le - 1, T, H) if tape else None
-        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, T)) if tape else 0
+        # a table kept over calls covers a quarter more on either side than the call that builds it
+        self._ck(lib.ng_edge_table_range(h, st, ne, E, ptr(d_src), ptr(d_eff_c), ptr(pos), None, 0.25 if reuse else 0.0, ptr(rng)),
+                 "ng_edge_table_range")
+        d_tab, ones = self._new(2 * T), self._new(2 * T)
+        perm_tab = torch.empty(2 * T, dtype=torch.int32, device=self.device)
+        self._ck(lib.ng_edge_table_points(h, st, T, 1, ptr(rng), ptr(d_tab), ptr(ones), ptr(perm_tab)), "ng_edge_table_points")
+        if getattr(self, "_rows_2t", None) is None or int(self._rows_2t_value) != 2 * T:
+            self._rows_2t = torch.full((1,), 2 * T, dtype=torch.int32, device=self.device)
+            self._rows_2t_value = 2 * T
+        e_all = self._new(2 * T, E)
+        z_tab = self._new(self.Le - 1, 2 * T, H) if tape else None
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, 2 * T)) if tape else 0
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_fwd(h, st, T, H, E, self.Le, self.fc_act, ptr(ones), ptr(d_tab), ptr(self.centers), self.gap,
-                                     ptr_array(W), ptr_array(B), ptr(e_tab), ptr(z_tab)), "ng_edge_mlp_fwd")
-        e = self._new(ne, E)
-        self._ck(lib.ng_edge_table_interp(h, st, ne, E, T, ptr(d_src), ptr(d_eff), ptr(rng), ptr(e_tab), ptr(e)),
-                 "ng_edge_table_interp")
-        return {"e": e, "d_eff": d_eff, "rng": rng, "d_tab": d_tab, "ones": ones, "z_tab": z_tab, "z_layout": z_layout, "T": T}
+        # rows 0 .. T-1: the table; rows T .. 2T-1: the midpoints the guard compares at (same launch: the 32 tiles run side by side)
+        self._ck(lib.ng_edge_mlp_fwd_live(h, st, 2 * T, H, E, self.Le, self.fc_act, ptr(ones), ptr(d_tab), ptr(perm_tab),
+                                          ptr(self._rows_2t), ptr(self.centers), self.gap, ptr_array(W), ptr_array(B),
+                                          ptr(e_all), ptr(z_tab)), "ng_edge_mlp_fwd_live")
+        self._ck(lib.ng_edge_table_check(h, st, T, E, ptr(e_all), tol, ptr(rng), None, ptr(n_live), 2 * T, None, ptr(gate)),
+                 "ng_edge_table_check")
+        tb = {"e_all": e_all, "rng": rng, "gate": gate, "T": T, "d_tab": d_tab, "ones": ones, "perm_tab": perm_tab, "z_tab": z_tab,
+              "z_layout": z_layout}
+        if reuse:
+            self._table_cache = {"key": (self._wgen, T, E), "e_all": e_all, "rng": rng, "gate": gate}
+        return tb
+
+    def edge_table_report(self, table=None):
+        """(guard up?, interpolation error at the midpoints, largest |e| of the table) of the last taped call's table (or of
+        ``table``).  Reads device words: synchronises; for tests and diagnostics."""
+        tb = table if table is not None else (self.tape.table if self.tape is not None else None)
+        if tb is None:
+            return None
+        g = tb["gate"].cpu().numpy()
+        return bool(g[0]), float(g[4:6].view(np.float32)[0]), float(g[4:6].view(np.float32)[1])
 
     def _edge_table_backward(self, tp, de):
+        """edge-weight gradients of a call that went through the table: the per-edge backward over gate[1] rows (zero unless the
+        guard was up) into temporaries, the table's backward over gate[2] rows (zero when it was) into the gradients, and the
+        sum of the two — one of which is exactly zero."""
         lib, h, st = self.lib, self.ctx.handle, self._st()
         P, tb, b = self.params, tp.table, tp.batch
         ne, E, H, T = b.n_edges, self.E, self.H, tb["T"]
-        de_tab = self._new(T, E)
-        self._ck(lib.ng_edge_table_scatter(h, st, ne, E, T, ptr(b.edges), ptr(tp.d_eff), ptr(tb["rng"]), ptr(de), ptr(de_tab)),
-                 "ng_edge_table_scatter")
+        perm, pos, d_c, n_live = tp.live
+        names = [f"edge_fc/{t}/{k}" for t in range(self.Le) for k in ("kernel", "bias")]
+        o0 = min(P.offsets[n] for n in names)
+        o1 = max(P.offsets[n] + int(np.prod(P.shapes[n])) for n in names)
+        tmp = self._new(o1 - o0)
+        tv = lambda n: tmp[P.offsets[n] - o0:P.offsets[n] - o0 + int(np.prod(P.shapes[n]))]
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
-        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, T, H, E, self.Le, self.fc_act, ptr(tb["ones"]), ptr(tb["d_tab"]),
-                                          ptr(self.centers), self.gap, ptr_array(W), ptr(tb["z_tab"]), ptr(de_tab),
-                                          ptr_array(dW), ptr_array(dB), tb["z_layout"]), "ng_edge_mlp_bwd")
+        dWt = [tv(f"edge_fc/{t}/kernel") for t in range(self.Le)]
+        dBt = [tv(f"edge_fc/{t}/bias") for t in range(self.Le)]
+        self._ck(lib.ng_edge_mlp_bwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_c), ptr(tp.d_eff), ptr(perm),
+                                          ptr(tb["gate"][1:]), ptr(self.centers), self.gap, ptr_array(W), ptr(tp.z_save),
+                                          ptr(de), ptr_array(dWt), ptr_array(dBt), tp.z_layout), "ng_edge_mlp_bwd_live")
+        de_tab = self._new(2 * T, E)
+        self._ck(lib.ng_edge_table_scatter(h, st, ne, E, T, 2 * T, ptr(b.edges), ptr(tp.d_eff), ptr(pos), ptr(tb["rng"]), ptr(de),
+                                           ptr(de_tab)), "ng_edge_table_scatter")
+        self._ck(lib.ng_edge_mlp_bwd_live(h, st, 2 * T, H, E, self.Le, self.fc_act, ptr(tb["ones"]), ptr(tb["d_tab"]),
+                                          ptr(tb["perm_tab"]), ptr(tb["gate"][2:]), ptr(self.centers), self.gap, ptr_array(W),
+                                          ptr(tb["z_tab"]), ptr(de_tab), ptr_array(dW), ptr_array(dB), tb["z_layout"]),
+                 "ng_edge_mlp_bwd_live")
+        blk = P.grad[o0:o1]
+        self._ck(lib.ng_add_scaled(h, st, o1 - o0, ptr(blk), ptr(tmp), 1.0, ptr(blk)), "ng_add_scaled")
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpeaks, on_node_grads=None):
@@ -440,6 +505,7 @@ class Engine:
         if lr is None:
             lr = float(self.hp.get('learning_rate'))
         self.adam_t += 1
+        self._wgen += 1
         P = self.params
         if self.cache_images:       # the update is followed by ONE launch that rebuilds this engine's packed weight images
             self._ck(self.lib.ng_weights_frozen(self.ctx.handle, self._id), "ng_weights_frozen")

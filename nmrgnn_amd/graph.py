@@ -218,11 +218,15 @@ class GraphBatch:
         ptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=self.N), 0)
         self._csc = (ptr.to(torch.int32).contiguous(), eid[order].to(torch.int32).contiguous())
 
-    def live_edges(self):
+    def live_edges(self, force=False):
         """(perm, pos, d_c, n_live) of the padded lists (include/nmrgnn_hip.h: ng_build_live_edges) — the row order of
         the compacted edge kernels; built once per batch on the device, no host synchronisation.  None for a CSR batch
-        (every entry is live) and for lists known to carry no padded slot."""
-        if self.is_csr or self.nlist_c is self.nlist or self.device.type != "cuda" or self.n_edges == 0:
+        (every entry is live) and for lists known to carry no padded slot — unless ``force``: the edge-function table's
+        guard runs the per-edge kernels over a device-side row count, which only the live view offers (the view of a list
+        without dead entries is the identity)."""
+        if self.device.type != "cuda" or self.n_edges == 0:
+            return None
+        if not force and (self.is_csr or self.nlist_c is self.nlist):
             return None
         if self._live is None:
             import ctypes as C

@@ -166,7 +166,9 @@ class ForwardReplay:
 
     def _one(self):
         self._gb = frames_to_batch(self.atoms, self.s_pos, self.K, device=self.eng.device)   # kept alive: the chain reads its buffers
-        return self.eng.forward(self._gb)
+        out = self.eng.forward(self._gb)
+        self._table = self.eng._table_cache      # (the edge-function table of frozen weights the captured calls read)
+        return out
 
     def __call__(self, positions):
         p = _like(self.s_pos, positions)

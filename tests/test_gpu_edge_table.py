@@ -1,5 +1,7 @@
-"""Opt-in edge path through a table of the edge function (csrc/edge_table.hip, Engine.edge_table): e, peaks and every
-gradient against the per-edge kernels and the float64 oracle; run-to-run bits."""
+"""Edge path through a table of the edge function (csrc/edge_table.hip, Engine.edge_table — the default on batches of 256 K
+edges and more since round 6, behind a device-side guard): e, peaks and every gradient against the per-edge kernels and the
+float64 oracle; run-to-run bits; the guard (forced, and tripped by weights that make the edge function too sharp for the
+table); the table kept over calls under frozen weights."""
 import numpy as np
 import pytest
 import torch
@@ -13,7 +15,9 @@ def _engines(F, dev, seed=3):
     hp = declare_gnn_space(HyperParameters(atom_feature_size=F, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
                                            fc_layers=4, edge_fc_layers=4))
     a, b = Engine(hp, 10, device=dev, seed=seed), Engine(hp, 10, device=dev, seed=seed)
+    a.edge_table = False
     b.edge_table = True
+    b.edge_table_min_edges = 0
     return a, b
 
 
@@ -55,6 +59,7 @@ def test_table_path_against_the_oracle(gpu_device):
     import test_gpu_parity as TP
     hp, b, eng, sd, gb, std, avg = TP._setup(gpu_device, TP.CONFIGS[0])
     eng.edge_table = True
+    eng.edge_table_min_edges = 0
     N, K = b["edges"].shape
     Fh = hp.get('atom_feature_size') // 2
     xi = eng.randn(N * K, seed=123)
@@ -70,3 +75,98 @@ def test_table_path_against_the_oracle(gpu_device):
     assert np.max(np.abs(peaks.cpu().numpy() - ref_peaks)) < TP.PEAK_ATOL
     bad = {k: rel_err(grads[k], g) for k, g in ref_grads.items() if rel_err(grads[k], g) > TP.GRAD_RTOL}
     assert not bad, bad
+
+
+def _step(eng, gb, y, w, seed=99):
+    p = eng.forward(gb, training=True, seed=seed)
+    e, eng.last_table = eng.tape.e.clone(), eng.tape.table
+    loss, d = eng.loss_l2(gb, y, w, p)
+    eng.backward(d)
+    return p.clone(), e, eng.params.grad.clone()
+
+
+def test_forced_guard_gives_the_per_edge_path_bit_for_bit(gpu_device):
+    """with the guard up the call IS the per-edge call: same kernels over the same rows (the table's own launches do nothing),
+    e, peaks and every gradient bit for bit — also for lists without a dead slot (identity live view) and inference"""
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.graph import GraphBatch
+    for pad in (0.05, 0.0):
+        b = synth.make_batch(12, 256, 16, 10, pad, seed=5)
+        gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+        y = torch.from_numpy(b["y"]).to(gpu_device); w = torch.from_numpy(b["w"]).to(gpu_device)
+        ea, eb = _engines(64, gpu_device)
+        eb.edge_table_force_fallback = True
+        pa, e_a, ga = _step(ea, gb, y, w)
+        pb, e_b, gb_ = _step(eb, gb, y, w)
+        assert eb.last_table is not None and eb.edge_table_report(eb.last_table)[0]
+        assert torch.equal(e_a, e_b) and torch.equal(pa, pb) and torch.equal(ga, gb_)
+        assert torch.equal(ea.forward(gb), eb.forward(gb))
+
+
+@pytest.mark.parametrize("scale,bias", [(1.0, 0.0), (4.0, 0.0), (4.0, 5.0), (16.0, -5.0), (16.0, 5.0)])
+def test_sharp_edge_functions_meet_the_tolerance_or_raise_the_guard(gpu_device, scale, bias):
+    """edge weights x 4 / x 16 and biases +- 5: the edge function gets steeper than anything glorot initialisation gives.
+    Either the midpoint check passes and the table path agrees with the per-edge path to the tolerances of the ordinary case,
+    or the guard is up and the results are the per-edge ones."""
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.graph import GraphBatch
+    b = synth.make_batch(12, 256, 16, 10, 0.05, seed=7)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    y = torch.from_numpy(b["y"]).to(gpu_device); w = torch.from_numpy(b["w"]).to(gpu_device)
+    ea, eb = _engines(64, gpu_device)
+    rng = np.random.default_rng(3)
+    for eng in (ea, eb):
+        sd = eng.params.state_dict()
+        for t in range(4):
+            sd[f"edge_fc/{t}/kernel"] = sd[f"edge_fc/{t}/kernel"] * np.float32(scale)
+            sd[f"edge_fc/{t}/bias"] = (bias * np.random.default_rng(10 + t).uniform(-1, 1, sd[f"edge_fc/{t}/bias"].shape)).astype(np.float32)
+        eng.params.load_state_dict(sd)
+    pa, e_a, ga = _step(ea, gb, y, w)
+    pb, e_b, gb_ = _step(eb, gb, y, w)
+    up, err, sc = eb.edge_table_report(eb.last_table)
+    print(f"[edge weights x {scale}, biases +-{bias}] guard {'UP' if up else 'down'}: midpoint error {err:.3e}, max |e| {sc:.3e}, "
+          f"ratio {err / max(sc, 1e-30):.2e}")
+    assert torch.isfinite(pb).all() and torch.isfinite(gb_).all()
+    if up:
+        assert torch.equal(e_a, e_b) and torch.equal(pa, pb) and torch.equal(ga, gb_)
+    else:
+        assert err <= eb.edge_table_tol * sc
+        assert float((e_a - e_b).abs().max()) <= 4e-6 * max(float(e_a.abs().max()), 1.0)
+        assert float((pa - pb).abs().max()) <= 4e-6 * max(float(pa.abs().max()), 1.0)
+        for name in ea.params.offsets:
+            x, z = ea.params.g(name), eb.params.g(name)
+            assert float((x - z).abs().max()) <= 4e-5 * max(float(x.abs().max()), 1e-12), name
+
+
+def test_table_is_kept_over_calls_while_the_weights_are_frozen(gpu_device):
+    """inference with freeze_weights: the table is built by the first call (its range widened by a quarter) and later calls
+    only check their distances against it; a frame whose distances leave the range is answered per edge (guard), a weight
+    change rebuilds the table"""
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.graph import GraphBatch
+    ea, eb = _engines(64, gpu_device)
+    ea.freeze_weights(True); eb.freeze_weights(True)
+    batches = []
+    for s, stretch in ((1, 1.0), (2, 1.02), (3, 0.97), (4, 3.0)):
+        b = synth.make_batch(10, 256, 16, 10, 0.05, seed=20 + s)
+        b["edges"] = (b["edges"] * np.float32(stretch)).astype(np.float32)
+        batches.append(GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device))
+    built = []
+    for i, gb in enumerate(batches):
+        pa, pb = ea.forward(gb), eb.forward(gb)
+        built.append(id(eb._table_cache["e_all"]))
+        assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1.0), i
+    assert len(set(built)) == 1                      # one table for the four calls
+    # the stretched frame was answered per edge: bit for bit
+    tb = eb._edge_table_build(batches[3], batches[3].live_edges(force=True), batches[3].live_edges(force=True)[2], False, False)
+    assert bool(tb["gate"].cpu()[0] != 0)
+    assert torch.equal(ea.forward(batches[3]), eb.forward(batches[3]))
+    tb = eb._edge_table_build(batches[1], batches[1].live_edges(force=True), batches[1].live_edges(force=True)[2], False, False)
+    assert bool(tb["gate"].cpu()[0] == 0)
+    # new weights: a new table
+    sd = eb.params.state_dict()
+    sd["edge_fc/0/kernel"] = sd["edge_fc/0/kernel"] * np.float32(1.1)
+    ea.params.load_state_dict(sd); eb.params.load_state_dict(sd)
+    pa, pb = ea.forward(batches[0]), eb.forward(batches[0])
+    assert id(eb._table_cache["e_all"]) != built[0]
+    assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1.0)

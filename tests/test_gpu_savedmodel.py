@@ -33,11 +33,15 @@ STD_ATOL = 5e-5
 REF32_FACTOR = {"padded": 3.0, "pdb108m": 1.5}     # pdb108m measures 0.7-0.9 x; only the small padded case needs 3 x
 
 
-def _engine(gpu_device, c):
+def _engine(gpu_device, c, edge_table=False):
+    """edge_table: the edge MLP through the guarded table of the edge function (the Engine's default on batches of 256 K edges
+    and more; forced here whatever the size) or evaluated per edge"""
     from nmrgnn_amd.engine import Engine
     from nmrgnn_amd.graph import GraphBatch
     hp = make_hp(atom_feature_size=c["F"])
     eng = Engine(hp, 10, c["peak_std"], c["peak_avg"], device=gpu_device, seed=1)
+    eng.edge_table = bool(edge_table)
+    eng.edge_table_min_edges = 0
     eng.params.load_state_dict(c["weights"])
     gb = GraphBatch(c["atoms"], c["nlist"], c["edges"], c["inv_degree"], device=gpu_device)
     return eng, gb
@@ -69,24 +73,32 @@ def _check(tag, c, peaks, ref64, ref32, what):
             assert err == 0.0           # std = avg = 0 elements predict exactly 0 (model.py:272-273)
 
 
+@pytest.mark.parametrize("edge_table", [False, True], ids=["per_edge", "edge_table"])
 @pytest.mark.parametrize("tag", ["padded", "pdb108m"])
-def test_hip_equals_reference_graph_inference(gpu_device, tag):
+def test_hip_equals_reference_graph_inference(gpu_device, tag, edge_table):
     c = load_savedmodel_case(tag)
-    eng, gb = _engine(gpu_device, c)
-    peaks = eng.forward(gb, training=False).cpu().numpy()
-    _check(tag, c, peaks, c["peaks64"], c["peaks32"], "inference")
+    eng, gb = _engine(gpu_device, c, edge_table)
+    peaks = eng.forward(gb, training=False, keep_tape=edge_table).cpu().numpy()
+    if edge_table:
+        up, err, scale = eng.edge_table_report()
+        print(f"[{tag}/inference] edge table: guard {'UP' if up else 'down'}, midpoint error {err:.3e} of max |e| {scale:.3e}")
+        assert not up
+    _check(tag, c, peaks, c["peaks64"], c["peaks32"], "inference" + ("/table" if edge_table else ""))
 
 
+@pytest.mark.parametrize("edge_table", [False, True], ids=["per_edge", "edge_table"])
 @pytest.mark.parametrize("tag", ["padded", "pdb108m"])
-def test_hip_equals_reference_graph_training(gpu_device, tag):
+def test_hip_equals_reference_graph_training(gpu_device, tag, edge_table):
     """training=True trace with the fixture's explicit GaussianNoise / Dropout draws."""
     import torch
     c = load_savedmodel_case(tag)
-    eng, gb = _engine(gpu_device, c)
+    eng, gb = _engine(gpu_device, c, edge_table)
     xi = torch.from_numpy(c["train_xi"]).to(gpu_device)
     mask = torch.from_numpy((c["train_keep"].astype(np.float32) * np.float32(1.25))).to(gpu_device)
     peaks = eng.forward(gb, training=True, noise=xi, dropout_mask=mask).cpu().numpy()
-    _check(tag, c, peaks, c["train_peaks64"], c["train_peaks32"], "training")
+    if edge_table:
+        assert eng.tape.table is not None and not eng.edge_table_report()[0]
+    _check(tag, c, peaks, c["train_peaks64"], c["train_peaks32"], "training" + ("/table" if edge_table else ""))
 
 
 @pytest.mark.parametrize("math", ["fp32"])
@@ -95,7 +107,7 @@ def test_strict_fp32_mfma_has_the_same_error(gpu_device, monkeypatch, math):
     (NG_EDGE_MATH / NG_GEMM_MATH = fp32) the error against the reference graph is of the same size,
     i.e. the remaining distance is float32 arithmetic, not the split."""
     c = load_savedmodel_case("pdb108m")
-    eng, gb = _engine(gpu_device, c)
+    eng, gb = _engine(gpu_device, c)        # per edge: the switches select edge kernels
     base = eng.forward(gb, training=False).cpu().numpy().astype(np.float64)
     monkeypatch.setenv("NG_EDGE_MATH", math)
     monkeypatch.setenv("NG_GEMM_MATH", math)
