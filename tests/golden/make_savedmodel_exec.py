@@ -334,6 +334,64 @@ class Interp:
         raise NotImplementedError(f"op {op} ({n['name']})")
 
 
+class TorchInterp(Interp):
+    """A SECOND backend for the primitive ops (task 5a): every arithmetic node is evaluated by torch's CPU
+    float64 kernels (einsum / matmul / index_select / logaddexp / ...) instead of NumPy's; graph walking, constants, slicing
+    and shape ops are shared.  main() asserts that the two backends agree to 1e-12 of the output scale on every case and both
+    FunctionDefs: a wrong result would have to come out of two independent numerical libraries identically."""
+
+    def eval(self, n, value):
+        import torch
+        op, a = n["op"], n["attr"]
+        arith = {"Sub", "AddV2", "Add", "Mul", "RealDiv", "Neg", "Pow", "Exp", "Softplus", "GatherV2", "Prod", "Sum", "MatMul",
+                 "BiasAdd", "Einsum", "Transpose"}
+        if op not in arith:
+            return super().eval(n, value)
+        self.ops_seen[op] = self.ops_seen.get(op, 0) + 1
+        x = [value(r) for r in n["input"] if not r.startswith("^")]
+        t = lambda v: torch.from_numpy(np.ascontiguousarray(v))
+        back = lambda v: v.numpy()
+        if op == "Sub":
+            return back(t(x[0]) - t(x[1]))
+        if op in ("AddV2", "Add", "BiasAdd"):
+            return back(t(x[0]) + t(x[1]))
+        if op == "Mul":
+            return back(t(x[0]) * t(x[1]))
+        if op == "RealDiv":
+            return back(t(x[0]) / t(x[1]))
+        if op == "Neg":
+            return back(-t(x[0]))
+        if op == "Pow":
+            return back(torch.pow(t(x[0]), t(x[1])))
+        if op == "Exp":
+            return back(torch.exp(t(x[0])))
+        if op == "Softplus":      # log(1 + exp(x)) without TensorFlow's three-branch form: the branches differ from it by < 2^-52
+            return back(torch.logaddexp(t(x[0]), torch.zeros((), dtype=t(x[0]).dtype)))
+        if op == "GatherV2":
+            idx = t(np.asarray(x[1]).astype(np.int64))
+            out = torch.index_select(t(x[0]), int(x[2]), idx.reshape(-1))
+            shp = list(x[0].shape)
+            ax = int(x[2])
+            return back(out.reshape(shp[:ax] + list(np.asarray(x[1]).shape) + shp[ax + 1:]))
+        if op == "Prod":
+            r = t(x[0])
+            for ax in sorted(np.atleast_1d(x[1]).tolist(), reverse=True):
+                r = torch.prod(r, dim=int(ax), keepdim=a.get("keep_dims", {}).get("b", False))
+            return back(r).astype(x[0].dtype)
+        if op == "Sum":
+            return back(torch.sum(t(x[0]), dim=tuple(int(v) for v in np.atleast_1d(x[1]).tolist()),
+                                  keepdim=a.get("keep_dims", {}).get("b", False)))
+        if op == "MatMul":
+            A = t(x[0]).T if a.get("transpose_a", {}).get("b", False) else t(x[0])
+            B = t(x[1]).T if a.get("transpose_b", {}).get("b", False) else t(x[1])
+            return back(torch.matmul(A, B))
+        if op == "Einsum":
+            return back(torch.einsum(a["equation"]["s"], *[t(v) for v in x]))
+        if op == "Transpose":
+            return back(t(x[0]).permute(*np.asarray(x[1]).tolist()).contiguous())
+        raise NotImplementedError(op)
+
+
 # resource argument (suffix after the function's name prefix) -> (state-dict key of this repo).
 # SURVEY App. A: edge-fc-block/dense..dense_3, mp-block/MPLayer w x4 (einsum, einsum_1..3),
 # fc-block/dense_4..7, out_layer = dense_8, embed_layer = dense_9.
@@ -423,6 +481,15 @@ def graph_108M():
     return atoms, nlist.astype(np.int32), edges.astype(np.float32), S.inv_degree_of(nlist)
 
 
+def graph_7lgi():
+    """frame 0 of tests/data/7lgi.pdb.gz (the reference's tests/7lgi.pdb.gz, BASELINE configs[4]): 2770 atoms, kNN K = 16"""
+    from nmrgnn_amd import structure as S
+    s = S.read_pdb(os.path.join(ROOT, "tests", "data", "7lgi.pdb.gz"))
+    nlist, edges = S.knn_graph(s.frames[0], 16)
+    atoms = S.atoms_onehot(s.elements)
+    return atoms, nlist.astype(np.int32), edges.astype(np.float32), S.inv_degree_of(nlist)
+
+
 def graph_padded(seed=11):
     """3 synthetic graphs (40/17/9 atoms; the 9-atom one has fewer than 16 possible neighbours, so
     half its slots are padding), global indices, an atom with NO neighbour at all, every element
@@ -449,7 +516,7 @@ def graph_padded(seed=11):
     return atoms.astype(np.float32), nlist.astype(np.int32), edges.astype(np.float32), inv.astype(np.float32)
 
 
-def run_function(fd, top_consts, graph, weights, float_dtype, random_feed=None, keep=()):
+def run_function(fd, top_consts, graph, weights, float_dtype, random_feed=None, keep=(), backend=None):
     vmap = variable_map(fd)
     variables = {res: weights[key] for res, key in vmap.items()}
     centers = next(v for v in top_consts.values() if v.shape == (128,))
@@ -458,7 +525,7 @@ def run_function(fd, top_consts, graph, weights, float_dtype, random_feed=None, 
     # the first four are the serving inputs, the next two the captured RBF constants (sub_y, truediv_y)
     assert len(names) == 6 and "sub_y" in names[4] and "truediv_y" in names[5], names
     feeds = dict(zip(names, [graph[0], graph[1], graph[2], graph[3], centers, gap]))
-    it = Interp(fd, float_dtype, variables, random_feed)
+    it = (backend or Interp)(fd, float_dtype, variables, random_feed)
     out = it.run(feeds)
     extra = {k: it.env[k] for k in keep if k in it.env}
     return out, it.ops_seen, extra
@@ -468,8 +535,12 @@ def main():
     funcs, top_consts = load_functions()
     out = {}
     summary = []
-    cases = [("pdb108m", graph_108M(), 256, 4657), ("padded", graph_padded(), 64, 4658)]
-    for tag, g, F, wseed in cases:
+    g108 = graph_108M()
+    # (tag, graph, width, weight seed, tag of an earlier case with the same graph or None).  Round 6 added the whole-protein case
+    # of BASELINE configs[4] (7lgi frame 0 at the bundled architecture) and the bench architecture (F = 64) on the 108M graph.
+    cases = [("pdb108m", g108, 256, 4657, None), ("padded", graph_padded(), 64, 4658, None),
+             ("lgi7", graph_7lgi(), 256, 4659, None), ("pdb108m_f64", g108, 64, 4660, "pdb108m")]
+    for tag, g, F, wseed, graph_of in cases:
         w = seeded_weights(F, wseed)
         N, K = g[2].shape
         fd = funcs[FN_INFER]
@@ -481,6 +552,8 @@ def main():
         # carries a bit mask instead of 1.2 MB of uniforms
         rng = np.random.default_rng(wseed + 1)
         xi = rng.standard_normal((N, K)).astype(np.float32)
+        if tag not in ("pdb108m", "padded"):     # the later cases store their draws as float16: the draws ARE those values
+            xi = xi.astype(np.float16).astype(np.float32)
         keep_mask = rng.random((N, F // 2)) >= 0.2
         u = keep_mask.astype(np.float32)
         fdt = funcs[FN_TRAIN]
@@ -488,19 +561,32 @@ def main():
                 "dropout/dropout/random_uniform/RandomUniform": u}
         t64, ops_t, _ = run_function(fdt, top_consts, g, w, np.float64, feed)
         t32, _, _ = run_function(fdt, top_consts, g, w, np.float32, feed)
+        # second backend for the primitive ops (torch CPU float64): both functions must agree to 1e-12 of the output scale
+        q64, _, _ = run_function(fd, top_consts, g, w, np.float64, backend=TorchInterp)
+        u64, _, _ = run_function(fdt, top_consts, g, w, np.float64, feed, backend=TorchInterp)
+        sc = max(1.0, float(np.abs(p64).max()))
+        d_inf, d_tr = float(np.abs(q64 - p64).max()), float(np.abs(u64 - t64).max())
+        assert d_inf <= 1e-12 * sc and d_tr <= 1e-12 * sc, (tag, d_inf, d_tr, sc)
+        print("   torch-CPU float64 backend vs NumPy: inference %.2e, training %.2e (scale %.1f)" % (d_inf, d_tr, sc))
         el = np.argmax(g[0], axis=1).astype(np.int8)
         assert np.array_equal(np.eye(10, dtype=np.float32)[el], g[0])
+        if graph_of is None:
+            out.update({f"{tag}:elem": el, f"{tag}:nlist": g[1].astype(np.int16 if N < 32768 else np.int32),
+                        f"{tag}:edges": g[2], f"{tag}:inv_degree": g[3]})
+        else:
+            out[f"{tag}:graph_of"] = np.array(graph_of)
+        full = tag in ("pdb108m", "padded")     # the first two cases carry intermediates of the float64 run too
+        if full:
+            out.update({
+                # intermediates of the float64 run (float32-rounded, for debugging a mismatch):
+                # masked edge features e[N,K,3] and every 16th row of the node features after the MP block
+                f"{tag}:e64": ex64["gnn-model/mul_1"].astype(np.float32),
+                f"{tag}:h_mp64_rows16": ex64["gnn-model/mp-block/add_3"][::16].astype(np.float32)})
         out.update({
-            f"{tag}:elem": el, f"{tag}:nlist": g[1].astype(np.int16 if N < 32768 else np.int32),
-            f"{tag}:edges": g[2], f"{tag}:inv_degree": g[3],
             f"{tag}:F": np.int64(F), f"{tag}:weight_seed": np.int64(wseed),
             f"{tag}:weights_sha256": np.array(weights_digest(w)),
             f"{tag}:peaks64": p64, f"{tag}:peaks32": p32.astype(np.float32),
-            # intermediates of the float64 run (float32-rounded, for debugging a mismatch):
-            # masked edge features e[N,K,3] and every 16th row of the node features after the MP block
-            f"{tag}:e64": ex64["gnn-model/mul_1"].astype(np.float32),
-            f"{tag}:h_mp64_rows16": ex64["gnn-model/mp-block/add_3"][::16].astype(np.float32),
-            f"{tag}:train_xi": xi, f"{tag}:train_keep_bits": np.packbits(keep_mask, axis=None),
+            f"{tag}:train_xi": xi.astype(np.float16) if not full else xi, f"{tag}:train_keep_bits": np.packbits(keep_mask, axis=None),
             f"{tag}:train_peaks64": t64, f"{tag}:train_peaks32": t32.astype(np.float32),
         })
         summary.append((tag, N, F, float(np.abs(p64).max()), float(np.abs(p32 - p64).max()),

@@ -81,16 +81,23 @@ def load_savedmodel_case(tag):
         h.update(k.encode())
         h.update(np.ascontiguousarray(w[k], np.float32).tobytes())
     assert h.hexdigest() == str(z[f"{tag}:weights_sha256"]), "seeded weights differ from the fixture's"
-    elem = z[f"{tag}:elem"].astype(np.int64)
+    gt = str(z[f"{tag}:graph_of"]) if f"{tag}:graph_of" in z.files else tag      # a case on the graph of an earlier one
+    elem = z[f"{gt}:elem"].astype(np.int64)
     atoms = np.eye(10, dtype=np.float32)[elem]
-    edges = z[f"{tag}:edges"]
+    edges = z[f"{gt}:edges"]
     N, K = edges.shape
     keep = np.unpackbits(z[f"{tag}:train_keep_bits"])[:N * (F // 2)].reshape(N, F // 2).astype(bool)
-    return dict(F=F, weights=w, atoms=atoms, nlist=z[f"{tag}:nlist"].astype(np.int32), edges=edges,
-                inv_degree=z[f"{tag}:inv_degree"], peak_std=z["peak_std"], peak_avg=z["peak_avg"],
-                peaks64=z[f"{tag}:peaks64"], peaks32=z[f"{tag}:peaks32"], e64=z[f"{tag}:e64"],
-                h_mp64_rows16=z[f"{tag}:h_mp64_rows16"], train_xi=z[f"{tag}:train_xi"], train_keep=keep,
-                train_peaks64=z[f"{tag}:train_peaks64"], train_peaks32=z[f"{tag}:train_peaks32"])
+    c = dict(F=F, weights=w, atoms=atoms, nlist=z[f"{gt}:nlist"].astype(np.int32), edges=edges,
+             inv_degree=z[f"{gt}:inv_degree"], peak_std=z["peak_std"], peak_avg=z["peak_avg"],
+             peaks64=z[f"{tag}:peaks64"], peaks32=z[f"{tag}:peaks32"],
+             train_xi=z[f"{tag}:train_xi"].astype(np.float32), train_keep=keep,      # (later cases store the draws as float16)
+             train_peaks64=z[f"{tag}:train_peaks64"], train_peaks32=z[f"{tag}:train_peaks32"])
+    if f"{tag}:e64" in z.files:      # intermediates of the float64 run: the first two cases only
+        c.update(e64=z[f"{tag}:e64"], h_mp64_rows16=z[f"{tag}:h_mp64_rows16"])
+    return c
+
+
+SAVEDMODEL_CASES = ["padded", "pdb108m", "lgi7", "pdb108m_f64"]
 
 
 # ---- full-batch oracle gradients, graph by graph (graphs are independent, so the batch gradient is the

@@ -51,13 +51,26 @@ def test_table_path_matches_the_per_edge_path(gpu_device, F, graphs):
     assert torch.equal(pb, pb2) and torch.equal(g1, eb.params.grad)
 
 
-def test_table_path_against_the_oracle(gpu_device):
+def _table_eligible(cfg):
+    """the shapes the fused live-edge kernels (and with them the table path) take: E <= 4 through the fused edge MLP"""
+    return cfg.get("edge_feature_size", 3) <= 4 and cfg.get("edge_hidden_size", 128) == 128 and cfg.get("edge_fc_layers", 4) == 4 \
+        and cfg.get("fc_activation", "softplus") == "softplus"
+
+
+def _eligible_configs():
+    import test_gpu_parity as TP
+    return [i for i, c in enumerate(TP.CONFIGS) if _table_eligible(c)]
+
+
+@pytest.mark.parametrize("ci", _eligible_configs())
+def test_table_path_against_the_oracle(gpu_device, ci):
     """the tolerances the per-edge path is held to (tests/test_gpu_parity.py): 1e-4 on shifts, 2e-4 of the largest entry on every
-    gradient tensor, against the float64 oracle — training mode with explicit noise and dropout draws"""
+    gradient tensor, against the float64 oracle — training mode with explicit noise and dropout draws; every architecture of
+    test_gpu_parity.CONFIGS the table path takes"""
     from oracle import nmrgnn_oracle as O
     from helpers import hp_to_oracle, rel_err
     import test_gpu_parity as TP
-    hp, b, eng, sd, gb, std, avg = TP._setup(gpu_device, TP.CONFIGS[0])
+    hp, b, eng, sd, gb, std, avg = TP._setup(gpu_device, TP.CONFIGS[ci])
     eng.edge_table = True
     eng.edge_table_min_edges = 0
     N, K = b["edges"].shape
@@ -65,7 +78,7 @@ def test_table_path_against_the_oracle(gpu_device):
     xi = eng.randn(N * K, seed=123)
     mask = eng.dropout_mask(N * Fh, seed=321)
     peaks = eng.forward(gb, training=True, noise=xi, dropout_mask=mask)
-    assert eng.tape.table is not None
+    assert eng.tape.table is not None and not eng.edge_table_report()[0]
     dpeaks = np.random.default_rng(9).standard_normal(N).astype(np.float32)
     eng.backward(torch.from_numpy(dpeaks).to(gpu_device))
     grads = eng.params.grads_dict()

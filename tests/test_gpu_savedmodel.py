@@ -10,27 +10,30 @@ evaluation of the reference's own graph (NumPy summation order) already sits 1.6
 peak_std, by this build or by the reference's own graph in float32.  The test asserts
   * 5e-5 on the STANDARDISED prediction ((peaks-avg)/std, the quantity the network computes; half the
     1e-4 budget of the north star at std = 1), and
-  * on the de-standardised shifts, per element: max error <= max(1e-4, 3 x the error of the reference's
-    own float32 evaluation of the same graph).  Both errors are samples of float32 rounding noise of one
-    scale; the factor is what actually holds over all cases — the worst is the small padded case in
-    training mode, element N (shifts of ~500 ppm there: one float32 ulp of the prediction is 3e-5):
-    1.88e-4 against a yardstick of 7.3e-5 (2.56 x); on 108M.pdb the ratio is 0.7-0.9.  History of that
-    one number: 1.80e-4 (2.45 x) while the FC block of this F = 64 case still ran f32-input MFMAs, 1.88e-4
-    since it runs on fp16 pieces (round 4, fc_fused.hip) — six ulps of the prediction either way.
-    (Rounds 2-3 wrote "1.5 x" beside an `or err_std < 5e-6` clause that the padded case passed
-    through; the clause is gone.)
+  * on the de-standardised shifts, per element: max error <= max(1e-4, REF32_FACTOR[case] x the error of the
+    reference's own float32 evaluation of the same graph).  Both errors are samples of float32 rounding noise
+    of one scale; the factor of a case is its largest measured ratio + 25 % (round 6: padded 1.94 -> 2.5,
+    pdb108m 0.94 -> 1.2, lgi7 1.09 -> 1.4, pdb108m_f64 1.01 -> 1.3).  The worst is the small padded case in
+    training mode, element N (shifts of ~500 ppm there: one float32 ulp of the prediction is 3e-5): 1.42e-4
+    against a yardstick of 7.3e-5; everywhere else the HIP path is AT or BELOW the reference graph's own
+    float32 error.  History of the padded number: 1.80e-4 (2.45 x, round 3), 1.88e-4 (2.56 x, rounds 4-5).
+  Cases (round 6 added the last two): a padded synthetic batch (F = 64), 108M.pdb at the bundled width (F = 256),
+  frame 0 of 7lgi.pdb.gz at the bundled width (BASELINE configs[4]), 108M.pdb at the bench architecture (F = 64);
+  each through the per-edge kernels and through the guarded edge-function table.
 The measured per-element errors (C = 2, N = 3, H = 4) are printed; the unfiltered print-out of a run on
-MI355X is profiles/r05z_savedmodel_errors.txt (regenerated each round by tools/round_profiles.sh).
+MI355X is profiles/r06_savedmodel_errors.txt (regenerated each round by tools/round_profiles.sh).
 """
 import numpy as np
 import pytest
 
-from helpers import load_savedmodel_case, make_hp
+from helpers import SAVEDMODEL_CASES, load_savedmodel_case, make_hp
 
 pytestmark = pytest.mark.gpu
 
 STD_ATOL = 5e-5
-REF32_FACTOR = {"padded": 3.0, "pdb108m": 1.5}     # pdb108m measures 0.7-0.9 x; only the small padded case needs 3 x
+# per case: the largest measured ratio |hip - ref64| / |ref32 - ref64| over elements, modes and both edge paths, + 25 %
+# (profiles/r06_savedmodel_errors.txt: padded 1.94 — its N shifts in training mode —, pdb108m 0.94, lgi7 1.09, pdb108m_f64 1.01)
+REF32_FACTOR = {"padded": 2.5, "pdb108m": 1.2, "lgi7": 1.4, "pdb108m_f64": 1.3}
 
 
 def _engine(gpu_device, c, edge_table=False):
@@ -74,7 +77,7 @@ def _check(tag, c, peaks, ref64, ref32, what):
 
 
 @pytest.mark.parametrize("edge_table", [False, True], ids=["per_edge", "edge_table"])
-@pytest.mark.parametrize("tag", ["padded", "pdb108m"])
+@pytest.mark.parametrize("tag", SAVEDMODEL_CASES)
 def test_hip_equals_reference_graph_inference(gpu_device, tag, edge_table):
     c = load_savedmodel_case(tag)
     eng, gb = _engine(gpu_device, c, edge_table)
@@ -87,7 +90,7 @@ def test_hip_equals_reference_graph_inference(gpu_device, tag, edge_table):
 
 
 @pytest.mark.parametrize("edge_table", [False, True], ids=["per_edge", "edge_table"])
-@pytest.mark.parametrize("tag", ["padded", "pdb108m"])
+@pytest.mark.parametrize("tag", SAVEDMODEL_CASES)
 def test_hip_equals_reference_graph_training(gpu_device, tag, edge_table):
     """training=True trace with the fixture's explicit GaussianNoise / Dropout draws."""
     import torch

@@ -11,23 +11,24 @@ fixture in tests/test_gpu_savedmodel.py.
 import numpy as np
 import pytest
 
-from helpers import load_savedmodel_case
+from helpers import SAVEDMODEL_CASES, load_savedmodel_case
 from oracle import nmrgnn_oracle as O
 
 # float64 oracle vs float64 execution of the reference graph: only re-association noise is allowed
 F64_ATOL = 1e-9
 
 
-@pytest.mark.parametrize("tag", ["padded", "pdb108m"])
+@pytest.mark.parametrize("tag", SAVEDMODEL_CASES)
 def test_oracle_equals_reference_graph_inference(tag):
     c = load_savedmodel_case(tag)
     hp = O.hypers(atom_feature_size=c["F"])
     out = O.gnn_forward((c["atoms"], c["nlist"], c["edges"], c["inv_degree"]), c["weights"], hp,
                         c["peak_std"], c["peak_avg"], return_all=True)
     assert np.max(np.abs(out["peaks"] - c["peaks64"])) < F64_ATOL
-    # intermediates (stored rounded to float32): masked edge features, node features after the MP block
-    assert np.max(np.abs(out["e"] - c["e64"])) < 1e-6
-    assert np.max(np.abs(out["h"][::16] - c["h_mp64_rows16"])) < 2e-6
+    if "e64" in c:
+        # intermediates (stored rounded to float32): masked edge features, node features after the MP block
+        assert np.max(np.abs(out["e"] - c["e64"])) < 1e-6
+        assert np.max(np.abs(out["h"][::16] - c["h_mp64_rows16"])) < 2e-6
     # the fixture exercises what it should: padded slots, index-0 neighbours, elements with std = 0
     if tag == "padded":
         assert (c["edges"] == 0).any() and (c["inv_degree"] == 0).any()
@@ -36,7 +37,7 @@ def test_oracle_equals_reference_graph_inference(tag):
     assert np.ptp(c["peaks64"]) > 1.0
 
 
-@pytest.mark.parametrize("tag", ["padded", "pdb108m"])
+@pytest.mark.parametrize("tag", SAVEDMODEL_CASES)
 def test_oracle_equals_reference_graph_training(tag):
     """training=True trace: GaussianNoise (sigma 0.025, mask from the un-noised distances) and Dropout
     (rate 0.2, kept units x1.25) with the SAME explicit draws fed to both."""
@@ -52,7 +53,7 @@ def test_oracle_equals_reference_graph_training(tag):
 def test_reference_fp32_execution_noise_is_recorded():
     """How far float32 evaluation of the reference's own graph sits from its float64 value — the
     yardstick for the 1e-4 budget once peak_std = 50.9 (N) multiplies the head output."""
-    for tag, lo, hi in (("padded", 1e-6, 1e-3), ("pdb108m", 1e-5, 5e-3)):
+    for tag, lo, hi in (("padded", 1e-6, 1e-3), ("pdb108m", 1e-5, 5e-3), ("lgi7", 1e-5, 5e-3), ("pdb108m_f64", 1e-5, 5e-3)):
         c = load_savedmodel_case(tag)
         err = np.max(np.abs(c["peaks32"].astype(np.float64) - c["peaks64"]))
         assert lo < err < hi, (tag, err)
