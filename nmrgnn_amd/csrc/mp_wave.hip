@@ -27,27 +27,13 @@
 #include "edge_fused.h"   // NG_LDS_BARRIER
 #include "h2_common.cuh"
 #include "mp_win16_common.cuh"
+#include "mp_wave_common.cuh"
 
 namespace ng {
 namespace wv {
 
-using w16c::f32x4;
-
-constexpr int WF = 64;
-constexpr int WROWS = 288;                 // window rows
-constexpr int MT = 16;                     // atoms per micro-tile
-constexpr int NWV = 8;                     // waves per workgroup
-constexpr int WTHREADS = NWV * 64;
-constexpr int GROUP = 2 * NWV * MT;        // atoms per window group: two micro-tiles per wave
-constexpr int E = 3;
-constexpr int NT2 = E * WF / 32;           // 32-wide k-steps
-constexpr int WIN_BYTES = WROWS * WF * 4;
-constexpr int WIMG_BYTES = 4 * NT2 * 2 * 1024;
 constexpr int STRIP_BYTES = 4096;          // [1 KB neighbour indices][3 KB edge features], each [piece][atom] x 16 B
 constexpr int LDS_BYTES = WIN_BYTES + WIMG_BYTES + NWV * STRIP_BYTES;
-constexpr int VOFF_NONE = 0x7ffffff0;      // beyond every buffer: the lane's piece reads as zeros
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
   int64_t N;
@@ -85,25 +71,12 @@ struct Args {
 __device__ __forceinline__ void lists_dma(const Args& a, char* strip, int64_t row0, int lane) {
   const int K = a.K, at = lane & 15, pp = lane >> 4;
   const int rows = (int)std::min<int64_t>(MT, a.N - row0);
-  const dma_i4 rn = dma_rsrc(a.nlist + row0 * K, (unsigned)(rows * K * 4));
-  lds_dma16(rn, strip, pp < (K >> 2) ? at * K * 4 + pp * 16 : VOFF_NONE, 0);
+  nlist_dma(a.nlist, K, a.N, strip, row0, lane);
   const dma_i4 re = dma_rsrc(a.e + row0 * K * E, (unsigned)(rows * K * E * 4));
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int p = 4 * t + pp;
     lds_dma16(re, strip + 1024 + t * 1024, 4 * p < 3 * K ? at * K * E * 4 + p * 16 : VOFF_NONE, 0);
-  }
-}
-
-// the window: rows wlo .. wlo+287 of h, chunk c of row R at 16-byte position 16 R + (c ^ (R & 15))
-__device__ __forceinline__ void win_dma(char* win, const float* h, int64_t wlo, int64_t N, int wave, int lane) {
-  const int64_t rows = std::min<int64_t>(N - wlo, WROWS);
-  const dma_i4 rs = dma_rsrc(h + wlo * WF, (unsigned)(rows * (WF * 4)));
-#pragma unroll
-  for (int j = 0; j < WIN_BYTES / 1024 / NWV; ++j) {
-    const int kb = wave + NWV * j;
-    const int R = 4 * kb + (lane >> 4);
-    lds_dma16(rs, win + kb * 1024, R * (WF * 4) + (((lane & 15) ^ (R & 15)) << 4), 0);
   }
 }
 
@@ -187,14 +160,7 @@ __device__ __forceinline__ void body(const Args& a) {
   if (a.stamps && tid == 0) a.stamps[1024 + blockIdx.x] = wall_clock64();
 #endif
 
-  if (H2) {
-    const dma_i4 rw = dma_rsrc(a.Wfrag, WIMG_BYTES);
-#pragma unroll
-    for (int j = 0; j < WIMG_BYTES / 1024 / NWV; ++j) {
-      const int kb = wave + NWV * j;
-      lds_dma16(rw, wimg + kb * 1024, lane * 16, kb * 1024);
-    }
-  }
+  if (H2) wimg_dma(wimg, a.Wfrag, wave, lane);
   int64_t have = A0 + (int64_t)wave * MT;          // the micro-tile whose lists the strip holds (or is receiving)
   if (have < A1) lists_dma(a, strip, have, lane);
 
@@ -368,18 +334,7 @@ __device__ __forceinline__ void body(const Args& a) {
       }
       WV_T(0);
       // ---- do the micro-tile's sources lie in the window?
-      bool inwin;
-      {
-        const i32x4 mine = *reinterpret_cast<const i32x4*>(strip + (lane << 4));
-        const bool valid = kg < nq && row0 + at < a.N;
-        int lo = std::min(std::min(mine[0], mine[1]), std::min(mine[2], mine[3]));
-        int hi = std::max(std::max(mine[0], mine[1]), std::max(mine[2], mine[3]));
-        lo = valid ? lo : 0x7fffffff;
-        hi = valid ? hi : -1;
-        lo = __builtin_amdgcn_readlane(w16c::wave_min_i32(lo), 63);
-        hi = -__builtin_amdgcn_readlane(w16c::wave_min_i32(-hi), 63);
-        inwin = hi < lo || (lo >= wlo && hi < wlo + WROWS);
-      }
+      const bool inwin = sources_in_window(strip, lane, nq, row0, a.N, wlo);
 #pragma unroll
       for (int n = 0; n < E; ++n)
 #pragma unroll

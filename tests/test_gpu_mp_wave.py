@@ -125,3 +125,4 @@ def test_whole_engine_with_the_wave_forward(gpu_device, monkeypatch, n_graphs, n
     assert np.abs(peaks1 - peaks0).max() <= 2e-6 * scale
     for k, v in g0.items():
         assert np.abs(g1[k] - v).max() <= 5e-6 * (np.abs(v).max() + 1e-30), k
+
