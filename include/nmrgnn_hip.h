@@ -185,7 +185,10 @@ int ng_edge_mlp_bwd_tape(ng_ctx*, void* stream, int64_t n_edges, int H, int E, i
  *   ng_edge_mlp_fwd_live / _bwd_live: d_src_c / d_eff_c are the COMPACTED distances (n_live rows; d_eff_c = d_src_c
  *     for inference); e_out and de keep the caller's [n_slots, E] layout (dead slots of e_out are written 0);
  *     z_save [Le-1, n_slots, H]: layer stride as for n_slots rows, the first n_live rows of every layer used.
- *   ng_edge_live_supported: 1 when this shape runs the fused edge path (the only one with a live view). */
+ *   ng_edge_live_supported: 1 when this shape runs the fused edge path (the only one with a live view).
+ *   *n_live < 0 (ABI 8): the launch has nothing to do and returns at once — _fwd_live leaves e_out (dead slots included) and
+ *     z_save untouched, _bwd_live writes dW = db = 0.  What the edge-function table's guard hands the per-edge launches when it
+ *     is down (ng_edge_table_check: gate[1]). */
 int ng_build_live_edges(ng_ctx*, void* stream, int64_t n_slots, const float* edges, int32_t* perm, int32_t* pos,
                         float* d_c, int32_t* n_live);
 int ng_add_noise_live(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, int64_t n, const float* x, const float* y,
@@ -394,7 +397,7 @@ int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
  * table (the exact adjoint, 64-bit fixed-point sums: order-free) and runs ng_edge_mlp_bwd on the table's rows.
  * GUARD (ABI 8).  The same launch also evaluates f_W at the T midpoints (rows T .. 2T-1); ng_edge_table_check compares the
  * interpolant with it there and decides ON THE DEVICE: gate[0] != 0 means "answer this call per edge".  The caller launches
- * ng_edge_mlp_fwd_live / _bwd_live with n_live = &gate[1] (the live row count when the guard is up, 0 otherwise) and the
+ * ng_edge_mlp_fwd_live / _bwd_live with n_live = &gate[1] (the live row count when the guard is up, -1 = "skip" otherwise) and the
  * table's backward with n_live = &gate[2] (0 when the guard is up), so exactly one of the two paths does work; interp skips
  * itself on gate[0].  No host synchronisation.
  *   d_src  [n]     raw distances in SLOT order (mask = d_src > 0)
@@ -408,7 +411,7 @@ int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
  *   ng_edge_table_check    e_all [2T,E] (or NULL: only the range is checked): err = max |interpolant - f_W| over the interior
  *                          midpoints, scale = max |f_W| over the table; bad = err > tol * scale, or a value not finite, or
  *                          cover != NULL and [cover[0], cover[1]] not inside [range[0], range[1]], or prev != NULL and
- *                          prev[0] != 0.  gate (8 device int32): {bad, bad ? *n_live : 0, bad ? 0 : rows, 0, err, scale (float
+ *                          prev[0] != 0.  gate (8 device int32): {bad, bad ? *n_live : -1, bad ? 0 : rows, 0, err, scale (float
  *                          bits), -, -}.
  *   ng_edge_table_interp   e_out[i][c] = m_i sum_k w_k(d_i) e_tab[i0 + k][c]   (E <= 4, T * E <= 16384); skipped on gate[0]
  *   ng_edge_table_scatter  de_tab[t][c] = sum_i m_i w_k(d_i) de[i][c] over the stencils that contain t, rows T .. rows_out-1

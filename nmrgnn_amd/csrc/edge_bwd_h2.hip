@@ -66,6 +66,9 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   const int col0 = 32 * zk + 4 * half;                  // its columns: col0 + 8q + j
   const int prz = hx_prow_z(row), prg = hx_prow_g(row); // where that row lives in the images
   const int E = a.E;
+  // a NEGATIVE live row count: nothing to do and nothing to write — the reduction behind this launch then writes zero gradients
+  // without reading the partials (the edge-function table's guard is down, edge_table.hip)
+  if (LIVE && __builtin_amdgcn_readfirstlane(*a.n_live) < 0) return;
   // gradients run scaled by a power of two S (header: Ranges), formed here by every workgroup from the block maxima of |de| and the
   // row-sum bounds the W^T pack left behind the fragments: max is exact and order-free, so S — and every bit of the result —
   // is the same in every workgroup and for every launch geometry (round 4: this was a one-block launch of its own)

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(TM * 4, TM == 64 ? 2 : 1) void edge_fused_fwd_kerne
   }
   __syncthreads();
 
+  if (a.perm && *a.n_live < 0) return;      // (a negative row count: nothing to do, e_out is somebody else's — edge_fwd_h2.hip)
   const int64_t n_edges = a.perm ? (int64_t)*a.n_live : a.n_edges;
   const int64_t ntiles = (n_edges + TM - 1) / TM;
   if (a.perm) {     // dead slots carry e == 0

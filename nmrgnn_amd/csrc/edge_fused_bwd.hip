@@ -208,6 +208,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void edge_fused_bwd_kernel(EdgeBwdAr
   for (int n = 0; n < E; ++n) accWo[n] = 0.f;
   float accbo = 0.f;
 
+  if (a.perm && *a.n_live < 0) return;      // (negative row count: edge_bwd_h2.hip)
   const int64_t n_edges = a.perm ? (int64_t)*a.n_live : a.n_edges;
   const int64_t ntiles = (n_edges + FTM - 1) / FTM;
   const float* Z1g = a.z_save;
@@ -366,13 +367,15 @@ struct BwdOut {
 // out[...] = sum_wg partial[wg][idx], scattered to the individual gradient tensors.  One 1024-thread
 // block per 64 consecutive elements; the 16 waves split the workgroup partials, so every lane has
 // n_wg/16 independent coalesced loads in flight (the one-thread-per-element form took 66 us).
+// n_live (nullable) negative: the kernels in front wrote no partials (their launch had nothing to do): the gradients are zero.
 __global__ __launch_bounds__(1024) void edge_bwd_reduce_kernel(const float* __restrict__ partial, int n_wg,
-                                                               int stride, int E, BwdOut o) {
+                                                               int stride, int E, BwdOut o, const int32_t* __restrict__ n_live) {
   __shared__ float red[16][64];
   const int total = bwd_part_floats(E);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   float s = 0.f;
+  if (n_live && *n_live < 0) n_wg = 0;
   if (idx < total) {
     // eight loads in flight per lane, added in workgroup order (same sum as the plain loop)
     const float* p = partial + idx;
@@ -468,7 +471,7 @@ int edge_fused_bwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const fl
     for (int l = 0; l < 3; ++l) { o.dW[l] = dW[l]; o.db[l] = db[l]; }
     o.dWo = dW[3]; o.dbo = db[3];
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((unsigned)cdiv(bwd_part_floats(E), 64)), dim3(1024), 0, st,
-                       partial, n_part, stride, E, o);
+                       partial, n_part, stride, E, o, live.n_live);
     NG_HIP(ctx, hipGetLastError());
   }
   return NG_OK;

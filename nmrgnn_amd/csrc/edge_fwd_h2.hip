@@ -228,7 +228,10 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   }
   if (tid < 32) sBo[tid] = tid < a.E ? a.bo[tid] : 0.f;
 
-  // rows of this launch: every slot, or the compacted live ones (device scalar: no host round trip per batch)
+  // rows of this launch: every slot, or the compacted live ones (device scalar: no host round trip per batch).  A NEGATIVE row
+  // count: this launch has nothing to do and e_out belongs to somebody else (the edge-function table's guard is down,
+  // edge_table.hip): not even the dead slots are written
+  if (a.perm && __builtin_amdgcn_readfirstlane(*a.n_live) < 0) return;
   const int64_t n_edges = a.perm ? (int64_t)__builtin_amdgcn_readfirstlane(*a.n_live) : a.n_edges;
   const int64_t ntiles = (n_edges + H2_TM - 1) / H2_TM;
   float ds_n, de_n;

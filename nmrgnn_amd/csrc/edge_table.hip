@@ -97,7 +97,8 @@ __global__ __launch_bounds__(ET_BLOCK) void et_points_kernel(int T, int mid, con
 // The guard.  e_all[2T][E]: the edge function at the table points and at the midpoints.  err = max over the interior
 // midpoints and the components of |cubic interpolant(table) - value|, scale = max |table value|.
 // gate[0] = bad (err > tol * scale, a value not finite, or — cover != null — the call's distances [cover[0], cover[1]] not inside
-// the table's [range[0], range[1]]);  gate[1] = bad ? *n_live : 0 (rows of the per-edge kernels);  gate[2] = bad ? 0 : rows
+// the table's [range[0], range[1]]);  gate[1] = bad ? *n_live : -1 (rows of the per-edge kernels; negative = the launch returns
+// at once: forward leaves e_out alone, backward's gradients are zero);  gate[2] = bad ? 0 : rows
 // (rows of the table's backward);  gate[4], gate[5] = err, scale as float bits.  prev (nullable): a gate decided earlier (the
 // table's own check, when only the range is checked per call): bad stays bad.
 constexpr int ET_CHECK_THREADS = 1024;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(ET_CHECK_THREADS) void et_check_kernel(int T, int E
     if (cover) bad = bad || !(cover[0] >= range[0] && cover[1] <= range[1]);
     if (prev) bad = bad || prev[0] != 0;
     gate[0] = bad ? 1 : 0;
-    gate[1] = bad && n_live ? *n_live : 0;
+    gate[1] = bad ? (n_live ? *n_live : 0) : -1;      // (negative: the per-edge launches skip themselves entirely)
     gate[2] = bad ? 0 : rows;
     gate[3] = 0;
     if (e_all) { gate[4] = __builtin_bit_cast(int32_t, err); gate[5] = __builtin_bit_cast(int32_t, sc); }

@@ -401,12 +401,14 @@ __global__ __launch_bounds__(WTHREADS) void mp_wave_fwd_kernel(Args a) {
 
 bool mp_wave_supported(int E, int K) { return E == 3 && K >= 4 && K <= 16 && K % 4 == 0; }
 
-// NG_MP_WAVE=1: every supported call; =0: none; default: batches that fill the chip (half a group per CU and more)
+// NG_MP_WAVE=1: every supported call; =0: none; default: batches of small graphs (ng_ctx_set_graph_span: every graph fits the
+// window a group places around its own rows — a protein's neighbours lie all over its frame, its micro-tiles would take their
+// sources from memory and mp_win16.hip's per-tile window choice serves it better) that fill the chip (half a group per CU and more)
 bool mp_wave_wanted(const ng_ctx* ctx, int64_t N, int E, int K) {
   if (!mp_wave_supported(E, K) || N >= (int64_t(1) << 31)) return false;
   if (sw().mp_wave == 0) return false;
   if (sw().mp_wave == 1) return true;
-  return N >= (int64_t)ctx->num_cu * (wv::GROUP / 2);
+  return N >= (int64_t)ctx->num_cu * (wv::GROUP / 2) && ctx->graph_span > 0 && ctx->graph_span <= wv::WROWS - (wv::WROWS - wv::GROUP) / 2;
 }
 
 // launch on the images mp_win_fwd has prepared (same fragments, same flag word as mp_win16.hip)
