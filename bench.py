@@ -287,7 +287,7 @@ KERNEL_SOURCES = {
     "edge_fwd_h2": ["edge_fwd_h2.hip", "h2_common.cuh", "pack_bodies.cuh"],
     "edge_bwd_h2": ["edge_bwd_h2.hip", "edge_bwd_h2.cuh", "h2_common.cuh", "pack_bodies.cuh"],
     "edge_fused_fwd": ["edge_fused.hip"], "edge_fused_bwd": ["edge_fused_bwd.hip"],
-    "mp_win_fwd": ["mp_win16.hip", "mp_win16_common.cuh", "mp_win.hip", "h2_common.cuh"],
+    "mp_win_fwd": ["mp_wave.hip", "mp_wave_common.cuh", "mp_win16.hip", "mp_win16_common.cuh", "mp_win.hip", "h2_common.cuh"],
     "mp_win_bwd_edge": ["mp_win16_bwd.hip", "mp_win16_common.cuh", "mp_win_bwd.hip", "h2_common.cuh"],
     "mp_win_bwd_node": ["mp_win_bwd.hip", "mp_win16_common.cuh", "h2_common.cuh"],
     "fc_fused_fwd": ["fc_fused.hip"], "fc_fused_bwd": ["fc_fused.hip"],
