@@ -471,7 +471,7 @@ def main():
     # `value` and every leg that does not say otherwise: the edge MLP evaluated PER EDGE, as the reference does and as
     # SURVEY 8(d) prices it (a timed region that replaces 2 M MLP evaluations by 4,096 would read as skipped
     # work).  The Engine's default since round 6 — the guarded edge-function table — is measured beside it (`edge_table`).
-    eng.edge_table = False
+    eng.edge_table = os.environ.get("NG_BENCH_EDGE_TABLE", "0") == "1"      # (tools/step_trace.sh: the trace of the table-path step)
     if args.scaling == "strong":
         # the SAME total_graphs graphs whatever the world size; this rank's contiguous shard
         lo, hi = parallel.shard_range(args.total_graphs, rank, world)
@@ -552,6 +552,8 @@ def main():
                                 + f" x {ATOMS_PER_GRAPH} atoms, K={K_NEIGH}, F=64, E=3, H=128, 4 MP / 4 edge-FC / 4 FC "
                                   f"layers, noise+dropout on"),
                    "atoms_total": atoms_total, "atoms_this_rank": atoms_local, "edges_this_rank": gb.n_edges,
+                   "edge_path": ("edge-function table (NG_BENCH_EDGE_TABLE=1: tracing only, NOT the graded configuration)"
+                                 if eng.edge_table else "edge MLP evaluated per edge (the reference's arithmetic; SURVEY 8d)"),
                    "parallelism": f"graph-parallel dp{world}", "params": eng.params.count(),
                    "backend": backend, "world_size": world, "collective_library": collective_library(backend),
                    # dmabuf IPC between the ranks' processes: what RCCL's intra-node transport needs here

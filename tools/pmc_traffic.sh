@@ -12,7 +12,7 @@ import csv, glob, json, collections
 res = collections.defaultdict(dict)
 names = {"edge_fused_bwd_kernel": "edge_fused_bwd",
          "edge_fused_fwd_kernel": "edge_fused_fwd", "edge_fwd_h2_kernel<2>": "edge_fwd_h2", "edge_fwd_h2_kernel<1>": "edge_fwd_h2_rowmajor", "edge_fwd_h2_kernel<0>": "edge_fwd_h2_inference", "edge_bwd_h2_kernel": "edge_bwd_h2",
-         "mp_win_fwd_kernel": "mp_win_fwd",
+         "mp_win_fwd_kernel": "mp_win_fwd_eight_or_sixteen_wave", "mp_win16_fwd_kernel": "mp_win_fwd_sixteen_wave", "mp_wave_fwd_kernel": "mp_win_fwd",
          "mp_win_bwd_edge_kernel": "mp_win_bwd_edge", "mp_win_bwd_node_kernel": "mp_win_bwd_node",
          "fc_fwd_kernel": "fc_fused_fwd", "fc_bwd_kernel": "fc_fused_bwd"}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):

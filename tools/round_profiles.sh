@@ -32,6 +32,6 @@ python -m pytest tests/test_gpu_savedmodel.py -m gpu -q -s 2>&1 | grep -o '\[[a-
 # round 5: small calls eager vs replayed, the edge-table step, list-builder times
 python tools/small_calls.py > gpurun_out/${TAG}_small_calls.txt 2>&1
 python tools/sort_time.py > gpurun_out/${TAG}_gl_sort.txt 2>&1
-NG_EDGE_TABLE=1 bash tools/step_trace.sh > /dev/null 2>&1; cp gpurun_out/step_trace.txt gpurun_out/${TAG}_step_trace_edge_table.txt
+NG_BENCH_EDGE_TABLE=1 bash tools/step_trace.sh > /dev/null 2>&1; cp gpurun_out/step_trace.txt gpurun_out/${TAG}_step_trace_edge_table.txt
 tail -3 gpurun_out/${TAG}_bench.err; head -c 400 gpurun_out/${TAG}_bench.json; echo; tail -4 gpurun_out/${TAG}_eval_bench.txt
 python tools/check_profiles.py > gpurun_out/${TAG}_profile_digests.txt 2>&1; grep -c STALE gpurun_out/${TAG}_profile_digests.txt
