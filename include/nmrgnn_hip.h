@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NG_ABI_VERSION 8
+#define NG_ABI_VERSION 9
 
 enum {
   NG_OK = 0,
@@ -191,6 +191,11 @@ int ng_edge_mlp_bwd_tape(ng_ctx*, void* stream, int64_t n_edges, int H, int E, i
  *     is down (ng_edge_table_check: gate[1]). */
 int ng_build_live_edges(ng_ctx*, void* stream, int64_t n_slots, const float* edges, int32_t* perm, int32_t* pos,
                         float* d_c, int32_t* n_live);
+/* ng_build_incoming_lists (padded form) and ng_build_live_edges as ONE call (ABI 9): the same outputs; one launch when
+ * ng_graph_lists_one_launch(N, K) != 0 (molecule-sized calls, the reference's own granularity: nmrgnn/library.py:88-89) */
+int ng_build_graph_lists(ng_ctx*, void* stream, int64_t N, int K, const int32_t* nlist, const float* edges, int32_t* nlist_c,
+                         int32_t* csc_ptr, int32_t* csc_edge, int32_t* perm, int32_t* pos, float* d_c, int32_t* n_live);
+int ng_graph_lists_one_launch(int64_t N, int K);
 int ng_add_noise_live(ng_ctx*, void* stream, uint64_t seed, uint64_t offset, int64_t n, const float* x, const float* y,
                       float alpha, const int32_t* pos, float* out_c);
 int ng_edge_live_supported(int H, int E, int Le, int act);
@@ -389,6 +394,26 @@ int ng_head_fwd_dropout(ng_ctx*, void* stream, int64_t N, int Fh, int C, const f
 int ng_head_bwd(ng_ctx*, void* stream, int64_t N, int Fh, int C, const float* g,
                 const float* drop_mask, const float* Wout, const float* atoms,
                 const float* peak_std, const float* dpeaks, float* dg, float* dWout, float* dbout);
+
+/* Head forward + NameLoss with s = 1 (ng_loss_l2) + head backward in ONE launch (ABI 9).  Replaces, for a training step whose
+ * loss is the L2 NameLoss, the chain ng_head_fwd_dropout -> ng_loss_l2 -> ng_head_bwd (nmrgnn/model.py:266-273,
+ * nmrgnn/losses.py:30-39): a workgroup owns whole graphs, so the graph's loss and dloss/dpeaks never leave the chip.
+ * peaks and dg carry the bits of the three-call chain; dWout / dbout and the mean over graphs are summed in a different order
+ * (last bits).  The loss is COMPLETE ONLY AFTER ng_head_loss_reduce (its first stage is a column of `partial`).
+ *   ng_head_loss_blocks  number of workgroups = rows of `partial` the call writes (0: shape not supported — a graph longer
+ *                        than 256 atoms, more than 16 elements, more graphs than the chip takes in one round of workgroups,
+ *                        or a head shape ng_head_bwd's fast form does not take; use the three-call chain)
+ *   keep < 1: the keras Dropout mask of ng_dropout_mask(seed, offset, keep) is applied (mask_out[N,Fh] optional: may be NULL);
+ *   keep == 1: no dropout.  grad_weight multiplies dloss/dpeaks (uneven data-parallel shards), 1 = none.
+ *   partial [blocks][Fh*C + C + 1]: first-stage sums of [dWout ; dbout ; loss]; ng_head_loss_reduce finishes them (queued behind
+ *   ng_defer_reductions like every other second stage: the caller keeps `partial` alive until the flush). */
+int ng_head_loss_blocks(ng_ctx*, int G, int Fh, int C, int64_t max_graph_atoms);
+int ng_head_loss_bwd(ng_ctx*, void* stream, int64_t N, int G, int Fh, int C, int64_t max_graph_atoms, const float* g,
+                     uint64_t seed, uint64_t offset, float keep, float* mask_out, const float* Wout, const float* bout,
+                     const float* atoms, const float* peak_std, const float* peak_avg, const int32_t* graph_ptr,
+                     const float* y, const float* w, float grad_weight, float* peaks, float* dg, float* partial);
+int ng_head_loss_reduce(ng_ctx*, void* stream, const float* partial, int blocks, int Fh, int C, float* dWout, float* dbout,
+                        float* loss_out);
 
 /* ---- edge path through a table of the edge function (round 5; the Engine's default since round 6: csrc/edge_table.hip) ----
  * mask + RBFExpansion + EdgeFCBlock (nmrgnn/model.py:251-261) maps ONE scalar per edge to e[E]: e_ij = m_ij f_W(d_ij).  The

@@ -62,6 +62,8 @@ SIGNATURES = {
     "ng_edge_mlp_bwd_tape": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _f,
                                     C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _int]),
     "ng_build_live_edges": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ng_build_graph_lists": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_graph_lists_one_launch": (_int, [_i64, _int]),
     "ng_add_noise_live": (_int, [_vp, _vp, _u64, _u64, _i64, _vp, _vp, _f, _vp, _vp]),
     "ng_edge_live_supported": (_int, [_int, _int, _int, _int]),
     "ng_edge_mlp_fwd_live": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _f,
@@ -95,6 +97,10 @@ SIGNATURES = {
     "ng_head_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_head_fwd_dropout": (_int, [_vp, _vp, _i64, _int, _int, _vp, _u64, _u64, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ng_head_bwd": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ng_head_loss_blocks": (_int, [_vp, _int, _int, _int, _i64]),
+    "ng_head_loss_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _i64, _vp, _u64, _u64, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _f, _vp, _vp, _vp]),
+    "ng_head_loss_reduce": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "ng_mp_layer_wants_aggregate": (_int, [_int, _int, _int]),
     "ng_fc_block_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ng_fc_block_scratch_floats": (_i64, [_i64, _int, _int]),
@@ -141,7 +147,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ng_abi_version() != 8:
+        if lib.ng_abi_version() != 9:
             raise NGError("libnmrgnn_hip.so ABI version mismatch")
         _lib = lib
         return lib

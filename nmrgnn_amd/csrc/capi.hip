@@ -261,9 +261,16 @@ int reduce_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, i
   return NG_OK;
 }
 
+bool defer_outer_job(ng_ctx* ctx, hipStream_t st, const float* X, const float* Y, int64_t n, int C, int F, float* out) {
+  if (!ctx->defer_reduce || n > OUTER_JOB_MAX_ROWS || !rqueue(ctx)) return false;
+  ReduceJob j{Y, out, (int64_t)C * F, (int64_t)F, (int)n, 3, F, C, 1, 1};
+  j.aux = X;
+  return queue_job(ctx, st, j) == NG_OK;
+}
+
 int reduce_seg_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, int64_t z_stride,
-                        const ReduceSegs& sg) {
-  if (ctx->defer_reduce && in_arena(ctx, partial)) {
+                        const ReduceSegs& sg, bool caller_owned) {
+  if (ctx->defer_reduce && (caller_owned || in_arena(ctx, partial))) {
     // a segment is a plain job of its own on the segment's slice of the partial rows (an element's sum does not
     // depend on which block holds it: the bits are those of reduce_z_seg_kernel)
     (void)n_elem;

@@ -57,7 +57,7 @@ struct EdgeBwdH2Args {
   float neg_inv_gap_log2e;
   const char* wt_img;   // [2 layers (W2, W3)][4 k-slabs][8 k-steps][2 pieces][1 KB], pieces of 2^8 W
   const float* blockmax;   // per-block max |de| (hx_absmax_kernel); with the row-sum bounds behind wt_img the kernel forms {S, 1/S}
-  int n_blockmax;
+  int n_blockmax;          // < 0: small call, no hx_absmax launch — blockmax IS de and every workgroup takes max |de| over its -n_blockmax values itself
   const float* Wo;      // [128][E]
   const float* z_save;  // [3][z_layer_stride / 128 edges][128], first edge of THIS launch's segment
   int64_t z_layer_stride;  // floats between the layers of the tape (= total edges * 128; a launch covers one segment)

@@ -76,7 +76,17 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
   {
     float* sred = reinterpret_cast<float*>(smem_hx);
     float m = 0.f;
-    for (int i = tid; i < a.n_blockmax; i += HX_THREADS) m = fmaxf(m, a.blockmax[i]);
+    if (a.n_blockmax >= 0) {
+      for (int i = tid; i < a.n_blockmax; i += HX_THREADS) m = fmaxf(m, a.blockmax[i]);
+    } else {        // molecule-sized call: max |de| directly (order-free: the value of the two-stage form)
+      const int n = -a.n_blockmax;
+      const float4* de4 = reinterpret_cast<const float4*>(a.blockmax);
+      for (int i = tid; i < n >> 2; i += HX_THREADS) {
+        const float4 v = de4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+      for (int i = (n & ~3) + tid; i < n; i += HX_THREADS) m = fmaxf(m, fabsf(a.blockmax[i]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) sred[wave] = m;
@@ -427,6 +437,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
 // largest absolute row sums of Wo, W3, W2 and S = 2^floor(log2(2^15 / bound)).  max is exact and order-free, so the
 // scale — and with it every bit of the result — does not depend on the launch geometry.
 constexpr int HX_SCALE_BLOCKS = 1024;
+constexpr int64_t HX_DIRECT_MAX = 32768;      // values of de a workgroup scans itself (edge_bwd_h2_launch)
 __global__ __launch_bounds__(256) void hx_absmax_kernel(const float* __restrict__ de, int64_t n, float* __restrict__ blockmax) {
   __shared__ float red[4];
   float m = 0.f;
@@ -480,9 +491,15 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
       if (int rc = pack_launch(ctx, st, j)) return rc;
       if (cached_wt) cache_set_job(ctx, W[1], 13, j);
     }
-    nb_max = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
-    hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb_max), dim3(256), 0, st, de, n_edges * E, blockmax);
-    NG_HIP(ctx, hipGetLastError());
+    if (n_edges * E <= HX_DIRECT_MAX && (reinterpret_cast<uintptr_t>(de) & 15) == 0) {
+      // one graph per call: the few workgroups read the 48 KB of de themselves instead of waiting for a launch that does
+      nb_max = -(int)(n_edges * E);
+      blockmax = const_cast<float*>(de);
+    } else {
+      nb_max = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
+      hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb_max), dim3(256), 0, st, de, n_edges * E, blockmax);
+      NG_HIP(ctx, hipGetLastError());
+    }
   }
   const int nseg = edge_bwd_h2_segments(n_edges);
   for (int sg = 0; sg < nseg; ++sg) {

@@ -131,6 +131,16 @@ __device__ __forceinline__ void h2_hidden_chunk(const char* slot, const u32x4 (&
   }
 }
 
+// the blocked tape's row stores (tools: -DH2_TAPE_PLAIN for the A/B of plain against non-temporal stores)
+template <class V>
+__device__ __forceinline__ void h2_tape_store(V v, V* p) {
+#ifdef H2_TAPE_PLAIN
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // layer epilogue for one output block: softplus (SP: still to do), optional save, split into the next layer's B
 // fragments.  SAVE: 0 none; 1 row-major tape through a wave-private LDS transposition; 2 blocked tape
 // (edge_fused.h: edge_tape_blocked) — the accumulator layout itself, one contiguous KB per wave store.
@@ -145,7 +155,7 @@ __device__ __forceinline__ void h2_epilogue(const f32x16& acc, u32x4 (&bfo)[2][2
     const float z0 = SP ? h2_softplus(acc[4 * q + 0]) : acc[4 * q + 0], z1 = SP ? h2_softplus(acc[4 * q + 1]) : acc[4 * q + 1];
     const float z2 = SP ? h2_softplus(acc[4 * q + 2]) : acc[4 * q + 2], z3 = SP ? h2_softplus(acc[4 * q + 3]) : acc[4 * q + 3];
     if (SAVE == 1) *reinterpret_cast<float4*>(tb + l31 * H2_TLD + 8 * q + 4 * hf) = make_float4(z0, z1, z2, z3);
-    if (SAVE == 2) __builtin_nontemporal_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
+    if (SAVE == 2) h2_tape_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
     // registers 4q..4q+3  ->  k-step s = q>>1, k-slots t = 4(q&1)..+3  ->  dwords 2(q&1), 2(q&1)+1
     const int s = q >> 1, j = 2 * (q & 1);
     unsigned h, l;
@@ -193,7 +203,7 @@ __device__ __forceinline__ void h2_epilogue_q(const f32x16& acc, u32x4 (&bfo)[2]
   typedef float nt4 __attribute__((ext_vector_type(4)));
   const float z0 = SP ? h2_softplus(acc[4 * q + 0]) : acc[4 * q + 0], z1 = SP ? h2_softplus(acc[4 * q + 1]) : acc[4 * q + 1];
   const float z2 = SP ? h2_softplus(acc[4 * q + 2]) : acc[4 * q + 2], z3 = SP ? h2_softplus(acc[4 * q + 3]) : acc[4 * q + 3];
-  if (SAVE == 2) __builtin_nontemporal_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
+  if (SAVE == 2) h2_tape_store(nt4{z0, z1, z2, z3}, reinterpret_cast<nt4*>(zp + q * qstride));
   const int s = q >> 1, j = 2 * (q & 1);
   unsigned h, l;
   split2_pair(z0, z1, h, l);

@@ -308,10 +308,9 @@ __global__ __launch_bounds__(GL_BLOCK) void gl_live_fill_kernel(int64_t n, const
 constexpr int GL_SMALL_THREADS = 1024, GL_SMALL_SLOTS = 16384, GL_SMALL_TARGETS = 2048;
 
 // live partition of <= GL_SMALL_SLOTS slots: thread t owns slots [t * per, t * per + per)
-__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_live_small_kernel(int n, const float* __restrict__ edges, int32_t* __restrict__ perm,
-                                                                         int32_t* __restrict__ pos, float* __restrict__ d_c,
-                                                                         int32_t* __restrict__ total) {
-  __shared__ int32_t s[GL_SMALL_THREADS];
+__device__ __forceinline__ void gl_live_small_body(int n, const float* __restrict__ edges, int32_t* __restrict__ perm,
+                                                   int32_t* __restrict__ pos, float* __restrict__ d_c,
+                                                   int32_t* __restrict__ total, int32_t* s /* [GL_SMALL_THREADS / 64] */) {
   const int per = (n + GL_SMALL_THREADS - 1) / GL_SMALL_THREADS;      // <= 16
   const int b0 = threadIdx.x * per, b1 = min(n, b0 + per);
   int32_t c = 0;
@@ -342,13 +341,19 @@ __global__ __launch_bounds__(GL_SMALL_THREADS) void gl_live_small_kernel(int n, 
   if (threadIdx.x == 0) *total = n_live;
 }
 
+__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_live_small_kernel(int n, const float* __restrict__ edges, int32_t* __restrict__ perm,
+                                                                         int32_t* __restrict__ pos, float* __restrict__ d_c,
+                                                                         int32_t* __restrict__ total) {
+  __shared__ int32_t s[GL_SMALL_THREADS / 64];
+  gl_live_small_body(n, edges, perm, pos, d_c, total, s);
+}
+
 // incoming lists of <= GL_SMALL_TARGETS targets and <= GL_SMALL_SLOTS entries: histogram (LDS integer atomics: order-free), scan,
 // unordered fill through LDS cursors, per-target rank sort back into ascending entry id — the stable order of the big form
-__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_lists_small_kernel(int n_entries, int N, int K, const int32_t* __restrict__ nlist,
-                                                                          const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
-                                                                          int32_t* __restrict__ csc_ptr, int32_t* __restrict__ csc_edge) {
-  __shared__ int32_t s_cnt[GL_SMALL_TARGETS], s_cur[GL_SMALL_TARGETS], s_scan[GL_SMALL_THREADS];
-  extern __shared__ int32_t s_tmp[];          // [n_entries]
+__device__ __forceinline__ void gl_lists_small_body(int n_entries, int N, int K, const int32_t* __restrict__ nlist,
+                                                    const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
+                                                    int32_t* __restrict__ csc_ptr, int32_t* __restrict__ csc_edge,
+                                                    int32_t* s_cnt, int32_t* s_cur, int32_t* s_scan, int32_t* s_tmp) {
   for (int t = threadIdx.x; t < N; t += GL_SMALL_THREADS) s_cnt[t] = 0;
   __syncthreads();
   for (int eid = threadIdx.x; eid < n_entries; eid += GL_SMALL_THREADS) {
@@ -406,6 +411,27 @@ __global__ __launch_bounds__(GL_SMALL_THREADS) void gl_lists_small_kernel(int n_
   }
 }
 
+__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_lists_small_kernel(int n_entries, int N, int K, const int32_t* __restrict__ nlist,
+                                                                          const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
+                                                                          int32_t* __restrict__ csc_ptr, int32_t* __restrict__ csc_edge) {
+  __shared__ int32_t s_cnt[GL_SMALL_TARGETS], s_cur[GL_SMALL_TARGETS], s_scan[GL_SMALL_THREADS / 64];
+  extern __shared__ int32_t s_tmp[];          // [n_entries]
+  gl_lists_small_body(n_entries, N, K, nlist, edges, nlist_c, csc_ptr, csc_edge, s_cnt, s_cur, s_scan, s_tmp);
+}
+
+// both builders of a one-graph call in ONE launch (round 6: ng_build_graph_lists): the live partition reads only `edges`, the
+// incoming lists only `nlist` / `edges` — neither reads what the other writes
+__global__ __launch_bounds__(GL_SMALL_THREADS) void gl_both_small_kernel(int n_entries, int N, int K, const int32_t* __restrict__ nlist,
+                                                                         const float* __restrict__ edges, int32_t* __restrict__ nlist_c,
+                                                                         int32_t* __restrict__ csc_ptr, int32_t* __restrict__ csc_edge,
+                                                                         int32_t* __restrict__ perm, int32_t* __restrict__ pos,
+                                                                         float* __restrict__ d_c, int32_t* __restrict__ n_live) {
+  __shared__ int32_t s_cnt[GL_SMALL_TARGETS], s_cur[GL_SMALL_TARGETS], s_scan[GL_SMALL_THREADS / 64], s_live[GL_SMALL_THREADS / 64];
+  extern __shared__ int32_t s_tmp[];          // [n_entries]
+  gl_live_small_body(n_entries, edges, perm, pos, d_c, n_live, s_live);
+  gl_lists_small_body(n_entries, N, K, nlist, edges, nlist_c, csc_ptr, csc_edge, s_cnt, s_cur, s_scan, s_tmp);
+}
+
 }  // namespace ng
 
 using namespace ng;
@@ -434,6 +460,34 @@ extern "C" int ng_build_live_edges(ng_ctx* ctx, void* stream, int64_t n_slots, c
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
 }
+
+static bool gl_small_shape(int64_t N, int K, int64_t n_entries) {
+  return N >= 1 && N <= GL_SMALL_TARGETS && n_entries <= GL_SMALL_SLOTS && n_entries > 0 && K > 0;
+}
+
+// ng_build_incoming_lists + ng_build_live_edges of the padded form as one call; one launch at molecule size
+extern "C" int ng_build_graph_lists(ng_ctx* ctx, void* stream, int64_t N, int K, const int32_t* nlist, const float* edges,
+                                    int32_t* nlist_c, int32_t* csc_ptr, int32_t* csc_edge, int32_t* perm, int32_t* pos, float* d_c,
+                                    int32_t* n_live) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, N >= 0 && K > 0 && N * (int64_t)K < ((int64_t)1 << 31), "graph lists: padded form, sizes in range");
+  NG_REQUIRE(ctx, csc_ptr && csc_edge && perm && pos && d_c && n_live && (N == 0 || (nlist && edges)), "graph lists: arguments");
+  const int64_t n_entries = N * K;
+  if (gl_small_shape(N, K, n_entries)) {
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard dg(ctx->device);
+    ProfScope ps(ctx, st, "graph_lists");
+    hipLaunchKernelGGL(gl_both_small_kernel, dim3(1), dim3(GL_SMALL_THREADS), (size_t)n_entries * sizeof(int32_t), st, (int)n_entries,
+                       (int)N, K, nlist, edges, nlist_c, csc_ptr, csc_edge, perm, pos, d_c, n_live);
+    NG_HIP(ctx, hipGetLastError());
+    return NG_OK;
+  }
+  const int rc = ng_build_incoming_lists(ctx, stream, N, K, n_entries, nlist, edges, nlist_c, csc_ptr, csc_edge);
+  if (rc) return rc;
+  return ng_build_live_edges(ctx, stream, n_entries, edges, perm, pos, d_c, n_live);
+}
+
+extern "C" int ng_graph_lists_one_launch(int64_t N, int K) { return gl_small_shape(N, K, N * (int64_t)K) ? 1 : 0; }
 
 // out[0..n] = exclusive prefix sums of in[0..n-1] (out[n] = total): row_ptr from a degree vector, on the device
 extern "C" int ng_exclusive_scan_i32(ng_ctx* ctx, void* stream, int64_t n, const int32_t* in, int32_t* out) {

@@ -175,6 +175,202 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t N, int C, in
   }
 }
 
+// ---- head forward + per-graph L2 loss + head backward in ONE launch (round 6; nmrgnn/model.py:266-273, losses.py:30-39 with s = 1)
+// The loss of a graph needs the graph's peaks and nothing else, and the head's backward needs dloss/dpeaks and nothing else: a
+// workgroup that owns whole graphs can run the three steps back to back with the peaks / their gradient in LDS.  Row arithmetic is
+// that of head_fwd_fast_kernel / loss_graph_kernel / head_bwd_fast_kernel (peaks, per-graph losses, dpeaks and dg carry the same
+// bits; the weight-gradient partials are cut at graph boundaries instead of row counts, so dWout / dbout differ in the last bits).
+// The keep-mask is drawn twice from the same Philox counters instead of being stored and read back.  The mean over graphs is one
+// more column of the workgroup's partial row (its graphs' losses / G), summed over the workgroups by the second stage that the
+// weight-gradient partials need anyway (ng_head_loss_reduce): the loss is complete when that has run.  (A first form let the
+// workgroup that finishes last take the mean: the two agent-scope fences per workgroup wrote back the XCD's L2 — 16.8 MB of
+// freshly stored dg — 512 times: 123 us at the bench shape.)
+struct HeadLossArgs {
+  int64_t N;
+  int G, C, gpw;                 // graphs per workgroup
+  const float *g, *Wout, *bout, *atoms, *pstd, *pavg;
+  const int32_t* gptr;
+  const float *y, *w;
+  float gweight;                 // shard weight of the rank's loss gradient (parallel.shard_grad_weight); 1 = none
+  float* peaks;
+  float* dg;
+  float* partial;                // [grid][Fh*C + C + 1]: [dWout ; dbout ; sum of the workgroup's graph losses / G]
+  HeadDraw dr;                   // mask_out may be nullptr (nobody reads the mask after this launch)
+};
+constexpr int HL_ROWS = 256;     // rows (atoms) a workgroup can own — a graph of the reference's training set; HL_CM: one-hot width limit
+constexpr int HL_CM = 16, HL_NT = 512;
+
+// Every input of the three steps is requested in the prologue — the rows' features stay in registers (RPT float4 per thread), the
+// one-hot rows, labels and weights go to LDS — so the launch is ONE memory round trip of loads long.  (A first form walked the rows
+// in trips of 32, eight dependent trips per phase: 84 us at the bench shape against 44 for the three separate launches; a loop form
+// for longer graphs lost to the separate launches too and is gone: such shapes report "not supported".)  137-204 registers at 512
+// threads: one workgroup per CU, so the launch pays only while the workgroups fit the chip in one round (head_loss_graphs_per_wg).
+template <int LPR, bool DRAW>
+__global__ __launch_bounds__(HL_NT) void head_loss_kernel(HeadLossArgs a) {
+  constexpr int Fh = LPR * 4, CM = HL_CM, NT = HL_NT;
+  constexpr int RL = NT / LPR;          // rows per trip
+  constexpr int NW = NT / 64;
+  constexpr int RPT = HL_ROWS / RL;
+  __shared__ __attribute__((aligned(16))) float sWs[Fh * HL_CM];
+  __shared__ float sV[HL_CM], sStd[HL_CM];
+  __shared__ float s_pk[HL_ROWS], s_y[HL_ROWS], s_w[HL_ROWS];
+  __shared__ float s_red[NW];
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [NW][Fh*C + C], then the one-hot rows [HL_ROWS][C]
+  const int C = a.C;
+  const int items = Fh * C + C;
+  float* s_at = red + NW * items;
+  const float* __restrict__ gin = a.g;
+  float* __restrict__ peaks = a.peaks;
+  float* __restrict__ dgo = a.dg;
+  const int g0 = blockIdx.x * a.gpw, g1 = min(a.G, g0 + a.gpw);
+  const int64_t r0 = a.gptr[g0], r1 = a.gptr[g1];
+  const int nrows = (int)(r1 - r0);      // <= HL_ROWS (the host's choice of gpw)
+  const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+  float4 xr[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int rr = r + u * RL;
+    xr[u] = *reinterpret_cast<const float4*>(gin + (r0 + (rr < nrows ? rr : 0)) * Fh + 4 * q);
+  }
+  for (int t = threadIdx.x; t < nrows * C; t += NT) s_at[t] = a.atoms[r0 * C + t];
+  for (int t = threadIdx.x; t < nrows; t += NT) { s_y[t] = a.y[r0 + t]; s_w[t] = a.w[r0 + t]; }
+  for (int t = threadIdx.x; t < Fh * C; t += NT) sWs[(t % C) * Fh + t / C] = a.Wout[t] * a.pstd[t % C];
+  if (threadIdx.x < C) {
+    sV[threadIdx.x] = a.pstd[threadIdx.x] * a.bout[threadIdx.x] + a.pavg[threadIdx.x];
+    sStd[threadIdx.x] = a.pstd[threadIdx.x];
+  }
+  __syncthreads();
+  const float inv_keep = 1.0f / a.dr.keep;
+  auto draw = [&](int64_t i) {
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (DRAW) {
+      uint32_t rr[4];
+      philox4x32(a.dr.staged ? a.dr.staged[0] : a.dr.seed, a.dr.offset + (uint64_t)(i * LPR + q), rr);
+      m = make_float4(u01(rr[0]) <= a.dr.keep ? inv_keep : 0.f, u01(rr[1]) <= a.dr.keep ? inv_keep : 0.f,
+                      u01(rr[2]) <= a.dr.keep ? inv_keep : 0.f, u01(rr[3]) <= a.dr.keep ? inv_keep : 0.f);
+      asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));      // opaque, as in head_fwd_fast_kernel
+    }
+    return m;
+  };
+  // ---- peaks
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int rr = r + u * RL;
+    if (rr < nrows) {
+      const int64_t i = r0 + rr;
+      const float* av = s_at + rr * C;
+      float4 x = xr[u];
+      if (DRAW) {
+        const float4 m = draw(i);
+        if (a.dr.mask_out) *reinterpret_cast<float4*>(a.dr.mask_out + i * Fh + 4 * q) = m;
+        x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+      }
+      float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, v = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float aa = av[c];
+        const float4 w4 = *reinterpret_cast<const float4*>(sWs + c * Fh + 4 * q);
+        u0 += aa * w4.x; u1 += aa * w4.y;
+        u2 += aa * w4.z; u3 += aa * w4.w;
+        v += aa * sV[c];
+      }
+      float p = fmaf(x.w, u3, fmaf(x.z, u2, fmaf(x.y, u1, x.x * u0)));
+      p = sum8(p);
+      if (LPR >= 16) p += __shfl_xor(p, 8, 64);
+      if (LPR == 32) p += __shfl_xor(p, 16, 64);
+      if (q == 0) { peaks[i] = p + v; s_pk[rr] = p + v; }
+    }
+  }
+  __syncthreads();
+  // ---- loss of each graph and dloss / dpeaks: one wave per graph, loss_graph_kernel's order
+  {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float wl = 0.f;
+    for (int gi = g0 + wv; gi < g1; gi += NW) {
+      const int ga = a.gptr[gi] - (int)r0, gb = a.gptr[gi + 1] - (int)r0;
+      float sw = 0.f, sl = 0.f;
+      for (int i = ga + lane; i < gb; i += 64) {
+        const float d = s_y[i] - s_pk[i];
+        sw += s_w[i];
+        sl += s_w[i] * d * d;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        sw += __shfl_xor(sw, off, 64);
+        sl += __shfl_xor(sl, off, 64);
+      }
+      const float inv = (sw != 0.f) ? 1.0f / sw : 0.f;
+      wl += sl * inv;
+      const float sc = -2.0f * inv / (float)a.G;
+      for (int i = ga + lane; i < gb; i += 64) {
+        float dp = sc * s_w[i] * (s_y[i] - s_pk[i]);
+        if (a.gweight != 1.0f) dp *= a.gweight;
+        s_pk[i] = dp;
+      }
+    }
+    if (lane == 0) s_red[wv] = wl;
+  }
+  __syncthreads();
+  // ---- dg and the workgroup's partial of [dWout ; dbout]
+  float acc[CM][4];
+  float db[CM];
+#pragma unroll
+  for (int c = 0; c < CM; ++c) { acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f; db[c] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int rr = r + u * RL;
+    if (rr < nrows) {
+      const int64_t i = r0 + rr;
+      const float* av = s_at + rr * C;
+      const float4 m = draw(i);
+      const float dp = s_pk[rr];
+      float4 x = xr[u];
+      x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+      float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+          const float aa = av[c];
+          const float4 w4 = *reinterpret_cast<const float4*>(sWs + c * Fh + 4 * q);
+          u0 += aa * w4.x; u1 += aa * w4.y;
+          u2 += aa * w4.z; u3 += aa * w4.w;
+          const float d = dp * aa * sStd[c];
+          acc[c][0] += x.x * d; acc[c][1] += x.y * d; acc[c][2] += x.z * d; acc[c][3] += x.w * d;
+          db[c] += d;
+        }
+      }
+      *reinterpret_cast<float4*>(dgo + i * Fh + 4 * q) = make_float4(m.x * dp * u0, m.y * dp * u1, m.z * dp * u2, m.w * dp * u3);
+    }
+  }
+  // sum over the wave's row lanes in registers (lanes q, q + LPR, ... hold the same columns), then over the waves through LDS
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) {
+    if (c < C) {
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[c][s] += __shfl_xor(acc[c][s], off, 64);
+        db[c] += __shfl_xor(db[c], off, 64);
+      }
+      if (lane < LPR) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) red[wv * items + (4 * q + s) * C + c] = acc[c][s];
+        if (q == 0) red[wv * items + Fh * C + c] = db[c];
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < items; it += NT) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += red[w * items + it];
+    a.partial[(int64_t)blockIdx.x * (items + 1) + it] = s;
+  }
+  if (threadIdx.x == 0) {      // s_red: written before the barrier behind the loss
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += s_red[w];
+    a.partial[(int64_t)blockIdx.x * (items + 1) + items] = s / (float)a.G;
+  }
+}
+
 // ---- embedding weight gradient --------------------------------------------------------------------------
 // thread = (row lane, float4 column); acc[c] float4 per thread
 template <int CM>
@@ -293,6 +489,57 @@ int head_bwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const f
   (void)summed;
   NG_HIP(ctx, hipGetLastError());
   return reduce_seg_or_defer(ctx, st, partial, nb, items, items, sg);
+}
+
+// graphs per workgroup of the fused head + loss launch; 0 = this shape does not take it (a graph longer than HL_ROWS atoms, more
+// than HL_CM elements, or more workgroups than the chip holds at once — two per CU at Fh = 32 (128 registers), one otherwise: a
+// second round costs what the fusion saves)
+int head_loss_graphs_per_wg(ng_ctx* ctx, int G, int Fh, int C, int64_t max_graph_atoms) {
+  if (!head_fast_supported(Fh, C) || C > HL_CM || G < 1 || max_graph_atoms < 1 || max_graph_atoms > HL_ROWS) return 0;
+  const int gpw = (int)cdiv(G, (int64_t)ctx->num_cu * (Fh == 32 ? 2 : 1));
+  if ((int64_t)gpw * max_graph_atoms > HL_ROWS) return 0;
+  return gpw;
+}
+
+int head_loss_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int G, int Fh, int C, int gpw, const float* g, uint64_t seed,
+                     uint64_t offset, float keep, bool draw, float* mask_out, const float* Wout, const float* bout,
+                     const float* atoms, const float* pstd, const float* pavg, const int32_t* gptr, const float* y,
+                     const float* w, float gweight, float* peaks, float* dg, float* partial) {
+  const int lpr = Fh / 4;
+  const int items = Fh * C + C;
+  const int grid = (int)cdiv(G, gpw);
+  HeadLossArgs a{};
+  a.N = N; a.G = G; a.C = C; a.gpw = gpw;
+  a.g = g; a.Wout = Wout; a.bout = bout; a.atoms = atoms; a.pstd = pstd; a.pavg = pavg;
+  a.gptr = gptr; a.y = y; a.w = w; a.gweight = gweight;
+  a.peaks = peaks; a.dg = dg; a.partial = partial;
+  a.dr = HeadDraw{seed, offset, keep, mask_out, draw ? replay_state(ctx) : nullptr};
+  const size_t lds = ((size_t)(HL_NT / 64) * items + (size_t)HL_ROWS * C) * 4;
+  ProfScope ps(ctx, st, "head_loss");
+#define NG_HL(L)                                                                                               \
+  do {                                                                                                         \
+    if (draw) hipLaunchKernelGGL((head_loss_kernel<L, true>), dim3(grid), dim3(HL_NT), lds, st, a);            \
+    else hipLaunchKernelGGL((head_loss_kernel<L, false>), dim3(grid), dim3(HL_NT), lds, st, a);                \
+  } while (0)
+  if (lpr == 8) NG_HL(8);
+  else if (lpr == 32) NG_HL(32);
+  else NG_HL(16);
+#undef NG_HL
+  NG_HIP(ctx, hipGetLastError());
+  return NG_OK;
+}
+
+// second stage of the fused launch's weight-gradient partials: queued with the backward's other reductions while they are
+// deferred (the caller keeps `partial` alive until the flush), launched at once otherwise
+int head_loss_reduce(ng_ctx* ctx, hipStream_t st, const float* partial, int nb, int Fh, int C, float* dWout, float* dbout,
+                     float* loss_out) {
+  const int items = Fh * C + C;
+  ReduceSegs sg{};
+  sg.n = 3;
+  sg.begin[0] = 0; sg.len[0] = Fh * C; sg.dst[0] = dWout;
+  sg.begin[1] = Fh * C; sg.len[1] = C; sg.dst[1] = dbout;
+  sg.begin[2] = items; sg.len[2] = 1; sg.dst[2] = loss_out;
+  return reduce_seg_or_defer(ctx, st, partial, nb, items + 1, items + 1, sg, /*caller_owned=*/true);
 }
 
 bool embed_bwd_fast_supported(int F, int C) {

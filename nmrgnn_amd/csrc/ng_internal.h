@@ -243,6 +243,13 @@ int mp_win_bwd(ng_ctx* ctx, hipStream_t st, int64_t N, int K, int E, int act, co
 
 // bandwidth-shaped head / embedding kernels (head_ops.hip); NG_HEAD_PATH=generic selects the old ones
 bool head_fast_supported(int Fh, int C);
+int head_loss_graphs_per_wg(ng_ctx* ctx, int G, int Fh, int C, int64_t max_graph_atoms);
+int head_loss_launch(ng_ctx* ctx, hipStream_t st, int64_t N, int G, int Fh, int C, int gpw, const float* g, uint64_t seed,
+                     uint64_t offset, float keep, bool draw, float* mask_out, const float* Wout, const float* bout,
+                     const float* atoms, const float* pstd, const float* pavg, const int32_t* gptr, const float* y,
+                     const float* w, float gweight, float* peaks, float* dg, float* partial);
+int head_loss_reduce(ng_ctx* ctx, hipStream_t st, const float* partial, int nb, int Fh, int C, float* dWout, float* dbout,
+                     float* loss_out);
 bool head_fwd_fast_supported(int Fh, int C);
 int head_fwd_fast(ng_ctx* ctx, hipStream_t st, int64_t N, int Fh, int C, const float* g, const float* mask,
                   const float* Wout, const float* bout, const float* atoms, const float* pstd,

@@ -808,6 +808,9 @@ extern "C" int ng_embed_bwd(ng_ctx* ctx, void* stream, int64_t N, int C, int F, 
     NG_HIP(ctx, hipMemsetAsync(dWemb, 0, items * 4, st));
     return NG_OK;
   }
+  // molecule-sized call inside a deferred-reduction window: the sum is a job of the batch launch, no launch of its own (the caller
+  // keeps atoms / dh0 alive until the flush, as it does for every deferred partial)
+  if (defer_outer_job(ctx, st, atoms, dh0, N, C, F, dWemb)) return NG_OK;
   if (embed_bwd_fast_supported(F, C)) return embed_bwd_fast(ctx, st, N, C, F, atoms, dh0, dWemb);
   // dWemb[c][f] = sum_i atoms[i][c] dh0[i][f]: small transposed product, rows staged through LDS
   const int64_t rows = 512;
@@ -953,6 +956,37 @@ extern "C" int ng_head_fwd_dropout(ng_ctx* ctx, void* stream, int64_t N, int Fh,
   const int rc = ng_dropout_mask(ctx, stream, seed, offset, keep, mask_out, N * Fh);
   if (rc) return rc;
   return ng_head_fwd(ctx, stream, N, Fh, C, g, mask_out, Wout, bout, atoms, peak_std, peak_avg, peaks);
+}
+
+// head forward + NameLoss(s = 1) + head backward as one launch (head_ops.hip: head_loss_kernel)
+extern "C" int ng_head_loss_blocks(ng_ctx* ctx, int G, int Fh, int C, int64_t max_graph_atoms) {
+  if (!ctx) return 0;
+  const int gpw = head_loss_graphs_per_wg(ctx, G, Fh, C, max_graph_atoms);
+  return gpw ? (int)cdiv(G, gpw) : 0;
+}
+
+extern "C" int ng_head_loss_bwd(ng_ctx* ctx, void* stream, int64_t N, int G, int Fh, int C, int64_t max_graph_atoms,
+                                const float* g, uint64_t seed, uint64_t offset, float keep, float* mask_out,
+                                const float* Wout, const float* bout, const float* atoms, const float* peak_std,
+                                const float* peak_avg, const int32_t* graph_ptr, const float* y, const float* w,
+                                float grad_weight, float* peaks, float* dg, float* partial) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, C >= 1 && C <= MAX_C, "head: number of elements <= 32");
+  NG_REQUIRE(ctx, keep > 0.f && keep <= 1.f, "dropout keep probability in (0,1]");
+  NG_REQUIRE(ctx, N >= 1 && G >= 1, "head_loss_bwd: at least one graph and one atom");
+  NG_REQUIRE(ctx, g && Wout && bout && atoms && peak_std && peak_avg && graph_ptr && y && w && peaks && dg && partial,
+             "head_loss_bwd: arguments");
+  const int gpw = head_loss_graphs_per_wg(ctx, G, Fh, C, max_graph_atoms);
+  if (!gpw) { ctx->err = "head_loss_bwd: shape not supported (ng_head_loss_blocks == 0)"; return NG_ERR_UNSUPPORTED; }
+  return head_loss_launch(ctx, (hipStream_t)stream, N, G, Fh, C, gpw, g, seed, offset, keep, keep < 1.f, mask_out, Wout, bout,
+                          atoms, peak_std, peak_avg, graph_ptr, y, w, grad_weight, peaks, dg, partial);
+}
+
+extern "C" int ng_head_loss_reduce(ng_ctx* ctx, void* stream, const float* partial, int nb, int Fh, int C, float* dWout,
+                                   float* dbout, float* loss_out) {
+  if (!ctx) return NG_ERR_INVALID;
+  NG_REQUIRE(ctx, partial && nb >= 1 && dWout && dbout && loss_out && C >= 1 && C <= MAX_C, "head_loss_reduce: arguments");
+  return head_loss_reduce(ctx, (hipStream_t)stream, partial, nb, Fh, C, dWout, dbout, loss_out);
 }
 
 extern "C" int ng_head_bwd(ng_ctx* ctx, void* stream, int64_t N, int Fh, int C, const float* g,

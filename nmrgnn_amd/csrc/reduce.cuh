@@ -39,6 +39,9 @@ struct ReduceJob {
   int64_t n_elem, z_stride;
   int nz, w_map, F, E, Nout;
   int narrow;                    // NG_REDUCE=narrow: 64 elements per block whatever the size (tests compare the two forms' bits)
+  // w_map == 3, "outer" job (round 6; queued by defer_outer_job): out[c*F + f] = sum_z aux[z*E + c] * partial[z*F + f] — the embedding
+  // weight gradient of a molecule-sized call straight from atoms [nz][E = C] and dh0 [nz][F], no first-stage launch
+  const float* aux = nullptr;
 };
 
 // Jobs of 32 K elements and more (the weight gradients of the default width: 196,608 elements x ~40 partials) run 256
@@ -105,7 +108,22 @@ __device__ __forceinline__ void reduce_job_block(const ReduceJob& j, const Reduc
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t idx = (int64_t)blk * 64 + lane;
   float s = 0.f;
-  if (idx < j.n_elem) {
+  if (j.w_map == 3) {
+    if (idx < j.n_elem) {
+      const int c = (int)(idx / j.F), f = (int)(idx % j.F);
+      const float* x = j.aux + c;
+      const float* y = j.partial + f;
+      int z = w;
+      for (; z + 112 < j.nz; z += 128) {
+        float xv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xv[u] = x[(int64_t)(z + 16 * u) * j.E]; yv[u] = y[(int64_t)(z + 16 * u) * j.F]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += xv[u] * yv[u];
+      }
+      for (; z < j.nz; z += 16) s += x[(int64_t)z * j.E] * y[(int64_t)z * j.F];
+    }
+  } else if (idx < j.n_elem) {
     // eight loads in flight per lane, added in z order (the sum is the one of the plain loop, bit for bit): with one
     // load per trip the kernel ran at the memory LATENCY — 40 us for the 68 MB of a training step's partials
     const float* p = j.partial + idx;
@@ -131,7 +149,7 @@ __device__ __forceinline__ void reduce_job_block(const ReduceJob& j, const Reduc
         if (k < sg->n && idx >= sg->begin[k] && idx < sg->begin[k] + sg->len[k]) sg->dst[k][idx - sg->begin[k]] = t;
       return;
     }
-    j.out[reduce_out_index(j, idx)] = t;
+    j.out[j.w_map == 3 ? idx : reduce_out_index(j, idx)] = t;
   }
 }
 
@@ -172,9 +190,14 @@ static inline void launch_reduce_z_seg(hipStream_t st, const float* partial, int
 float* deferred_partials(ng_ctx* ctx, size_t floats);
 int reduce_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, float* out, int w_map = 0,
                     int F = 0, int E = 0, int Nout = 1, int64_t z_stride = 0);
+// caller_owned: `partial` is not from the arena but the caller keeps it alive until the flush (head_loss_reduce)
 int reduce_seg_or_defer(ng_ctx* ctx, hipStream_t st, const float* partial, int nz, int64_t n_elem, int64_t z_stride,
-                        const ReduceSegs& sg);
+                        const ReduceSegs& sg, bool caller_owned = false);
 int flush_reductions(ng_ctx* ctx, hipStream_t st);
+// out[c*F + f] = sum_{i < n} X[i*C + c] * Y[i*F + f] as a job of the deferred batch (no launch of its own); false: deferral is
+// off or n is too long for a single-stage sum — the caller runs its two-stage form.  X, Y must stay valid until the flush.
+constexpr int64_t OUTER_JOB_MAX_ROWS = 2048;
+bool defer_outer_job(ng_ctx* ctx, hipStream_t st, const float* X, const float* Y, int64_t n, int C, int F, float* out);
 
 // partial[blk][a*B + b] = sum_{rows of blk} X(row, a) * Y(row, b)      (A <= 32, any B)
 // rows are staged 64 at a time in LDS; thread t owns items t, t+256, ... (<= SMALL_TN_ITEMS each);

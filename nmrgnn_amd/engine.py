@@ -36,7 +36,7 @@ def rbf_grid(low, high, count):
 class Tape:
     """activations kept between forward(training=True) and backward()"""
     __slots__ = ("batch", "d_eff", "z_save", "z_layout", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
-                 "peaks", "live", "table")
+                 "peaks", "live", "table", "loss", "dpeaks", "dg", "head_partial")
 
 
 class Engine:
@@ -90,6 +90,8 @@ class Engine:
         # per call, so code that writes into parameter views directly stays correct.
         self.cache_images = False
         self.defer_reductions = True      # backward(): queue the weight-gradient sums, one launch (ng_defer_reductions)
+        # forward(loss=...): head + L2 loss + head backward as one launch where the shape allows (ng_head_loss_bwd)
+        self.fuse_head_loss = os.environ.get("NG_HEAD_LOSS", "1") != "0"
         # padded slots (edges == 0) are skipped by the fused edge kernels (include/nmrgnn_hip.h: ng_edge_mlp_fwd_live);
         # NG_EDGE_LIVE=0 runs every slot as rounds 1-3 did (A/B measurements, tests)
         self.use_live_edges = os.environ.get("NG_EDGE_LIVE", "1") != "0"
@@ -151,20 +153,26 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch: GraphBatch, training=False, noise=None, dropout_mask=None, seed=0, keep_tape=None):
+    def forward(self, batch: GraphBatch, training=False, noise=None, dropout_mask=None, seed=0, keep_tape=None, loss=None):
         """peaks[N].  training=True keeps the tape for backward(); ``keep_tape=True`` keeps it for an inference-mode
         forward too (no noise, no dropout — what autograd through ``model(g, training=False)`` differentiates).
         ``noise`` (xi[N,K], standard normal) / ``dropout_mask`` ([N,F/2], values 0 or 1/keep) may be
-        supplied explicitly (parity tests); otherwise they are drawn on the GPU from ``seed``."""
+        supplied explicitly (parity tests); otherwise they are drawn on the GPU from ``seed``.
+        ``loss = (y, w, grad_weight)``: the L2 NameLoss (``loss_l2``) of the peaks is taken inside the forward —
+        ``tape.loss`` holds it ONCE ``backward(None)`` HAS RUN (which continues from its gradient); where the shape
+        allows, the head, the loss and the head's backward are ONE launch whose second stage rides with the backward's
+        other reductions (``ng_head_loss_bwd``; ``fuse_head_loss = False`` / NG_HEAD_LOSS=0: three calls)."""
+        if loss is not None and not (training if keep_tape is None else keep_tape):
+            raise ValueError("forward(loss=...) needs a tape (training=True)")
         if not (self._frozen or self.cache_images):
-            return self._forward(batch, training, noise, dropout_mask, seed, keep_tape)
+            return self._forward(batch, training, noise, dropout_mask, seed, keep_tape, loss)
         self._ck(self.lib.ng_weights_frozen(self.ctx.handle, self._id), "ng_weights_frozen")
         try:
-            return self._forward(batch, training, noise, dropout_mask, seed, keep_tape)
+            return self._forward(batch, training, noise, dropout_mask, seed, keep_tape, loss)
         finally:
             self.lib.ng_weights_frozen(self.ctx.handle, 0)
 
-    def _forward(self, batch, training, noise, dropout_mask, seed, keep_tape=None):
+    def _forward(self, batch, training, noise, dropout_mask, seed, keep_tape=None, loss=None):
         tape = bool(training) if keep_tape is None else bool(keep_tape)
         lib, h, st = self.lib, self.ctx.handle, self._st()
         P = self.params
@@ -274,7 +282,21 @@ class Engine:
                                      ptr_array(Bfc), ptr_array(fx[1:]), ptr(g)), "ng_fc_block_fwd")
         mask = None
         peaks = self._new(N)
-        if training and self.use_dropout and dropout_mask is None:
+        loss_t = dpeaks = dg = head_partial = None
+        nb = 0
+        if loss is not None and self.fuse_head_loss and dropout_mask is None:
+            nb = int(lib.ng_head_loss_blocks(h, batch.G, Fh, self.C, batch.max_graph_atoms))
+        if nb > 0:
+            y, w, gw = loss
+            keep = (1.0 - DROPOUT_RATE) if (training and self.use_dropout) else 1.0
+            loss_t, dg = self._new(1), self._new(N, Fh)
+            head_partial = self._new(nb, Fh * self.C + self.C + 1)
+            self._ck(lib.ng_head_loss_bwd(h, st, N, batch.G, Fh, self.C, batch.max_graph_atoms, ptr(g), seed, 1 << 40, keep,
+                                          None, ptr(P["out/kernel"]), ptr(P["out/bias"]), ptr(batch.atoms),
+                                          ptr(self.peak_std), ptr(self.peak_avg), ptr(batch.graph_ptr), ptr(y), ptr(w),
+                                          float(gw), ptr(peaks), ptr(dg), ptr(head_partial)),
+                     "ng_head_loss_bwd")
+        elif training and self.use_dropout and dropout_mask is None:
             # the keep-mask is drawn inside the head launch and kept for the backward (the values of ng_dropout_mask)
             mask = self._new(N, Fh)
             self._ck(lib.ng_head_fwd_dropout(h, st, N, Fh, self.C, ptr(g), seed, 1 << 40, 1.0 - DROPOUT_RATE, ptr(mask),
@@ -286,8 +308,14 @@ class Engine:
             self._ck(lib.ng_head_fwd(h, st, N, Fh, self.C, ptr(g), ptr(mask), ptr(P["out/kernel"]),
                                      ptr(P["out/bias"]), ptr(batch.atoms), ptr(self.peak_std),
                                      ptr(self.peak_avg), ptr(peaks)), "ng_head_fwd")
+        if loss is not None and nb == 0:
+            y, w, gw = loss
+            loss_t, dpeaks = self.loss_l2(batch, y, w, peaks)
+            if gw != 1.0:
+                dpeaks.mul_(gw)
         if tape:
             tp = Tape()
+            tp.loss, tp.dpeaks, tp.dg, tp.head_partial = loss_t, dpeaks, dg, head_partial
             tp.batch, tp.d_eff, tp.z_save, tp.e = batch, d_eff, z_save, e
             tp.z_layout = z_layout
             tp.live = live
@@ -389,7 +417,8 @@ class Engine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpeaks, on_node_grads=None):
-        """fills params.grad (overwrite) from the upstream gradient dpeaks[N].
+        """fills params.grad (overwrite) from the upstream gradient dpeaks[N] (None: the gradient of the loss
+        taken inside ``forward(loss=...)``).
         ``on_node_grads`` is called once every non-edge gradient has been enqueued (the data-parallel
         trainer launches the node-side all-reduce there, overlapping the edge-MLP backward)."""
         tp = self.tape
@@ -415,12 +444,26 @@ class Engine:
         Fh = F // 2
         ne = b.n_edges
         self._ck(lib.ng_ctx_set_graph_span(h, b.max_graph_atoms), "ng_ctx_set_graph_span")
-        dpeaks = dpeaks.contiguous()
-        dg = self._new(N, Fh)
-        self._ck(lib.ng_head_bwd(h, st, N, Fh, self.C, ptr(tp.g), ptr(tp.drop_mask),
-                                 ptr(P["out/kernel"]), ptr(b.atoms), ptr(self.peak_std),
-                                 ptr(dpeaks), ptr(dg), ptr(P.g("out/kernel")), ptr(P.g("out/bias"))),
-                 "ng_head_bwd")
+        if dpeaks is None and tp.dg is not None:
+            # head + loss + head backward ran as one launch in the forward: only its weight-gradient partials are left
+            dg = tp.dg
+            self._ck(lib.ng_head_loss_reduce(h, st, ptr(tp.head_partial), tp.head_partial.shape[0], Fh, self.C,
+                                             ptr(P.g("out/kernel")), ptr(P.g("out/bias")), ptr(tp.loss)),
+                     "ng_head_loss_reduce")
+        else:
+            if tp.dg is not None:
+                raise RuntimeError("backward(dpeaks) after forward(loss=...): the head's backward already ran with the "
+                                   "loss gradient; call backward(None)")
+            if dpeaks is None:
+                dpeaks = tp.dpeaks
+            if dpeaks is None:
+                raise RuntimeError("backward(None) without forward(loss=...)")
+            dpeaks = dpeaks.contiguous()
+            dg = self._new(N, Fh)
+            self._ck(lib.ng_head_bwd(h, st, N, Fh, self.C, ptr(tp.g), ptr(tp.drop_mask),
+                                     ptr(P["out/kernel"]), ptr(b.atoms), ptr(self.peak_std),
+                                     ptr(dpeaks), ptr(dg), ptr(P.g("out/kernel")), ptr(P.g("out/bias"))),
+                     "ng_head_bwd")
         dx = self._new(N, F)
         Wfc = [P[f"fc/{t}/kernel"] for t in range(self.Lf)]
         ns = int(lib.ng_fc_block_scratch_floats(N, F, self.Lf))

@@ -196,6 +196,21 @@ class GraphBatch:
         n_entries = self.n_edges
         csc_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=self.device)
         csc_edge = torch.empty(max(n_entries, 1), dtype=torch.int32, device=self.device)
+        if nlist_c is not None and not self.is_csr and self._live is None \
+                and ctx.lib.ng_graph_lists_one_launch(self.N, self.K):
+            # molecule-sized call: the live-edge view in the same launch (ng_build_graph_lists)
+            perm = torch.empty(n_entries, dtype=torch.int32, device=self.device)
+            pos = torch.empty(n_entries, dtype=torch.int32, device=self.device)
+            d_c = torch.empty(n_entries, dtype=torch.float32, device=self.device)
+            n_live = torch.empty(1, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                ctx.check(ctx.lib.ng_build_graph_lists(ctx.handle, st, self.N, self.K, ptr(self.nlist), ptr(self.edges),
+                                                       ptr(nlist_c), ptr(csc_ptr), ptr(csc_edge), ptr(perm), ptr(pos),
+                                                       ptr(d_c), ptr(n_live)), "ng_build_graph_lists")
+            self._csc = (csc_ptr, csc_edge)
+            self._live = (perm, pos, d_c, n_live)
+            return
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             ctx.check(ctx.lib.ng_build_incoming_lists(ctx.handle, st, self.N, 0 if self.is_csr else self.K, n_entries,

@@ -51,14 +51,16 @@ class Trainer:
             # sequence of draws instead of replaying it
             seed = 0x9E3779B97F4A7C15 ^ (eng.adam_t * 1000003) ^ (rank * 0x5851F42D4C957F2D)
         seed &= (1 << 63) - 1
-        peaks = eng.forward(batch, training=True, seed=seed)
-        if self.loss_balance == 1.0:
-            loss, dpred = eng.loss_l2(batch, y, w, peaks)
-        else:
-            loss, dpred = eng.loss_name(batch, y, w, peaks, self.loss_balance)
         wgt = shard_grad_weight(batch.G, world, total_graphs)
-        if wgt != 1.0:
-            dpred.mul_(wgt)
+        if self.loss_balance == 1.0:
+            # the L2 loss is taken inside the forward: head, loss and the head's backward are one launch where the shape allows
+            eng.forward(batch, training=True, seed=seed, loss=(y, w, wgt))
+            loss, dpred = eng.tape.loss, None
+        else:
+            peaks = eng.forward(batch, training=True, seed=seed)
+            loss, dpred = eng.loss_name(batch, y, w, peaks, self.loss_balance)
+            if wgt != 1.0:
+                dpred.mul_(wgt)
         eng.backward(dpred, on_node_grads=self.buckets.launch_node)
         self.buckets.launch_edge()
         if self.measure_comm:

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/nmrgnn_hip.h but not exported"
     assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
-    assert lib.ng_abi_version() == 8
+    assert lib.ng_abi_version() == 9
 
 
 def test_engine_refuses_to_run_without_gpu():

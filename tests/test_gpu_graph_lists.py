@@ -96,3 +96,37 @@ def test_incoming_lists_long_segments(gpu_device, hub):
     np.testing.assert_array_equal(eid.cpu().numpy()[:len(he)], he)
     gb2 = GraphBatch.from_csr(atoms, row_ptr.astype(np.int32), col, dist, device=gpu_device)
     assert torch.equal(gb2.csc()[1][:len(he)], eid[:len(he)])
+
+
+@pytest.mark.parametrize("atoms,K,pad", [(5, 2, 0.0), (256, 16, 0.05), (700, 16, 0.3), (2048, 8, 0.1)])
+def test_one_launch_builds_lists_and_live_view(gpu_device, atoms, K, pad):
+    """ng_build_graph_lists (ABI 9): molecule-sized calls build the incoming lists and the live-edge view in ONE launch; the
+    outputs are those of the two separate builders, and of the host construction"""
+    from nmrgnn_amd import _lib, synth
+    from nmrgnn_amd._lib import ptr
+    from nmrgnn_amd.graph import GraphBatch
+    import ctypes as C
+    b = synth.make_batch(1, atoms, K, 10, pad, seed=atoms + K)
+    ctx = _lib.get_context(gpu_device.index)
+    assert ctx.lib.ng_graph_lists_one_launch(atoms, K) == 1
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    assert gb._live is not None                      # built by the same launch
+    perm, pos, d_c, n_live = gb._live
+    ne = atoms * K
+    p2 = torch.empty(ne, dtype=torch.int32, device=gpu_device)
+    q2 = torch.empty(ne, dtype=torch.int32, device=gpu_device)
+    d2 = torch.empty(ne, dtype=torch.float32, device=gpu_device)
+    n2 = torch.empty(1, dtype=torch.int32, device=gpu_device)
+    st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    ctx.check(ctx.lib.ng_build_live_edges(ctx.handle, st, ne, ptr(gb.edges), ptr(p2), ptr(q2), ptr(d2), ptr(n2)), "live")
+    torch.cuda.synchronize()
+    nl = int(n_live)
+    assert nl == int(n2) == int((b["edges"] > 0).sum())
+    assert torch.equal(perm, p2) and torch.equal(pos, q2) and torch.equal(d_c[:nl], d2[:nl])
+    cp, ce = gb.csc()
+    hp, he = _host_lists(b["nlist"], b["edges"], atoms)
+    np.testing.assert_array_equal(cp.cpu().numpy(), hp)
+    np.testing.assert_array_equal(ce.cpu().numpy()[:len(he)], he)
+    own = np.arange(atoms)[:, None]
+    np.testing.assert_array_equal(gb.nlist_c.cpu().numpy(), np.where(b["edges"] > 0, b["nlist"], own))
+    assert ctx.lib.ng_graph_lists_one_launch(4096, 16) == 0

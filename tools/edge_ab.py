@@ -21,6 +21,8 @@ lib, h = eng.lib, eng.ctx.handle
 lay = int(lib.ng_edge_tape_layout(128, 3, 4, 1, ne))
 fwd = lambda: eng._ck(lib.ng_edge_mlp_fwd(h, eng._st(), ne, 128, 3, 4, 1, ptr(d), ptr(d), ptr(eng.centers), eng.gap, ptr_array(W), ptr_array(B), ptr(e), ptr(z)), "f")
 bwd = lambda: eng._ck(lib.ng_edge_mlp_bwd_tape(h, eng._st(), ne, 128, 3, 4, 1, ptr(d), ptr(d), ptr(eng.centers), eng.gap, ptr_array(W), ptr(z), ptr(de), ptr_array(dW), ptr_array(dB), lay), "b")
-for _ in range(3): fwd(); bwd()
-f = np.median(bench.event_timed(fwd, 20)); b = np.median(bench.event_timed(bwd, 20))
-print("edge fwd %.3f ms  bwd %.3f ms   env: %s" % (f, b, " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("NG_"))))
+fwd_inf = lambda: eng._ck(lib.ng_edge_mlp_fwd(h, eng._st(), ne, 128, 3, 4, 1, ptr(d), ptr(d), ptr(eng.centers), eng.gap, ptr_array(W), ptr_array(B), ptr(e), None), "f")
+for _ in range(3): fwd(); bwd(); fwd_inf()
+f = np.median(bench.event_timed(fwd, 20)); b = np.median(bench.event_timed(bwd, 20)); fi = np.median(bench.event_timed(fwd_inf, 20))
+print("edge fwd %.3f ms (no tape: %.3f; tape 3 x %d x 512 B = %.2f GB -> %.2f TB/s over the difference)  bwd %.3f ms   env: %s"
+      % (f, fi, ne, 3 * ne * 512 / 1e9, 3 * ne * 512 / 1e9 / max(f - fi, 1e-9), b, " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("NG_"))))
