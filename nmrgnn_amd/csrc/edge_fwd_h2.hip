@@ -214,6 +214,14 @@ __device__ __forceinline__ void h2_epilogue_q(const f32x16& acc, u32x4 (&bfo)[2]
 
 #define H2_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// -DH2_STAMP (tools/variants): cycle stamps of one wave of one workgroup through its third tile, printed by the launcher
+#ifdef H2_STAMP
+__device__ unsigned long long h2_stamps[2][64];
+#define H2_T(i) do { if (blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 5) && tile == blockIdx.x + 2 * (int64_t)gridDim.x) h2_stamps[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define H2_T(i) do { } while (0)
+#endif
+
 template <int SAVE>
 __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_h2[];
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
       const int64_t lstride = a.z_layer_stride;
       auto zpl = [&](int layer) -> float* { return todummy ? a.dummy + 4 * hf : zp0 + layer * lstride; };
       // B fragments of the first two steps up front, the rest inside layer 0's first chunk
+      H2_T(0);
       rbf_unit(0, 0, 0); rbf_unit(0, 0, 1); rbf_unit(0, 1, 0); rbf_unit(0, 1, 1);
       {   // distances of this workgroup's next tile
         const int64_t gn = std::min<int64_t>((tile + gridDim.x) * H2_TM + 32 * wave + l31, n_edges - 1);
@@ -332,7 +341,9 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
       }
 #pragma unroll
       for (int layer = 0; layer < 3; ++layer) {
+        H2_T(1 + 5 * layer);
         H2_STEP_BEGIN();
+        H2_T(2 + 5 * layer);
         if (layer == 0) {
           h2_hidden_chunk_f(ring + use_s * SLOT, bf, acc[0], acc[1], sBias, 0, lane, [&](int step) {
             if (step < 6) { rbf_unit((step + 2) >> 1, (step + 2) & 1, 0); rbf_unit((step + 2) >> 1, (step + 2) & 1, 1); }
@@ -344,18 +355,22 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
             if (step >= 2 && step < 6) h2_epilogue_q<SAVE, true>(acc[3], bf[3], step - 2, zp + 3 * bstride, qstride);
           });
         }
+        H2_T(3 + 5 * layer);
         // blocks 2 / 3 of THIS layer (the previous layer's acc[2] / acc[3] were consumed inside the chunk above)
         h2_hidden_chunk_f(ring + use_s * SLOT + H2_CHUNK, bf, acc[2], acc[3], sBias + layer * FH, 2, lane, [&](int step) {
           acc[0][2 * step] = h2_softplus(acc[0][2 * step]); acc[0][2 * step + 1] = h2_softplus(acc[0][2 * step + 1]);
           acc[1][2 * step] = h2_softplus(acc[1][2 * step]); acc[1][2 * step + 1] = h2_softplus(acc[1][2 * step + 1]);
         });
+        H2_T(4 + 5 * layer);
         H2_STEP_END();
+        H2_T(5 + 5 * layer);
         float* zp = zpl(layer);
 #pragma unroll
         for (int q = 0; q < 4; ++q) h2_epilogue_q<SAVE, false>(acc[0], bf[0], q, zp, qstride);
 #pragma unroll
         for (int q = 0; q < 4; ++q) h2_epilogue_q<SAVE, false>(acc[1], bf[1], q, zp + bstride, qstride);
       }
+      H2_T(16);
       {   // the last hidden layer's blocks 2 / 3 have no MFMAs left to hide under (the output layer needs all pieces)
         float* zp = zpl(2);
 #pragma unroll
@@ -396,6 +411,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
     }
     }
     // ---- output layer: rows 0..E-1 of one 32-row block
+    H2_T(17);
     {
       f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
@@ -422,7 +438,9 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
         }
       }
       const f32x16 acc = (acc0 + acc1) + (acc2 + acc3);   // small products | leading products
+      H2_T(18);
       H2_STEP_END();
+      H2_T(19);
       if (valid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -436,6 +454,7 @@ __global__ __launch_bounds__(512, 1) void edge_fwd_h2_kernel(EdgeH2Args a) {
         }
       }
     }
+    H2_T(20);
   }
   range_guard_raise(a.guard, bad);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -481,6 +500,24 @@ int edge_h2_fwd(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, const float
   else
     hipLaunchKernelGGL(edge_fwd_h2_kernel<0>, dim3(grid), dim3(512), 2 * H2_RING + misc, st, a);
   NG_HIP(ctx, hipGetLastError());
+#ifdef H2_STAMP
+  {
+    static int calls = 0;
+    if (++calls % 20 == 0 && ntiles > 4 * (int64_t)grid) {
+      unsigned long long hb[2][64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(h2_stamps), sizeof(hb));
+      static const char* nm[21] = {"tile start", "L0 rbf up front", "L0 barrier+request", "L0 chunk A", "L0 chunk B", "L0 dma wait", "L1 epilogue 0/1",
+                                   "L1 barrier+request", "L1 chunk A", "L1 chunk B", "L1 dma wait", "L2 epilogue 0/1", "L2 barrier+request", "L2 chunk A",
+                                   "L2 chunk B", "L2 dma wait", "epilogue 0/1", "epilogue 2/3", "out layer (barrier, request, 24 MFMA)", "out dma wait", "e stores"};
+      for (int w = 0; w < 2; ++w) {
+        fprintf(stderr, "H2 stamps, %s form, wave %d:", z_save ? "tape" : "no-tape", w ? 5 : 0);
+        for (int i = 1; i <= 20; ++i) fprintf(stderr, "  %s %lld", nm[i], (long long)(hb[w][i] - hb[w][i - 1]));
+        fprintf(stderr, "  | tile %lld\n", (long long)(hb[w][20] - hb[w][0]));
+      }
+    }
+  }
+#endif
   // the same call on f32-input MFMA, executed only if the kernel above raised the guard (operands beyond the fp16 range)
   return edge_fused_fwd_f32(ctx, st, n_edges, E, d_src, d_eff, centers, gap, W, b, e_out, z_save,
                             z_save && edge_tape_blocked(E, n_edges), &a.guard, live);
