@@ -291,7 +291,7 @@ KERNEL_SOURCES = {
     "mp_win_bwd_edge": ["mp_win16_bwd.hip", "mp_win16_common.cuh", "mp_win_bwd.hip", "h2_common.cuh"],
     "mp_win_bwd_node": ["mp_win_bwd.hip", "mp_win16_common.cuh", "h2_common.cuh"],
     "fc_fused_fwd": ["fc_fused.hip"], "fc_fused_bwd": ["fc_fused.hip"],
-    "head_fwd": ["head_ops.hip"], "head_bwd": ["head_ops.hip"], "embed_bwd": ["node_ops.hip"], "adam": ["node_ops.hip"],
+    "head_fwd": ["head_ops.hip"], "head_bwd": ["head_ops.hip"], "head_loss": ["head_ops.hip"], "embed_bwd": ["node_ops.hip"], "adam": ["node_ops.hip"],
     "reduce_partials": ["reduce.cuh", "capi.hip"], "mp_records": ["mp_win_bwd.hip"], "repack_all": ["repack.hip", "pack_bodies.cuh"],
 }
 
@@ -857,7 +857,7 @@ def one_graph_leg(dev, hp, n_graphs=64, steps=200):
     rev = event_timed(rstep, steps)
     replay = {"ms_per_step": wall, "ms_per_step_hipevent_median": float(np.median(rev)),
               "note": "HIP-graph replay (TrainStepReplay): 1 staging launch + 1 graph launch per step"}
-    eag = {"ms_per_step": eager, "ms_per_step_hipevent_median": float(np.median(ev)), "note": "~33 eager launches per step"}
+    eag = {"ms_per_step": eager, "ms_per_step_hipevent_median": float(np.median(ev)), "note": "28 eager launches per step (34 before the round-6 merges)"}
     # which of the two wins depends on the host: the GPU timeline of the step is ~0.30 ms either way (small-kernel latency,
     # DESIGN 4.5); the replay takes the host's launch work out
     best, path = (replay, "replay") if wall <= eager else (eag, "eager")
