@@ -438,8 +438,10 @@ __global__ __launch_bounds__(HX_THREADS, 1) void edge_bwd_h2_kernel(EdgeBwdH2Arg
 // scale — and with it every bit of the result — does not depend on the launch geometry.
 constexpr int HX_SCALE_BLOCKS = 1024;
 constexpr int64_t HX_DIRECT_MAX = 32768;      // values of de a workgroup scans itself (edge_bwd_h2_launch)
-__global__ __launch_bounds__(256) void hx_absmax_kernel(const float* __restrict__ de, int64_t n, float* __restrict__ blockmax) {
+__global__ __launch_bounds__(256) void hx_absmax_kernel(const float* __restrict__ de, int64_t n, float* __restrict__ blockmax,
+                                                        const int32_t* __restrict__ n_live) {
   __shared__ float red[4];
+  if (n_live && *n_live < 0) return;      // the launch behind this one has nothing to do (edge-function table: guard down)
   float m = 0.f;
   // float4 body when the tensor starts 16-byte aligned (a torch allocation does), the rest element by element
   const int64_t n4 = (reinterpret_cast<uintptr_t>(de) & 15) == 0 ? n >> 2 : 0;
@@ -497,7 +499,7 @@ int edge_bwd_h2_launch(ng_ctx* ctx, hipStream_t st, int64_t n_edges, int E, cons
       blockmax = const_cast<float*>(de);
     } else {
       nb_max = (int)std::min<int64_t>(HX_SCALE_BLOCKS, cdiv(n_edges * E, 1024));
-      hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb_max), dim3(256), 0, st, de, n_edges * E, blockmax);
+      hipLaunchKernelGGL(hx_absmax_kernel, dim3(nb_max), dim3(256), 0, st, de, n_edges * E, blockmax, live.n_live);
       NG_HIP(ctx, hipGetLastError());
     }
   }

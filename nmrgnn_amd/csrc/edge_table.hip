@@ -25,6 +25,8 @@
 namespace ng {
 
 constexpr int ET_BLOCK = 256;
+constexpr int ET_WIDE = 1024;      // the per-edge passes that keep the table in LDS: one workgroup per CU (one table copy), sixteen waves (round 6: 256 threads and
+                                   // one copy per workgroup of four waves left a CU with four waves walking 32 dependent round trips each: scatter 57 us)
 
 // lo, hi of d_eff over the live slots (d_src > 0) and max |de| (de may be null): out = {lo, hi, maxabs}.  Two stages.
 // pos (nullable): d_eff is compacted, slot i's distance is d_eff[pos[i]] (ng_build_live_edges)
@@ -33,11 +35,37 @@ __global__ __launch_bounds__(ET_BLOCK) void et_range_kernel(int64_t n, int E, co
                                                           const float* __restrict__ de, float* __restrict__ part) {
   __shared__ float s[3][ET_BLOCK / 64];
   float lo = 3.0e38f, hi = -3.0e38f, mx = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * ET_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * ET_BLOCK) {
-    if (d_src[i] > 0.f) {
-      if (d_eff) { const float d = d_eff[pos ? pos[i] : i]; lo = fminf(lo, d); hi = fmaxf(hi, d); }
-      if (de)
-        for (int c = 0; c < E; ++c) mx = fmaxf(mx, fabsf(de[i * E + c]));
+  // four slots per trip, every load of the trip requested before the first is used (dead slots read slot 0's distance / their own
+  // gradient row and are masked out of the min / max: one slot per trip was a chain of two or three dependent round trips, 15.8 us
+  // for the 33 MB of the gradient pass)
+  const int64_t stride = (int64_t)gridDim.x * ET_BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * ET_BLOCK + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    float ds[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ds[u] = d_src[std::min<int64_t>(i0 + u * stride, n - 1)];
+    int32_t pi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = std::min<int64_t>(i0 + u * stride, n - 1);
+      pi[u] = (d_eff && pos) ? pos[i] : (int32_t)i;
+    }
+    float dv[4], g[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = std::min<int64_t>(i0 + u * stride, n - 1);
+      const bool live = ds[u] > 0.f && i0 + u * stride < n;
+      dv[u] = d_eff ? d_eff[live ? pi[u] : 0] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g[u][c] = (de && c < E) ? de[i * E + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool live = ds[u] > 0.f && i0 + u * stride < n;
+      if (live) {
+        if (d_eff) { lo = fminf(lo, dv[u]); hi = fmaxf(hi, dv[u]); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fabsf(g[u][c]));
+      }
     }
   }
 #pragma unroll
@@ -168,17 +196,17 @@ __device__ __forceinline__ void et_stencil(float d, float lo, float inv_h, int T
 
 // e[i][c] = m_i * sum_k w_k e_tab[i0 + k][c]; the table (T x E floats) sits in LDS
 template <int EC>
-__global__ __launch_bounds__(ET_BLOCK) void et_interp_kernel(int64_t n, int T, const float* __restrict__ d_src,
+__global__ __launch_bounds__(ET_WIDE) void et_interp_kernel(int64_t n, int T, const float* __restrict__ d_src,
                                                            const float* __restrict__ d_eff, const int32_t* __restrict__ pos,
                                                            const float* __restrict__ range, const float* __restrict__ e_tab,
                                                            const int32_t* __restrict__ gate, float* __restrict__ e_out) {
   extern __shared__ float et_s[];
   if (gate && gate[0] != 0) return;      // the guard is up: the per-edge kernels have written e
-  for (int t = threadIdx.x; t < T * EC; t += ET_BLOCK) et_s[t] = e_tab[t];
+  for (int t = threadIdx.x; t < T * EC; t += ET_WIDE) et_s[t] = e_tab[t];
   __syncthreads();
   float lo, inv_h, h;
   et_geom(range, T, lo, inv_h, h);
-  for (int64_t i = (int64_t)blockIdx.x * ET_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * ET_BLOCK) {
+  for (int64_t i = (int64_t)blockIdx.x * ET_WIDE + threadIdx.x; i < n; i += (int64_t)gridDim.x * ET_WIDE) {
     float r[EC];
 #pragma unroll
     for (int c = 0; c < EC; ++c) r[c] = 0.f;
@@ -199,12 +227,12 @@ __global__ __launch_bounds__(ET_BLOCK) void et_interp_kernel(int64_t n, int T, c
 // adjoint: table[i0 + k][c] += w_k * m_i * de[i][c], in 64-bit fixed point (scale 2^sh from max |de|: |sum| < 2^62 for up to
 // 2^21 terms of size <= 2^40 each), per workgroup in LDS, partial tables to memory
 template <int EC>
-__global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, const float* __restrict__ d_src,
+__global__ __launch_bounds__(ET_WIDE) void et_scatter_kernel(int64_t n, int T, const float* __restrict__ d_src,
                                                             const float* __restrict__ d_eff, const int32_t* __restrict__ pos,
                                                             const float* __restrict__ range, const float* __restrict__ de,
                                                             long long* __restrict__ part) {
   extern __shared__ long long et_q[];
-  for (int t = threadIdx.x; t < T * EC; t += ET_BLOCK) et_q[t] = 0;
+  for (int t = threadIdx.x; t < T * EC; t += ET_WIDE) et_q[t] = 0;
   __syncthreads();
   float lo, inv_h, h;
   et_geom(range, T, lo, inv_h, h);
@@ -212,7 +240,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, 
   int ex = 0;
   if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex);      // mx <= 2^ex
   const float scale = ldexpf(1.0f, 38 - ex);                // |w de| * scale < 2^39 (|w| < 1.5)
-  for (int64_t i = (int64_t)blockIdx.x * ET_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * ET_BLOCK) {
+  for (int64_t i = (int64_t)blockIdx.x * ET_WIDE + threadIdx.x; i < n; i += (int64_t)gridDim.x * ET_WIDE) {
     if (d_src[i] > 0.f) {
       int i0;
       float w[4];
@@ -231,7 +259,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_scatter_kernel(int64_t n, int T, 
   }
   __syncthreads();
   long long* p = part + (size_t)blockIdx.x * T * EC;
-  for (int t = threadIdx.x; t < T * EC; t += ET_BLOCK) p[t] = et_q[t];
+  for (int t = threadIdx.x; t < T * EC; t += ET_WIDE) p[t] = et_q[t];
 }
 // 64 table entries per workgroup, four groups of 64 threads each summing a quarter of the workgroups' partial tables (eight
 // loads in flight; one thread walking all 256 partials of its entry was a chain of dependent round trips: 62 us).  Integer
@@ -276,7 +304,7 @@ using namespace ng;
 extern "C" int ng_edge_table_range(ng_ctx* ctx, void* stream, int64_t n, int E, const float* d_src, const float* d_eff,
                                    const int32_t* pos, const float* de, float pad, float* range) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, d_src && range && (d_eff || de) && pad >= 0.f && pad <= 4.f, "edge_table_range: arguments");
+  NG_REQUIRE(ctx, d_src && range && (d_eff || de) && pad >= 0.f && pad <= 4.f && (!de || (E >= 1 && E <= 4)), "edge_table_range: arguments (E <= 4)");
   hipStream_t st = (hipStream_t)stream;
   const int nb = std::max(1, et_blocks(ctx, n));
   float* part = (float*)aux_workspace(ctx, (size_t)nb * 3 * 4);
@@ -317,14 +345,14 @@ extern "C" int ng_edge_table_interp(ng_ctx* ctx, void* stream, int64_t n, int E,
   NG_REQUIRE(ctx, E >= 1 && E <= 4 && T >= 8 && (size_t)T * E * 4 <= 64 * 1024, "edge_table_interp: E <= 4, table <= 64 KB");
   if (n == 0) return NG_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = et_blocks(ctx, n);
+  const int nb = std::max(1, (int)std::min<int64_t>(cdiv(n, ET_WIDE), (int64_t)ctx->num_cu));
   const size_t lds = (size_t)T * E * 4;
   ProfScope ps(ctx, st, "edge_table_interp");
   switch (E) {
-    case 1: hipLaunchKernelGGL((et_interp_kernel<1>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
-    case 2: hipLaunchKernelGGL((et_interp_kernel<2>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
-    case 3: hipLaunchKernelGGL((et_interp_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
-    default: hipLaunchKernelGGL((et_interp_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    case 1: hipLaunchKernelGGL((et_interp_kernel<1>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    case 2: hipLaunchKernelGGL((et_interp_kernel<2>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    case 3: hipLaunchKernelGGL((et_interp_kernel<3>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    default: hipLaunchKernelGGL((et_interp_kernel<4>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
   }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
@@ -338,16 +366,16 @@ extern "C" int ng_edge_table_scatter(ng_ctx* ctx, void* stream, int64_t n, int E
   hipStream_t st = (hipStream_t)stream;
   // max |de| over the live slots -> range[2]
   if (int rc = ng_edge_table_range(ctx, stream, n, E, d_src, nullptr, nullptr, de, 0.f, range)) return rc;
-  const int nb = std::max(1, (int)std::min<int64_t>(cdiv(n, (int64_t)ET_BLOCK * 8), (int64_t)ctx->num_cu));
+  const int nb = std::max(1, (int)std::min<int64_t>(cdiv(n, (int64_t)ET_WIDE * 2), (int64_t)ctx->num_cu));
   long long* part = (long long*)workspace(ctx, (size_t)nb * T * E * 8);
   if (!part) return NG_ERR_NOMEM;
   const size_t lds = (size_t)T * E * 8;
   ProfScope ps(ctx, st, "edge_table_scatter");
   switch (E) {
-    case 1: hipLaunchKernelGGL((et_scatter_kernel<1>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
-    case 2: hipLaunchKernelGGL((et_scatter_kernel<2>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
-    case 3: hipLaunchKernelGGL((et_scatter_kernel<3>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
-    default: hipLaunchKernelGGL((et_scatter_kernel<4>), dim3(nb), dim3(ET_BLOCK), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    case 1: hipLaunchKernelGGL((et_scatter_kernel<1>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    case 2: hipLaunchKernelGGL((et_scatter_kernel<2>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    case 3: hipLaunchKernelGGL((et_scatter_kernel<3>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    default: hipLaunchKernelGGL((et_scatter_kernel<4>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
   }
   hipLaunchKernelGGL(et_scatter_final_kernel, dim3((unsigned)cdiv(rows_out * E, 64)), dim3(ET_BLOCK), 0, st, nb, T * E, rows_out * E, part,
                      range, de_tab);
