@@ -110,8 +110,9 @@ __device__ __noinline__ EdgeDots<E> edge_dot_global(int lane, int al, int idx, c
   return r;
 }
 
-template <int E, bool H2>
+template <int E, bool H2, int ACT = -1>      // ACT: compile-time activation (softplus) or -1 = from the arguments (mp_wave.hip: body)
 __device__ __forceinline__ void body(const Args& a) {
+  const int act_ = ACT >= 0 ? ACT : a.act;
   constexpr int KF = E * WF;
   constexpr int LD = KF + 4;
   constexpr int NCT = KF / 16;              // column tiles of dA: one per matrix wave
@@ -174,9 +175,9 @@ __device__ __forceinline__ void body(const Args& a) {
   // dP rows of tile t into the planes (and HBM), the tile's neighbour range into ctl
   auto commit = [&](int64_t t) {
     float4 g = p_dh;
-    if (a.act != NG_ACT_NONE) {
-      g.x *= act_grad_from_out(a.act, p_s.x); g.y *= act_grad_from_out(a.act, p_s.y);
-      g.z *= act_grad_from_out(a.act, p_s.z); g.w *= act_grad_from_out(a.act, p_s.w);
+    if (act_ != NG_ACT_NONE) {
+      g.x *= act_grad_from_out(act_, p_s.x); g.y *= act_grad_from_out(act_, p_s.y);
+      g.z *= act_grad_from_out(act_, p_s.z); g.w *= act_grad_from_out(act_, p_s.w);
     }
     g.x *= p_rs; g.y *= p_rs; g.z *= p_rs; g.w *= p_rs;
     if (H2) {
@@ -285,6 +286,7 @@ __device__ __forceinline__ void body(const Args& a) {
 template <int E>
 __global__ __launch_bounds__(WTHREADS) void mp_win16_bwd_edge_kernel(Args a) {
   if (a.guard.word && (range_guard_raised(a.guard) || wimage_flag_raised(a.wflag))) body<E, false>(a);
+  else if (a.act == NG_ACT_SOFTPLUS) body<E, true, NG_ACT_SOFTPLUS>(a);
   else body<E, true>(a);
 }
 
