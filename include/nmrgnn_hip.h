@@ -65,7 +65,10 @@ int ng_weights_changed(ng_ctx* ctx);
  * ng_defer_reductions(ctx, stream, 1) and the matching ng_defer_reductions(ctx, stream, 0) the entry points keep their
  * partials in a context-owned arena and only QUEUE the reduction; ng_flush_reductions(ctx, stream) runs everything
  * queued so far in one launch on `stream` (switching deferral off flushes too).  A gradient tensor is defined only
- * after the flush that follows its entry point; the bits are those of the eager form.  Off by default. */
+ * after the flush that follows its entry point; the bits are those of the eager form.  Off by default.
+ * ABI 9: inside such a window ng_embed_bwd of a molecule-sized call (N <= 2048) launches nothing of its own — its sum
+ * is a job of the flush launch that reads `atoms` and `dh0` THEN: both must stay valid and unchanged until the flush
+ * (the same holds for the caller-owned `partial` of ng_head_loss_reduce). */
 int ng_defer_reductions(ng_ctx* ctx, void* stream, int on);
 int ng_flush_reductions(ng_ctx* ctx, void* stream);
 /* Hint about the batch the following calls work on: the largest number of atoms of one member graph (the reference
