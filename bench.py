@@ -702,11 +702,18 @@ def main():
             ms = event_timed(step, tsteps)
             eng.forward(gb)
             ims = event_timed(lambda: eng.forward(gb), tsteps)
+            # serving form: weights frozen, the table kept over calls (built once per weight generation; every call checks its own
+            # distance range against the table's on the device)
+            eng.freeze_weights(True)
+            eng.forward(gb)
+            fms = event_timed(lambda: eng.forward(gb), tsteps)
+            eng.freeze_weights(False)
             peaks_t = eng.forward(gb, training=True, seed=1)
             rep = eng.edge_table_report()
             eng.tape = None
             blk = {"ms_per_step": float(np.median(ms)), "value": gb.N / (np.median(ms) * 1e-3), "unit": "atoms/s", "steps": tsteps,
                    "inference_ms_per_step": float(np.median(ims)),
+                   "inference_frozen_weights_ms_per_step": float(np.median(fms)),
                    "max_abs_peak_difference_to_per_edge_path": p_diff,
                    "guard": {"raised": rep[0], "midpoint_error": rep[1], "max_abs_e": rep[2], "tolerance_relative": eng.edge_table_tol},
                    "note": "Engine default (NG_EDGE_TABLE=0 / Engine.edge_table = False: per edge): edge MLP evaluated on a 4096-point "
