@@ -224,7 +224,9 @@ __global__ __launch_bounds__(HL_NT) void head_loss_kernel(HeadLossArgs a) {
   float* __restrict__ dgo = a.dg;
   const int g0 = blockIdx.x * a.gpw, g1 = min(a.G, g0 + a.gpw);
   const int64_t r0 = a.gptr[g0], r1 = a.gptr[g1];
-  const int nrows = (int)(r1 - r0);      // <= HL_ROWS (the host's choice of gpw)
+  int nrows = (int)(r1 - r0);            // <= HL_ROWS by the host's choice of gpw from max_graph_atoms ...
+  const bool overlong = nrows > HL_ROWS;       // ... unless the caller's max_graph_atoms understated graph_ptr: stay inside the LDS
+  if (overlong) nrows = HL_ROWS;               // arrays and poison the loss (the rows beyond are left unwritten)
   const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
   float4 xr[RPT];
 #pragma unroll
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(HL_NT) void head_loss_kernel(HeadLossArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float wl = 0.f;
     for (int gi = g0 + wv; gi < g1; gi += NW) {
-      const int ga = a.gptr[gi] - (int)r0, gb = a.gptr[gi + 1] - (int)r0;
+      const int ga = min(a.gptr[gi] - (int)r0, nrows), gb = min(a.gptr[gi + 1] - (int)r0, nrows);
       float sw = 0.f, sl = 0.f;
       for (int i = ga + lane; i < gb; i += 64) {
         const float d = s_y[i] - s_pk[i];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(HL_NT) void head_loss_kernel(HeadLossArgs a) {
   if (threadIdx.x == 0) {      // s_red: written before the barrier behind the loss
     float s = 0.f;
     for (int w = 0; w < NW; ++w) s += s_red[w];
-    a.partial[(int64_t)blockIdx.x * (items + 1) + items] = s / (float)a.G;
+    a.partial[(int64_t)blockIdx.x * (items + 1) + items] = overlong ? __builtin_nanf("") : s / (float)a.G;
   }
 }
 

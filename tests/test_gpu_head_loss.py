@@ -141,3 +141,33 @@ def test_small_call_embedding_gradient_rides_with_the_deferred_reductions(gpu_de
             assert float(np.abs(gb[k]).max()) > 0
         else:
             assert np.array_equal(ga[k], gb[k]), k
+
+
+def test_understated_graph_length_poisons_the_loss_and_stays_in_bounds(gpu_device):
+    """C-ABI caller error: max_graph_atoms smaller than graph_ptr's longest graph.  The launch must stay inside its LDS arrays
+    (rows beyond the 256 a workgroup can hold are left unwritten) and the loss comes back NaN."""
+    import ctypes as C
+    from nmrgnn_amd import _lib
+    from nmrgnn_amd._lib import ptr
+    dev = gpu_device
+    ctx = _lib.get_context(dev.index)
+    N, Fh, Cn = 400, 32, 10
+    g = torch.randn(N, Fh, device=dev)
+    atoms = torch.zeros(N, Cn, device=dev); atoms[:, 3] = 1
+    W, b = torch.randn(Fh, Cn, device=dev), torch.randn(Cn, device=dev)
+    std, avg = torch.ones(Cn, device=dev), torch.zeros(Cn, device=dev)
+    gptr = torch.tensor([0, 300, 400], dtype=torch.int32, device=dev)
+    y, w = torch.randn(N, device=dev), torch.ones(N, device=dev)
+    nb = ctx.lib.ng_head_loss_blocks(ctx.handle, 2, Fh, Cn, 200)          # the caller claims 200 atoms per graph
+    assert nb == 2
+    peaks, dg = torch.zeros(N, device=dev), torch.zeros(N, Fh, device=dev)
+    part = torch.zeros(nb, Fh * Cn + Cn + 1, device=dev)
+    dW, db, loss = torch.zeros(Fh, Cn, device=dev), torch.zeros(Cn, device=dev), torch.zeros(1, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.check(ctx.lib.ng_head_loss_bwd(ctx.handle, st, N, 2, Fh, Cn, 200, ptr(g), 1, 0, 1.0, None, ptr(W), ptr(b), ptr(atoms), ptr(std),
+                                       ptr(avg), ptr(gptr), ptr(y), ptr(w), 1.0, ptr(peaks), ptr(dg), ptr(part)), "head_loss_bwd")
+    ctx.check(ctx.lib.ng_head_loss_reduce(ctx.handle, st, ptr(part), nb, Fh, Cn, ptr(dW), ptr(db), ptr(loss)), "head_loss_reduce")
+    torch.cuda.synchronize()
+    assert torch.isnan(loss).all()
+    assert torch.isfinite(peaks).all() and torch.isfinite(dg).all()
+    assert float(peaks[256:300].abs().max()) == 0.0          # rows a workgroup cannot hold: untouched
