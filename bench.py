@@ -722,7 +722,7 @@ def main():
             if not args.no_profile:
                 prof_t = profiled_steps(eng, step, 3)
                 n_live = int((b["edges"] > 0).sum())
-                rows_t = roofline_rows(prof_t, 3, kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM, live_edges=2 * eng.EDGE_TABLE_POINTS),
+                rows_t = roofline_rows(prof_t, 3, kernel_work(gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, NUM_ELEM, live_edges=2 * eng._table_points()),
                                        h2_gemm=False)
                 blk["roofline_all"] = rows_t
                 blk["survey_8d"] = survey_8d_block(rows_t, gb.N, K_NEIGH, 64, 3, 128, 4, 4, 4, blk["ms_per_step"], None)

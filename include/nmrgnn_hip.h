@@ -441,7 +441,7 @@ int ng_head_loss_reduce(ng_ctx*, void* stream, const float* partial, int blocks,
  *                          cover != NULL and [cover[0], cover[1]] not inside [range[0], range[1]], or prev != NULL and
  *                          prev[0] != 0.  gate (8 device int32): {bad, bad ? *n_live : -1, bad ? 0 : rows, 0, err, scale (float
  *                          bits), -, -}.
- *   ng_edge_table_interp   e_out[i][c] = m_i sum_k w_k(d_i) e_tab[i0 + k][c]   (E <= 4, T * E <= 16384); skipped on gate[0]
+ *   ng_edge_table_interp   e_out[i][c] = m_i sum_k w_k(d_i) e_tab[i0 + k][c]   (E <= 8, T * E <= 16384: T = 2048 for E > 4); skipped on gate[0]
  *   ng_edge_table_scatter  de_tab[t][c] = sum_i m_i w_k(d_i) de[i][c] over the stencils that contain t, rows T .. rows_out-1
  *                          of de_tab zeroed (the midpoint rows of the table's backward); writes range[2] */
 int ng_edge_table_range(ng_ctx*, void* stream, int64_t n, int E, const float* d_src, const float* d_eff, const int32_t* pos,

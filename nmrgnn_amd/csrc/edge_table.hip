@@ -25,6 +25,7 @@
 namespace ng {
 
 constexpr int ET_BLOCK = 256;
+constexpr int ET_EMAX = 8;         // edge features a table carries (model.py:23 offers 1, 2, 3, 8, 64: the last one stays per edge); E > 4 with T <= 2048 (LDS)
 constexpr int ET_WIDE = 1024;      // the per-edge passes that keep the table in LDS: one workgroup per CU (one table copy), sixteen waves (round 6: 256 threads and
                                    // one copy per workgroup of four waves left a CU with four waves walking 32 dependent round trips each: scatter 57 us)
 
@@ -49,14 +50,14 @@ __global__ __launch_bounds__(ET_BLOCK) void et_range_kernel(int64_t n, int E, co
       const int64_t i = std::min<int64_t>(i0 + u * stride, n - 1);
       pi[u] = (d_eff && pos) ? pos[i] : (int32_t)i;
     }
-    float dv[4], g[4][4];
+    float dv[4], g[4][ET_EMAX];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t i = std::min<int64_t>(i0 + u * stride, n - 1);
       const bool live = ds[u] > 0.f && i0 + u * stride < n;
       dv[u] = d_eff ? d_eff[live ? pi[u] : 0] : 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) g[u][c] = (de && c < E) ? de[i * E + c] : 0.f;
+      for (int c = 0; c < ET_EMAX; ++c) g[u][c] = (de && c < E) ? de[i * E + c] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(ET_BLOCK) void et_range_kernel(int64_t n, int E, co
       if (live) {
         if (d_eff) { lo = fminf(lo, dv[u]); hi = fmaxf(hi, dv[u]); }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fabsf(g[u][c]));
+        for (int c = 0; c < ET_EMAX; ++c) mx = fmaxf(mx, fabsf(g[u][c]));
       }
     }
   }
@@ -304,7 +305,7 @@ using namespace ng;
 extern "C" int ng_edge_table_range(ng_ctx* ctx, void* stream, int64_t n, int E, const float* d_src, const float* d_eff,
                                    const int32_t* pos, const float* de, float pad, float* range) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, d_src && range && (d_eff || de) && pad >= 0.f && pad <= 4.f && (!de || (E >= 1 && E <= 4)), "edge_table_range: arguments (E <= 4)");
+  NG_REQUIRE(ctx, d_src && range && (d_eff || de) && pad >= 0.f && pad <= 4.f && (!de || (E >= 1 && E <= ET_EMAX)), "edge_table_range: arguments (E <= 8)");
   hipStream_t st = (hipStream_t)stream;
   const int nb = std::max(1, et_blocks(ctx, n));
   float* part = (float*)aux_workspace(ctx, (size_t)nb * 3 * 4);
@@ -330,7 +331,7 @@ extern "C" int ng_edge_table_points(ng_ctx* ctx, void* stream, int T, int midpoi
 extern "C" int ng_edge_table_check(ng_ctx* ctx, void* stream, int T, int E, const float* e_all, float tol, const float* range,
                                    const float* cover, const int32_t* n_live, int rows, const int32_t* prev, int32_t* gate) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, T >= 8 && E >= 1 && E <= 4 && gate && (e_all || cover) && (!cover || range) && (size_t)2 * T * E * 4 <= 128 * 1024,
+  NG_REQUIRE(ctx, T >= 8 && E >= 1 && E <= ET_EMAX && gate && (e_all || cover) && (!cover || range) && (size_t)2 * T * E * 4 <= 128 * 1024,
              "edge_table_check: arguments (table + midpoints <= 128 KB)");
   ProfScope ps(ctx, (hipStream_t)stream, "edge_table_check");
   hipLaunchKernelGGL(et_check_kernel, dim3(1), dim3(ET_CHECK_THREADS), e_all ? (size_t)2 * T * E * 4 : 0, (hipStream_t)stream, T, E, e_all,
@@ -342,17 +343,16 @@ extern "C" int ng_edge_table_check(ng_ctx* ctx, void* stream, int T, int E, cons
 extern "C" int ng_edge_table_interp(ng_ctx* ctx, void* stream, int64_t n, int E, int T, const float* d_src, const float* d_eff,
                                     const int32_t* pos, const float* range, const float* e_tab, const int32_t* gate, float* e_out) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, E >= 1 && E <= 4 && T >= 8 && (size_t)T * E * 4 <= 64 * 1024, "edge_table_interp: E <= 4, table <= 64 KB");
+  NG_REQUIRE(ctx, E >= 1 && E <= ET_EMAX && T >= 8 && (size_t)T * E * 4 <= 64 * 1024, "edge_table_interp: E <= 8, table <= 64 KB");
   if (n == 0) return NG_OK;
   hipStream_t st = (hipStream_t)stream;
   const int nb = std::max(1, (int)std::min<int64_t>(cdiv(n, ET_WIDE), (int64_t)ctx->num_cu));
   const size_t lds = (size_t)T * E * 4;
   ProfScope ps(ctx, st, "edge_table_interp");
   switch (E) {
-    case 1: hipLaunchKernelGGL((et_interp_kernel<1>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
-    case 2: hipLaunchKernelGGL((et_interp_kernel<2>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
-    case 3: hipLaunchKernelGGL((et_interp_kernel<3>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
-    default: hipLaunchKernelGGL((et_interp_kernel<4>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+#define NG_ETI(EC) case EC: hipLaunchKernelGGL((et_interp_kernel<EC>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, e_tab, gate, e_out); break;
+    NG_ETI(1) NG_ETI(2) NG_ETI(3) NG_ETI(4) NG_ETI(5) NG_ETI(6) NG_ETI(7) NG_ETI(8)
+#undef NG_ETI
   }
   NG_HIP(ctx, hipGetLastError());
   return NG_OK;
@@ -361,8 +361,8 @@ extern "C" int ng_edge_table_interp(ng_ctx* ctx, void* stream, int64_t n, int E,
 extern "C" int ng_edge_table_scatter(ng_ctx* ctx, void* stream, int64_t n, int E, int T, int rows_out, const float* d_src,
                                      const float* d_eff, const int32_t* pos, float* range, const float* de, float* de_tab) {
   if (!ctx) return NG_ERR_INVALID;
-  NG_REQUIRE(ctx, E >= 1 && E <= 4 && T >= 8 && (size_t)T * E * 8 <= 128 * 1024 && rows_out >= T,
-             "edge_table_scatter: E <= 4, table <= 128 KB, rows_out >= T");
+  NG_REQUIRE(ctx, E >= 1 && E <= ET_EMAX && T >= 8 && (size_t)T * E * 8 <= 128 * 1024 && rows_out >= T,
+             "edge_table_scatter: E <= 8, table <= 128 KB, rows_out >= T");
   hipStream_t st = (hipStream_t)stream;
   // max |de| over the live slots -> range[2]
   if (int rc = ng_edge_table_range(ctx, stream, n, E, d_src, nullptr, nullptr, de, 0.f, range)) return rc;
@@ -372,10 +372,9 @@ extern "C" int ng_edge_table_scatter(ng_ctx* ctx, void* stream, int64_t n, int E
   const size_t lds = (size_t)T * E * 8;
   ProfScope ps(ctx, st, "edge_table_scatter");
   switch (E) {
-    case 1: hipLaunchKernelGGL((et_scatter_kernel<1>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
-    case 2: hipLaunchKernelGGL((et_scatter_kernel<2>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
-    case 3: hipLaunchKernelGGL((et_scatter_kernel<3>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
-    default: hipLaunchKernelGGL((et_scatter_kernel<4>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+#define NG_ETS(EC) case EC: hipLaunchKernelGGL((et_scatter_kernel<EC>), dim3(nb), dim3(ET_WIDE), lds, st, n, T, d_src, d_eff, pos, range, de, part); break;
+    NG_ETS(1) NG_ETS(2) NG_ETS(3) NG_ETS(4) NG_ETS(5) NG_ETS(6) NG_ETS(7) NG_ETS(8)
+#undef NG_ETS
   }
   hipLaunchKernelGGL(et_scatter_final_kernel, dim3((unsigned)cdiv(rows_out * E, 64)), dim3(ET_BLOCK), 0, st, nb, T * E, rows_out * E, part,
                      range, de_tab);

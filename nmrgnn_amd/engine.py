@@ -188,7 +188,7 @@ class Engine:
         # (the live kernels index e with 32 bits: n_slots * E * 4 < 2^31, check_live in edge_fwd_h2.hip; larger batches take the
         # every-slot kernels)
         live_ok = ne * E * 4 < (1 << 31) and bool(lib.ng_edge_live_supported(H, E, self.Le, self.fc_act))
-        use_table = self.edge_table and E <= 4 and ne >= self.edge_table_min_edges and live_ok
+        use_table = self.edge_table and E <= 8 and ne >= self.edge_table_min_edges and live_ok
         live = batch.live_edges(force=use_table) if (live_ok and (use_table or self.use_live_edges)) else None
         if live is not None:
             perm, pos, d_c, n_live = live
@@ -325,7 +325,10 @@ class Engine:
         return peaks
 
     # ------------------------------------------------------------------ edge function table (opt-in)
-    EDGE_TABLE_POINTS = 4096
+    EDGE_TABLE_POINTS = 4096      # E <= 4; 2048 for E = 5 .. 8 (the scatter's 64-bit table and the guard's staged copy share the LDS)
+
+    def _table_points(self):
+        return self.EDGE_TABLE_POINTS if self.E <= 4 else self.EDGE_TABLE_POINTS // 2
 
     def _edge_table_build(self, batch, live, d_eff_c, tape, training):
         """The table of the edge function for this call (csrc/edge_table.hip) and the guard's gate words.
@@ -335,7 +338,7 @@ class Engine:
         lib, h, st = self.lib, self.ctx.handle, self._st()
         P = self.params
         perm, pos, d_c, n_live = live
-        ne, E, H, T = batch.n_edges, self.E, self.H, self.EDGE_TABLE_POINTS
+        ne, E, H, T = batch.n_edges, self.E, self.H, self._table_points()
         d_src = batch.edges.reshape(-1)
         tol = -1.0 if self.edge_table_force_fallback else float(self.edge_table_tol)
         reuse = self._frozen and not tape and not training and not self.edge_table_force_fallback

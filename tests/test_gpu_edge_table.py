@@ -9,10 +9,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _engines(F, dev, seed=3):
+def _engines(F, dev, seed=3, E=3):
     from nmrgnn_amd.engine import Engine
     from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
-    hp = declare_gnn_space(HyperParameters(atom_feature_size=F, edge_feature_size=3, edge_hidden_size=128, mp_layers=4,
+    hp = declare_gnn_space(HyperParameters(atom_feature_size=F, edge_feature_size=E, edge_hidden_size=128, mp_layers=4,
                                            fc_layers=4, edge_fc_layers=4))
     a, b = Engine(hp, 10, device=dev, seed=seed), Engine(hp, 10, device=dev, seed=seed)
     a.edge_table = False
@@ -21,20 +21,22 @@ def _engines(F, dev, seed=3):
     return a, b
 
 
-@pytest.mark.parametrize("F,graphs", [(64, 24), (256, 6)])
-def test_table_path_matches_the_per_edge_path(gpu_device, F, graphs):
+# (E = 8, model.py:23's largest table-sized choice: 2048 points instead of 4096; the table's backward runs on the f32-input kernels)
+@pytest.mark.parametrize("F,graphs,E", [(64, 24, 3), (256, 6, 3), (64, 12, 8), (64, 12, 1)])
+def test_table_path_matches_the_per_edge_path(gpu_device, F, graphs, E):
     from nmrgnn_amd import synth
     from nmrgnn_amd.graph import GraphBatch
     b = synth.make_batch(graphs, 256, 16, 10, 0.05, seed=11)
     gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
     y = torch.from_numpy(b["y"]).to(gpu_device); w = torch.from_numpy(b["w"]).to(gpu_device)
-    ea, eb = _engines(F, gpu_device)
+    ea, eb = _engines(F, gpu_device, E=E)
     for training in (False, True):
         pa = ea.forward(gb, training=training, seed=99)
         pb = eb.forward(gb, training=training, seed=99)
         scale = float(pa.abs().max())
         assert float((pa - pb).abs().max()) <= 2e-6 * max(scale, 1.0), (training, float((pa - pb).abs().max()), scale)
     # edge features themselves: interpolation error far below fp32 resolution of the values
+    assert eb.tape.table is not None and not eb.edge_table_report()[0]
     assert float((ea.tape.e - eb.tape.e).abs().max()) <= 1e-6 * max(float(ea.tape.e.abs().max()), 1.0)
     la, da = ea.loss_l2(gb, y, w, pa); lb, db = eb.loss_l2(gb, y, w, pb)
     ea.backward(da); eb.backward(db)
@@ -52,8 +54,8 @@ def test_table_path_matches_the_per_edge_path(gpu_device, F, graphs):
 
 
 def _table_eligible(cfg):
-    """the shapes the fused live-edge kernels (and with them the table path) take: E <= 4 through the fused edge MLP"""
-    return cfg.get("edge_feature_size", 3) <= 4 and cfg.get("edge_hidden_size", 128) == 128 and cfg.get("edge_fc_layers", 4) == 4 \
+    """the shapes the fused live-edge kernels (and with them the table path) take: E <= 8 through the fused edge MLP"""
+    return cfg.get("edge_feature_size", 3) <= 8 and cfg.get("edge_hidden_size", 128) == 128 and cfg.get("edge_fc_layers", 4) == 4 \
         and cfg.get("fc_activation", "softplus") == "softplus"
 
 
