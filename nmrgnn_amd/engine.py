@@ -36,7 +36,7 @@ def rbf_grid(low, high, count):
 class Tape:
     """activations kept between forward(training=True) and backward()"""
     __slots__ = ("batch", "d_eff", "z_save", "z_layout", "e", "h", "A", "S", "fx", "fs", "g", "drop_mask",
-                 "peaks", "live", "table", "loss", "dpeaks", "dg", "head_partial")
+                 "peaks", "live", "table", "table_sync", "loss", "dpeaks", "dg", "head_partial")
 
 
 class Engine:
@@ -90,6 +90,9 @@ class Engine:
         # per call, so code that writes into parameter views directly stays correct.
         self.cache_images = False
         self.defer_reductions = True      # backward(): queue the weight-gradient sums, one launch (ng_defer_reductions)
+        # edge shapes without the fused live-edge kernels (edge_hidden_size != 128, ...): the same table, its guard read on the
+        # HOST (one synchronisation per call: nothing on the device can gate the layered kernels) — False / NG_EDGE_TABLE_SYNC=0: per edge
+        self.edge_table_sync = os.environ.get("NG_EDGE_TABLE_SYNC", "1") != "0"
         # forward(loss=...): head + L2 loss + head backward as one launch where the shape allows (ng_head_loss_bwd)
         self.fuse_head_loss = os.environ.get("NG_HEAD_LOSS", "1") != "0"
         # padded slots (edges == 0) are skipped by the fused edge kernels (include/nmrgnn_hip.h: ng_edge_mlp_fwd_live);
@@ -208,13 +211,26 @@ class Engine:
         # the table of the edge function and the guard's verdict (device words) — before the per-edge launch, which runs over
         # gate[1] rows: none unless the guard is up
         table = self._edge_table_build(batch, live, d_eff, tape, training) if (use_table and live is not None) else None
-        z_save = self._new(self.Le - 1, ne, H) if tape else None
+        table_sync = None
+        if (table is None and live is None and self.edge_table and self.edge_table_sync and not live_ok and not batch.is_csr
+                and E <= 8 and ne >= self.edge_table_min_edges and ne * E * 4 < (1 << 31)
+                and not torch.cuda.is_current_stream_capturing()):
+            table_sync = self._edge_table_build_sync(batch, d_src, d_eff, tape)      # None: the guard is up
+        if table_sync is not None:
+            z_save, z_layout = None, 0
+            e = self._new(ne, E)
+            self._ck(lib.ng_edge_table_interp(h, st, ne, E, table_sync["T"], ptr(batch.edges), ptr(d_eff), None,
+                                              ptr(table_sync["rng"]), ptr(table_sync["e_all"]), ptr(table_sync["gate"]), ptr(e)),
+                     "ng_edge_table_interp")
+        z_save = self._new(self.Le - 1, ne, H) if (tape and table_sync is None) else None
         # element order of the tape the edge forward is about to write (it depends on the NG_EDGE_* switches in force
         # NOW; the backward is told, so a switch flipped in between cannot make it misread the tape)
-        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if tape else 0
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, ne)) if (tape and table_sync is None) else 0
         W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
         B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
-        if live is not None:
+        if table_sync is not None:
+            pass            # e came from the table
+        elif live is not None:
             e = self._new(ne, E)
             rows = table["gate"][1:] if table is not None else n_live
             self._ck(lib.ng_edge_mlp_fwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_src), ptr(d_eff), ptr(perm),
@@ -320,6 +336,7 @@ class Engine:
             tp.z_layout = z_layout
             tp.live = live
             tp.table = table
+            tp.table_sync = table_sync
             tp.h, tp.A, tp.S, tp.fx, tp.fs, tp.g, tp.drop_mask, tp.peaks = hs, As, Ss, fx, fs, g, mask, peaks
             self.tape = tp
         return peaks
@@ -378,10 +395,53 @@ class Engine:
             self._table_cache = {"key": (self._wgen, T, E), "e_all": e_all, "rng": rng, "gate": gate}
         return tb
 
+    def _edge_table_build_sync(self, batch, d_src, d_eff, tape):
+        """The table for an edge shape WITHOUT the fused live-edge kernels (layered edge MLP: any hidden size / depth): the same
+        passes on the every-slot entry points, and the guard's verdict read on the host — one synchronisation per call instead
+        of the device-side gate (nothing on the device can make the layered kernels skip themselves).  None: the guard is up,
+        the caller evaluates the MLP per edge as before."""
+        lib, h, st = self.lib, self.ctx.handle, self._st()
+        P = self.params
+        ne, E, H, T = batch.n_edges, self.E, self.H, self._table_points()
+        tol = -1.0 if self.edge_table_force_fallback else float(self.edge_table_tol)
+        rng = self._new(4)
+        self._ck(lib.ng_edge_table_range(h, st, ne, E, ptr(d_src), ptr(d_eff), None, None, 0.0, ptr(rng)), "ng_edge_table_range")
+        d_tab, ones = self._new(2 * T), self._new(2 * T)
+        self._ck(lib.ng_edge_table_points(h, st, T, 1, ptr(rng), ptr(d_tab), ptr(ones), None), "ng_edge_table_points")
+        e_all = self._new(2 * T, E)
+        z_tab = self._new(self.Le - 1, 2 * T, H) if tape else None
+        z_layout = int(lib.ng_edge_tape_layout(H, E, self.Le, self.fc_act, 2 * T)) if tape else 0
+        W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
+        B = [P[f"edge_fc/{t}/bias"] for t in range(self.Le)]
+        self._ck(lib.ng_edge_mlp_fwd(h, st, 2 * T, H, E, self.Le, self.fc_act, ptr(ones), ptr(d_tab), ptr(self.centers), self.gap,
+                                     ptr_array(W), ptr_array(B), ptr(e_all), ptr(z_tab)), "ng_edge_mlp_fwd")
+        gate = torch.empty(8, dtype=torch.int32, device=self.device)
+        self._ck(lib.ng_edge_table_check(h, st, T, E, ptr(e_all), tol, ptr(rng), None, None, 2 * T, None, ptr(gate)),
+                 "ng_edge_table_check")
+        if int(gate[0].item()) != 0:          # the one host round trip of this path
+            return None
+        return {"e_all": e_all, "rng": rng, "gate": gate, "T": T, "d_tab": d_tab, "ones": ones, "z_tab": z_tab, "z_layout": z_layout}
+
+    def _edge_table_backward_sync(self, tp, de):
+        """edge-weight gradients of a call answered by the host-guarded table: scatter de onto the table, the layered backward on
+        its 2T rows"""
+        lib, h, st = self.lib, self.ctx.handle, self._st()
+        P, tb, b = self.params, tp.table_sync, tp.batch
+        ne, E, H, T = b.n_edges, self.E, self.H, tb["T"]
+        W = [P[f"edge_fc/{t}/kernel"] for t in range(self.Le)]
+        dW = [P.g(f"edge_fc/{t}/kernel") for t in range(self.Le)]
+        dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
+        de_tab = self._new(2 * T, E)
+        self._ck(lib.ng_edge_table_scatter(h, st, ne, E, T, 2 * T, ptr(b.edges), ptr(tp.d_eff), None, ptr(tb["rng"]), ptr(de),
+                                           ptr(de_tab)), "ng_edge_table_scatter")
+        self._ck(lib.ng_edge_mlp_bwd_tape(h, st, 2 * T, H, E, self.Le, self.fc_act, ptr(tb["ones"]), ptr(tb["d_tab"]),
+                                          ptr(self.centers), self.gap, ptr_array(W), ptr(tb["z_tab"]), ptr(de_tab),
+                                          ptr_array(dW), ptr_array(dB), tb["z_layout"]), "ng_edge_mlp_bwd")
+
     def edge_table_report(self, table=None):
         """(guard up?, interpolation error at the midpoints, largest |e| of the table) of the last taped call's table (or of
         ``table``).  Reads device words: synchronises; for tests and diagnostics."""
-        tb = table if table is not None else (self.tape.table if self.tape is not None else None)
+        tb = table if table is not None else ((self.tape.table or self.tape.table_sync) if self.tape is not None else None)
         if tb is None:
             return None
         g = tb["gate"].cpu().numpy()
@@ -512,6 +572,8 @@ class Engine:
         dB = [P.g(f"edge_fc/{t}/bias") for t in range(self.Le)]
         if getattr(tp, "table", None) is not None:
             self._edge_table_backward(tp, de)
+        elif tp.table_sync is not None:
+            self._edge_table_backward_sync(tp, de)
         elif tp.live is not None:
             perm, _, d_c, n_live = tp.live
             self._ck(lib.ng_edge_mlp_bwd_live(h, st, ne, H, E, self.Le, self.fc_act, ptr(d_c), ptr(tp.d_eff), ptr(perm),

@@ -185,3 +185,46 @@ def test_table_is_kept_over_calls_while_the_weights_are_frozen(gpu_device):
     pa, pb = ea.forward(batches[0]), eb.forward(batches[0])
     assert id(eb._table_cache["e_all"]) != built[0]
     assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("cfg", [dict(atom_feature_size=32, edge_feature_size=2, edge_hidden_size=64, mp_layers=2, fc_layers=3, edge_fc_layers=3),
+                                 dict(atom_feature_size=64, edge_feature_size=8, edge_hidden_size=32, mp_layers=2, fc_layers=2, edge_fc_layers=5),
+                                 dict(atom_feature_size=64, edge_feature_size=3, edge_hidden_size=256, mp_layers=1, fc_layers=2, edge_fc_layers=2)])
+def test_host_guarded_table_for_edge_shapes_without_the_fused_kernels(gpu_device, cfg):
+    """edge_hidden_size != 128 / other depths: the layered edge MLP has no device-gated form, so the table's guard is read on the host
+    (Engine.edge_table_sync): outputs and gradients against the per-edge engine; a forced guard gives the per-edge bits"""
+    from nmrgnn_amd import synth
+    from nmrgnn_amd.engine import Engine
+    from nmrgnn_amd.graph import GraphBatch
+    from nmrgnn_amd.hypers import HyperParameters, declare_gnn_space
+    from helpers import randomize_biases
+    hp = declare_gnn_space(HyperParameters(**cfg))
+    b = synth.make_batch(6, 200, 16, 10, 0.1, seed=21)
+    gb = GraphBatch(b["atoms"], b["nlist"], b["edges"], b["inv_degree"], graph_ptr=b["graph_ptr"], device=gpu_device)
+    y = torch.from_numpy(b["y"]).to(gpu_device); w = torch.from_numpy(b["w"]).to(gpu_device)
+    ea, eb, ec = (Engine(hp, 10, device=gpu_device, seed=8) for _ in range(3))
+    for e in (ea, eb, ec):
+        randomize_biases(e)
+        e.edge_table_min_edges = 0
+    ea.edge_table = False
+    ec.edge_table_force_fallback = True
+    assert not ea.lib.ng_edge_live_supported(ea.H, ea.E, ea.Le, ea.fc_act)
+    grads = []
+    for e in (ea, eb, ec):
+        p_inf = e.forward(gb).clone()
+        p = e.forward(gb, training=True, seed=5)
+        used = e.tape.table_sync is not None
+        ee = e.tape.e.clone()
+        l, d = e.loss_l2(gb, y, w, p)
+        e.backward(d)
+        grads.append((p_inf, p.clone(), ee, e.params.grad.clone(), used))
+    torch.cuda.synchronize()
+    (ia, pa, ea_e, ga, ua), (ib, pb, eb_e, gb_, ub), (ic, pc, ec_e, gc, uc) = grads
+    assert not ua and ub and not uc
+    assert torch.equal(ia, ic) and torch.equal(pa, pc) and torch.equal(ga, gc)          # guard forced up: the per-edge call
+    scale = max(float(pa.abs().max()), 1.0)
+    assert float((pa - pb).abs().max()) <= 4e-6 * scale and float((ia - ib).abs().max()) <= 4e-6 * scale
+    assert float((ea_e - eb_e).abs().max()) <= 2e-6 * max(float(ea_e.abs().max()), 1.0)
+    for name in ea.params.offsets:
+        x, z = ea.params.g(name), eb.params.g(name)
+        assert float((x - z).abs().max()) <= 4e-5 * max(float(x.abs().max()), 1e-12), name
